@@ -1,0 +1,62 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+ACTS = ("lrelu", "relu", "softplus")
+REGIMES = {"live": dict(seed=0, gain=2.0, out_bias=0.1), "mixed": dict(seed=0, gain=2.5, out_bias=0.05)}
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+def load_golden(act, regime):
+    return dict(np.load(os.path.join(GOLDEN, f"posendf_{act}_{regime}.npz")))
+
+
+def golden_weights(regime):
+    from posendf_amd import synth
+    return synth.make_weights(**REGIMES[regime])
+
+
+def rel_err(a, b):
+    """Per-pose relative error, the parity metric used throughout (DESIGN.md 'Parity metric'):
+    for every pose (row) max_i |a_i - b_i| / max(max_i |b_i|, tiny); returns the max over poses.
+    For [B,1] distances this is the plain elementwise relative error (exact zeros must match
+    exactly or within 1e-30)."""
+    return float(rel_err_rows(a, b).max())
+
+
+def rel_err_rows(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    a = a.reshape(a.shape[0], -1)
+    b = b.reshape(b.shape[0], -1)
+    num = np.abs(a - b).max(axis=1)
+    den = np.maximum(np.abs(b).max(axis=1), 1e-30)
+    return np.where(num == 0, 0.0, num / den)
+
+
+def d_err(a, b, floor_frac=0.05):
+    """Distance parity metric: |a-b| / max(|b|, floor_frac * max|b|), max over poses.  The floor
+    exists because d = relu(sum of 64 cancelling terms): for poses whose d is far below the batch
+    scale the REFERENCE's own fp32 result is only good to ~1e-4 relative against its fp64 run
+    (tests/golden 'mixed' regime: 9.9e-5), so a purely elementwise 1e-4 gate would fail the
+    reference against itself.  In the 'live' benchmark regime the floor is inactive."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    den = np.maximum(np.abs(b), floor_frac * max(np.abs(b).max(), 1e-30))
+    return float((np.abs(a - b) / den).max())
+
+
+@pytest.fixture(params=[(a, r) for a in ACTS for r in REGIMES], ids=lambda p: f"{p[0]}-{p[1]}")
+def golden_case(request):
+    act, regime = request.param
+    return act, regime, load_golden(act, regime), golden_weights(regime)
