@@ -1,0 +1,97 @@
+/* posendf_amd.h -- C ABI of the MI355X-native Pose-NDF distance / projection engine.
+ *
+ * The reference (garvita-tiwari/PoseNDF) has no FFI layer: its seam is the Python class
+ * PoseNDF(nn.Module) (reference model/posendf.py:30-101) as called from
+ * experiments/sample_poses.py:71-74 and experiments/motion_denoise.py:82.  These entry points are what a
+ * binding for that seam needs (INTEGRATION.md shows the ctypes stub); each cites the reference lines it
+ * replaces.  Plain pointers and sizes only -- no torch types.
+ *
+ * Conventions
+ *   - all tensors are contiguous fp32; poses are [B, 21, 4] = [B, 84] row-major (model/posendf.py:64),
+ *     distances are [B] (the reference's [B, 1]); device pointers must be 16-byte aligned;
+ *   - every call enqueues work on the caller's HIP stream (`stream` is a hipStream_t passed as void*;
+ *     NULL = the default stream) and returns without synchronising;
+ *   - the caller owns every buffer; the engine owns only its packed copy of the weights;
+ *   - return value: 0 on success, a negative pndf_status otherwise; pndf_last_error() has the text;
+ *   - a handle belongs to one device and must not be used from two threads at once.
+ */
+#ifndef POSENDF_AMD_H
+#define POSENDF_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pndf_engine* pndf_handle;
+
+typedef enum {
+    PNDF_OK = 0,
+    PNDF_ERR_BAD_ARG = -1,        /* null / misaligned pointer, negative size */
+    PNDF_ERR_BAD_SHAPE = -2,      /* weight tensor count or shape does not match the architecture */
+    PNDF_ERR_HIP = -3,            /* a HIP runtime call failed (text in pndf_last_error) */
+    PNDF_ERR_UNSUPPORTED = -4,    /* activation / architecture the kernels do not implement */
+    PNDF_ERR_NO_WEIGHTS = -5,     /* compute call before pndf_load_weights */
+    PNDF_ERR_NO_DEVICE = -6       /* no gfx950 device visible */
+} pndf_status;
+
+typedef enum { PNDF_ACT_RELU = 0, PNDF_ACT_LRELU = 1, PNDF_ACT_SOFTPLUS = 2 } pndf_act;
+
+/* Mirrors the keys PoseNDF.__init__ actually reads (reference model/posendf.py:35-55,
+ * model/network/net_modules.py:14-41,116-128; configs/amass.yaml:22-43). */
+typedef struct {
+    int32_t act;            /* pndf_act: model.DFNet.act == model.StrEnc.act */
+    float beta;             /* Softplus beta (amass.yaml:32,43); ignored for relu / lrelu */
+    int32_t num_joints;     /* 21 */
+    int32_t n_dims;         /* 8: in_dim, dims..., 1 */
+    int32_t dims[16];       /* 126,256,512,1024,512,256,64,1 (amass.yaml:26,30) */
+    int32_t parent[32];     /* net_utils.py:46 */
+} pndf_config;
+
+/* Fills cfg with the configs/amass.yaml architecture and the SMPL parent table. */
+void pndf_default_config(pndf_config* cfg, int32_t act, float beta);
+
+/* PoseNDF(opt) + .to(device) (model/posendf.py:32-55; sample_poses.py:88,93). */
+int pndf_create(pndf_handle* out, const pndf_config* cfg, int device);
+int pndf_destroy(pndf_handle h);
+
+/* load_state_dict (sample_poses.py:90-91).  `tensors` are HOST pointers in state-dict order:
+ * for i in 0..20: enc.net.i.net.0.weight [10,in], .bias [10], enc.net.i.net.2.weight [6,10], .bias [6];
+ * then for l in 0..6: dfnet.lin{l}.weight [out,in] row-major, .bias [out]   (98 tensors).
+ * `numel[i]` is checked against the architecture.  Weights are re-packed into MFMA tile order and
+ * uploaded; the call synchronises. */
+int pndf_load_weights(pndf_handle h, const float* const* tensors, const int64_t* numel, int n_tensors);
+
+/* PoseNDF.forward(pose, train=False)['dist_pred'] (model/posendf.py:62-76,100-101). */
+int pndf_forward(pndf_handle h, const float* q, float* d, int64_t B, void* stream);
+
+/* forward + torch.autograd.grad(d, q, grad_outputs) (model/posendf.py:18-27; sample_poses.py:71-73;
+ * motion_denoise.py:82-83,97-98).  dq[b] = grad_out[b] * d d_b / d q_b; grad_out == NULL means ones. */
+int pndf_forward_grad(pndf_handle h, const float* q, const float* grad_out, float* d, float* dq,
+                      int64_t B, void* stream);
+
+/* The projection loop of experiments/sample_poses.py:67-74: `steps` times q <- q - d(q) * grad d(q), in one
+ * persistent launch.  q_out may alias q_in.  d_last[b] (may be NULL) is dist_pred of the last iteration. */
+int pndf_project(pndf_handle h, const float* q_in, float* q_out, float* d_last, int64_t B, int steps,
+                 void* stream);
+
+/* Bring-up aid: forward_grad on the first 64 poses with per-stage register dumps of workgroup 0.
+ * `dump` is a device buffer of pndf_debug_floats() floats. */
+int pndf_debug_forward_grad(pndf_handle h, const float* q, float* d, float* dq, int64_t B, float* dump,
+                            void* stream);
+int64_t pndf_debug_floats(void);
+
+/* Host-only weight packer (what pndf_load_weights uploads); needs no device.  Output sizes in floats come
+ * from pndf_packed_sizes.  Used by the CPU tests that check the MFMA tile order against a lane-level model. */
+void pndf_packed_sizes(int64_t* stream_floats, int64_t* enc_floats, int64_t* bias_floats);
+int pndf_pack_host(const float* const* tensors, const int64_t* numel, int n_tensors, float* stream,
+                   float* enc, float* bias);
+
+const char* pndf_last_error(pndf_handle h);   /* h may be NULL: last error of a failed pndf_create */
+const char* pndf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSENDF_AMD_H */

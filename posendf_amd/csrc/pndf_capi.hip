@@ -1,0 +1,275 @@
+// C ABI of the Pose-NDF engine (include/posendf_amd.h): handle management, weight packing, launches.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/posendf_amd.h"
+#include "pndf_layout.h"
+
+using namespace pndf;
+
+// must match pndf_kernel.hip
+struct PndfKernelArgs {
+    const float* q_in;
+    float* q_out;
+    float* d_out;
+    const float* grad_out;
+    const char* stream;
+    const float* enc;
+    const float* bias;
+    float* dbg;
+    long long B;
+    int steps;
+    int mode;
+    float slope;
+};
+extern "C" __global__ void pndf_fused_relu_kernel(PndfKernelArgs args);
+extern "C" __global__ void pndf_fused_relu_kernel_dbg(PndfKernelArgs args);
+extern "C" int pndf_kernel_lds_bytes();
+extern "C" int pndf_kernel_dbg_floats();
+
+enum { MODE_FORWARD = 0, MODE_FORWARD_GRAD = 1, MODE_PROJECT = 2 };
+
+struct pndf_engine {
+    pndf_config cfg;
+    int device = 0;
+    bool have_weights = false;
+    char* d_stream = nullptr;   // STEP_TILES KiB
+    float* d_enc = nullptr;
+    float* d_bias = nullptr;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(pndf_engine* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(h, PNDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char* pndf_version(void) { return "posendf_amd 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
+
+extern "C" const char* pndf_last_error(pndf_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+extern "C" void pndf_default_config(pndf_config* cfg, int32_t act, float beta) {
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->act = act;
+    cfg->beta = beta;
+    cfg->num_joints = NJ;
+    cfg->n_dims = NLIN + 1;
+    for (int i = 0; i <= NLIN; ++i) cfg->dims[i] = DIMS[i];
+    for (int i = 0; i < NJ; ++i) cfg->parent[i] = PARENT[i];
+}
+
+static int check_config(pndf_engine* h, const pndf_config* cfg) {
+    if (!cfg) return fail(h, PNDF_ERR_BAD_ARG, "cfg is null");
+    if (cfg->num_joints != NJ || cfg->n_dims != NLIN + 1)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "only the 21-joint, 7-layer configs/amass.yaml architecture is implemented");
+    for (int i = 0; i <= NLIN; ++i)
+        if (cfg->dims[i] != DIMS[i])
+            return fail(h, PNDF_ERR_UNSUPPORTED, "DFNet dims must be 126,256,512,1024,512,256,64,1 (StrEnc.use=True)");
+    for (int i = 0; i < NJ; ++i)
+        if (cfg->parent[i] != PARENT[i]) return fail(h, PNDF_ERR_UNSUPPORTED, "parent table must be get_parent_mapping('smpl')");
+    if (cfg->act != PNDF_ACT_RELU && cfg->act != PNDF_ACT_LRELU)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "activation not implemented by the HIP kernels (relu and lrelu are)");
+    return PNDF_OK;
+}
+
+extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device) {
+    if (!out) return fail(nullptr, PNDF_ERR_BAD_ARG, "out is null");
+    *out = nullptr;
+    int rc = check_config(nullptr, cfg);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+        return fail(nullptr, PNDF_ERR_NO_DEVICE, "no HIP device " + std::to_string(device) + " (the engine has no CPU fallback)");
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, PNDF_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    pndf_engine* h = new pndf_engine();
+    h->cfg = *cfg;
+    h->device = device;
+    HIP_TRY(nullptr, hipSetDevice(device));
+    hipError_t e = hipMalloc((void**)&h->d_stream, (size_t)STEP_TILES * TILE_BYTES);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_enc, ENC_FLOATS * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias, BIAS_FLOATS * sizeof(float));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)pndf_fused_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)pndf_fused_relu_kernel_dbg, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
+    if (e != hipSuccess) {
+        std::string m = std::string("pndf_create: ") + hipGetErrorString(e);
+        pndf_destroy(h);
+        return fail(nullptr, PNDF_ERR_HIP, m);
+    }
+    *out = h;
+    return PNDF_OK;
+}
+
+extern "C" int pndf_destroy(pndf_handle h) {
+    if (!h) return PNDF_OK;
+    (void)hipSetDevice(h->device);
+    if (h->d_stream) (void)hipFree(h->d_stream);
+    if (h->d_enc) (void)hipFree(h->d_enc);
+    if (h->d_bias) (void)hipFree(h->d_bias);
+    delete h;
+    return PNDF_OK;
+}
+
+// ------------------------------------------------------------------------------------------ packing
+namespace {
+
+struct Mat {          // logical matrix view M[r][c] of dfnet.lin{l}.weight, optionally transposed, zero padded
+    const float* w;   // (out, in) row-major
+    int out, in;
+    bool transposed;
+    float at(int r, int c) const {
+        const int o = transposed ? c : r, i = transposed ? r : c;
+        return (o < out && i < in) ? w[(size_t)o * in + i] : 0.f;
+    }
+};
+
+// tile(M, nt, kt)[lane*4 + s] = M[16 nt + (lane & 15)][16 kt + 4 (lane >> 4) + s]   (pndf_layout.h)
+void emit_tile(const Mat& m, int nt, int kt, float* dst) {
+    for (int lane = 0; lane < 64; ++lane)
+        for (int s = 0; s < 4; ++s) dst[lane * 4 + s] = m.at(16 * nt + (lane & 15), 16 * kt + 4 * (lane >> 4) + s);
+}
+
+}  // namespace
+
+extern "C" void pndf_packed_sizes(int64_t* stream_floats, int64_t* enc_floats, int64_t* bias_floats) {
+    if (stream_floats) *stream_floats = (int64_t)STEP_TILES * TILE_FLOATS;
+    if (enc_floats) *enc_floats = ENC_FLOATS;
+    if (bias_floats) *bias_floats = BIAS_FLOATS;
+}
+
+static const char* check_tensors(const float* const* tensors, const int64_t* numel, int n) {
+    if (!tensors || !numel) return "tensors / numel is null";
+    if (n != 4 * NJ + 2 * NLIN) return "expected 98 tensors in state-dict order";
+    int t = 0;
+    for (int j = 0; j < NJ; ++j) {
+        const int64_t want[4] = {HID * enc_in(j), HID, FEAT * HID, FEAT};
+        for (int k = 0; k < 4; ++k, ++t)
+            if (!tensors[t] || numel[t] != want[k]) return "encoder tensor missing or of the wrong size";
+    }
+    for (int l = 0; l < NLIN; ++l) {
+        if (!tensors[t] || numel[t] != (int64_t)DIMS[l + 1] * DIMS[l]) return "dfnet weight missing or of the wrong size";
+        ++t;
+        if (!tensors[t] || numel[t] != DIMS[l + 1]) return "dfnet bias missing or of the wrong size";
+        ++t;
+    }
+    return nullptr;
+}
+
+extern "C" int pndf_pack_host(const float* const* tensors, const int64_t* numel, int n_tensors, float* stream,
+                              float* enc, float* bias) {
+    if (check_tensors(tensors, numel, n_tensors) || !stream || !enc || !bias) return PNDF_ERR_BAD_SHAPE;
+    // ---- encoder block: per joint W1[10][in] | b1[10] +2 | W2[6][10] | b2[6] +2
+    memset(enc, 0, ENC_FLOATS * sizeof(float));
+    for (int j = 0; j < NJ; ++j) {
+        float* e = enc + enc_off(j);
+        memcpy(e, tensors[4 * j + 0], sizeof(float) * HID * enc_in(j));
+        memcpy(e + enc_b1(j), tensors[4 * j + 1], sizeof(float) * HID);
+        memcpy(e + enc_w2(j), tensors[4 * j + 2], sizeof(float) * FEAT * HID);
+        memcpy(e + enc_b2(j), tensors[4 * j + 3], sizeof(float) * FEAT);
+    }
+    // ---- bias block: b0..b5 | w6 | b6
+    memset(bias, 0, BIAS_FLOATS * sizeof(float));
+    const float* const* lin = tensors + 4 * NJ;
+    for (int l = 0; l < NLIN - 1; ++l) memcpy(bias + BIAS_OFF[l], lin[2 * l + 1], sizeof(float) * DIMS[l + 1]);
+    memcpy(bias + W6_OFF, lin[2 * (NLIN - 1)], sizeof(float) * DIMS[NLIN - 1]);
+    bias[BIAS_OFF[NLIN - 1]] = lin[2 * (NLIN - 1) + 1][0];
+    // ---- trunk stream: tiles in the exact order run_phase consumes them
+    float* dst = stream;
+    for (int ph = 0; ph < 6; ++ph) {
+        const Phase& P = PHASES[ph];
+        const Mat A{lin[2 * P.a_lin], DIMS[P.a_lin + 1], DIMS[P.a_lin], P.transposed};
+        const Mat B{lin[2 * P.b_lin], DIMS[P.b_lin + 1], DIMS[P.b_lin], P.transposed};
+        for (int c = 0; c < P.NC; ++c) {
+            for (int kt = 0; kt < P.KA; ++kt)                       // part A: (kt, ci)
+                for (int ci = 0; ci < P.CT; ++ci, dst += TILE_FLOATS) emit_tile(A, c * P.CT + ci, kt, dst);
+            for (int nbp = 0; nbp < P.NB / 2; ++nbp)                // part B: (nbp, ci, h)
+                for (int ci = 0; ci < P.CT; ++ci)
+                    for (int hh = 0; hh < 2; ++hh, dst += TILE_FLOATS) emit_tile(B, 2 * nbp + hh, c * P.CT + ci, dst);
+        }
+    }
+    return (dst - stream == (ptrdiff_t)STEP_TILES * TILE_FLOATS) ? PNDF_OK : PNDF_ERR_BAD_SHAPE;
+}
+
+extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, const int64_t* numel, int n_tensors) {
+    if (!h) return PNDF_ERR_BAD_ARG;
+    if (const char* why = check_tensors(tensors, numel, n_tensors)) return fail(h, PNDF_ERR_BAD_SHAPE, why);
+    std::vector<float> stream((size_t)STEP_TILES * TILE_FLOATS), enc(ENC_FLOATS), bias(BIAS_FLOATS);
+    if (pndf_pack_host(tensors, numel, n_tensors, stream.data(), enc.data(), bias.data()) != PNDF_OK)
+        return fail(h, PNDF_ERR_BAD_SHAPE, "internal: packed stream length mismatch");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());   // no launch may still be reading the old weights
+    HIP_TRY(h, hipMemcpy(h->d_stream, stream.data(), stream.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_enc, enc.data(), enc.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->have_weights = true;
+    return PNDF_OK;
+}
+
+// ------------------------------------------------------------------------------------------ launches
+static int launch(pndf_engine* h, int mode, const float* q, const float* gout, float* qo, float* d, int64_t B,
+                  int steps, float* dbg, void* stream) {
+    if (!h) return PNDF_ERR_BAD_ARG;
+    if (!h->have_weights) return fail(h, PNDF_ERR_NO_WEIGHTS, "pndf_load_weights has not been called");
+    if (B < 0 || steps < 0) return fail(h, PNDF_ERR_BAD_ARG, "negative batch or step count");
+    if (B == 0) return PNDF_OK;
+    if (!q || (mode != MODE_FORWARD && !qo) || (mode == MODE_FORWARD && !d))
+        return fail(h, PNDF_ERR_BAD_ARG, "null pose / output pointer");
+    if (((uintptr_t)q | (uintptr_t)qo) & 15) return fail(h, PNDF_ERR_BAD_ARG, "pose buffers must be 16-byte aligned");
+    if (((uintptr_t)d | (uintptr_t)gout) & 3) return fail(h, PNDF_ERR_BAD_ARG, "misaligned distance buffer");
+    PndfKernelArgs a;
+    a.q_in = q; a.q_out = qo; a.d_out = d; a.grad_out = gout;
+    a.stream = h->d_stream; a.enc = h->d_enc; a.bias = h->d_bias; a.dbg = dbg;
+    a.B = B; a.steps = steps; a.mode = mode;
+    a.slope = (h->cfg.act == PNDF_ACT_LRELU) ? 0.01f : 0.0f;   // nn.LeakyReLU() default slope, net_modules.py:31
+    if (mode == MODE_PROJECT && steps == 0) {
+        // zero iterations: the loop body never runs (sample_poses.py:70); poses pass through
+        if (qo != q) HIP_TRY(h, hipMemcpyAsync(qo, q, (size_t)B * NQ * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        if (d) HIP_TRY(h, hipMemsetAsync(d, 0, (size_t)B * sizeof(float), (hipStream_t)stream));
+        return PNDF_OK;
+    }
+    const dim3 grid((unsigned)((B + WG_POSES - 1) / WG_POSES)), block(WG_THREADS);
+    if (dbg) hipLaunchKernelGGL(pndf_fused_relu_kernel_dbg, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(pndf_fused_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+    HIP_TRY(h, hipGetLastError());
+    return PNDF_OK;
+}
+
+extern "C" int pndf_forward(pndf_handle h, const float* q, float* d, int64_t B, void* stream) {
+    return launch(h, MODE_FORWARD, q, nullptr, nullptr, d, B, 1, nullptr, stream);
+}
+
+extern "C" int pndf_forward_grad(pndf_handle h, const float* q, const float* grad_out, float* d, float* dq,
+                                 int64_t B, void* stream) {
+    return launch(h, MODE_FORWARD_GRAD, q, grad_out, dq, d, B, 1, nullptr, stream);
+}
+
+extern "C" int pndf_project(pndf_handle h, const float* q_in, float* q_out, float* d_last, int64_t B, int steps,
+                            void* stream) {
+    return launch(h, MODE_PROJECT, q_in, nullptr, q_out, d_last, B, steps, nullptr, stream);
+}
+
+extern "C" int64_t pndf_debug_floats(void) { return pndf_kernel_dbg_floats(); }
+
+extern "C" int pndf_debug_forward_grad(pndf_handle h, const float* q, float* d, float* dq, int64_t B, float* dump,
+                                       void* stream) {
+    if (!dump) return fail(h, PNDF_ERR_BAD_ARG, "dump is null");
+    return launch(h, MODE_FORWARD_GRAD, q, nullptr, dq, d, B, 1, dump, stream);
+}

@@ -1,0 +1,639 @@
+// Fused Pose-NDF distance / gradient / projection kernel for gfx950 (MI355X, CDNA4), exact fp32.
+//
+// One workgroup = 4 waves = 64 poses; one wave = 16 poses, one wave per SIMD, whole 512-register file.
+// Per projection step (reference experiments/sample_poses.py:70-74) a wave runs, entirely on chip:
+//   normalise over joints (model/posendf.py:71) -> 21 BoneMLPs along the kinematic tree
+//   (model/network/net_modules.py:162-169; VALU, weights via scalar loads) -> trunk forward
+//   (net_modules.py:46-72; v_mfma_f32_16x16x4_f32, activations resident in registers, weights streamed
+//   global -> LDS by DMA) -> d -> trunk backward (same MFMA, transposed weight tiles) -> encoder backward
+//   -> normalise backward -> q <- q - d * grad.
+// See pndf_layout.h for the register/tile layout and DESIGN.md for the roofline.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pndf_layout.h"
+
+using namespace pndf;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PNDF_GLOBAL __attribute__((address_space(1)))
+#define PNDF_LDS __attribute__((address_space(3)))
+
+namespace {
+
+constexpr int SLOT_BYTES = SLOT_TILES * TILE_BYTES;          // 16 KiB
+// LDS carve.  Every region is addressed as (one base register) + (16-bit immediate): hundreds of distinct
+// constant LDS addresses above 64 KiB would each be materialised in an SGPR, hoisted out of the step loop
+// and spilled.  The DMA ring sits at the bottom so that its M0 base stays below 64 KiB.
+constexpr int FSTRIDE = 132;                                 // floats per pose in the feature buffer (bank skew)
+constexpr int RING_SLOTS = 3;
+constexpr int LDS_RING = 0;                                  // 3 slots of 16 KiB (DMA target, lowest addresses)
+constexpr int LDS_ENC = LDS_RING + RING_SLOTS * SLOT_BYTES;  // ENC_FLOATS floats
+constexpr int LDS_BIAS = LDS_ENC + ENC_FLOATS * 4;           // BIAS_FLOATS floats
+constexpr int LDS_MASK = LDS_BIAS + BIAS_FLOATS * 4;         // u16 [MASK_CHUNKS][256]; aliased by GN after the trunk
+constexpr int LDS_GN = LDS_MASK;                             // float [64][84]  d d / d n per pose
+constexpr int LDS_Q = LDS_MASK + MASK_CHUNKS * WG_THREADS * 2;   // float [64][84]  the pose tile
+constexpr int LDS_F = LDS_Q + WG_POSES * NQ * 4;             // float [64][FSTRIDE]  features, then d d / d feature
+constexpr int LDS_EM = LDS_F + WG_POSES * FSTRIDE * 4;       // u16 [64][21] encoder derivative bits
+constexpr int LDS_TOTAL = LDS_EM + WG_POSES * NJ * 2;
+static_assert(LDS_BIAS % 16 == 0 && LDS_MASK % 16 == 0 && LDS_Q % 16 == 0 && LDS_F % 16 == 0 &&
+              LDS_EM % 16 == 0 && LDS_ENC % 16 == 0, "16-byte LDS carve");
+static_assert(WG_POSES * NQ * 4 <= MASK_CHUNKS * WG_THREADS * 2, "GN aliases the chunk-mask region");
+static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+
+enum { MODE_FORWARD = 0, MODE_FORWARD_GRAD = 1, MODE_PROJECT = 2 };
+
+// debug dump stage offsets (floats per thread)
+enum {
+    DBG_FEAT = 0, DBG_X2 = 126, DBG_X4 = DBG_X2 + 128, DBG_X6 = DBG_X4 + 128, DBG_D = DBG_X6 + 16,
+    DBG_G4 = DBG_D + 1, DBG_G2 = DBG_G4 + 128, DBG_G0 = DBG_G2 + 128, DBG_GN = DBG_G0 + 32,
+    DBG_DQ = DBG_GN + 84, DBG_TOTAL = DBG_DQ + 84
+};
+
+// Weight ring: 3 slots of 16 tiles.  Slot i lives in buffer i % 3.  The one barrier per slot sits in the
+// MIDDLE of the slot being consumed (tile 8): at that point every wave has left slot i-1, so its buffer
+// can take the DMA of slot i+2, and the DMA of slot i+1 (issued one slot earlier) has landed for everybody.
+// Crossing a slot boundary therefore needs no synchronisation and tile prefetch runs straight through.
+struct Ring {
+    const char* gstream;   // packed weight stream (global)
+    char* smem;
+    int nslots;            // slots per step (wrap point)
+    int next;              // next slot to DMA
+    int cur;               // buffer holding the slot being consumed
+    int wave;              // wave id (uniform)
+    int lane;
+};
+
+// LDS-DMA of one 16 KiB slot: each wave moves 4 tiles (global_load_lds_dwordx4 = 1 KiB per instruction,
+// LDS destination = M0 + lane * 16).  Issued from inline asm on purpose: when hipcc sees the builtin it
+// degrades every `s_waitcnt lgkmcnt(N)` of the tile prefetch to lgkmcnt(0), which serialises ds_read and
+// MFMA.  Consequence (cdna_hip_programming.md 5.7): the compiler does not count these loads, so every
+// consumer-side barrier is preceded by an explicit `s_waitcnt vmcnt(0)`.
+__device__ __forceinline__ void ring_dma(Ring& r, int buf) {
+    const char* src = r.gstream + (size_t)r.next * SLOT_BYTES + r.wave * (4 * TILE_BYTES) + r.lane * 16;
+    const uint32_t lds_base = (uint32_t)(size_t)(PNDF_LDS char*)(r.smem + LDS_RING);
+    const uint32_t dst = lds_base + buf * SLOT_BYTES + r.wave * (4 * TILE_BYTES);
+    uint32_t keep;
+    // the instruction offset applies to BOTH the global and the LDS address, so M0 stays put
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(dst)
+        : "memory");
+    r.next = (r.next + 1 == r.nslots) ? 0 : r.next + 1;
+}
+
+__device__ __forceinline__ void ring_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ void ring_start(Ring& r) {
+    r.next = 0;
+    ring_dma(r, 0);
+    ring_dma(r, 1);
+    r.cur = 2;             // the first slot boundary makes it 0
+}
+
+// tile 0 of a slot: switch buffers (no barrier needed, see above)
+__device__ __forceinline__ void ring_boundary(Ring& r) { r.cur = (r.cur == 2) ? 0 : r.cur + 1; }
+
+// tile 8 of a slot: one barrier, then prefetch two slots ahead into the buffer of the previous slot
+__device__ __forceinline__ void ring_midslot(Ring& r) {
+    ring_wait_dma();
+    __syncthreads();
+    ring_dma(r, (r.cur == 0) ? 2 : r.cur - 1);
+}
+
+__device__ __forceinline__ f32x4 ring_tile(const Ring& r, int t_in_slot) {
+    return *(const f32x4*)(r.smem + LDS_RING + r.cur * SLOT_BYTES + t_in_slot * TILE_BYTES + r.lane * 16);
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// relu family: slope = 0 (relu) or 0.01 (lrelu).  PyTorch conventions: relu'(0) = 0, lrelu'(0) = slope.
+__device__ __forceinline__ float act_relu(float z, float slope, bool& pos) {
+    pos = z > 0.0f;
+    return pos ? z : z * slope;
+}
+
+// One fused layer pair.  xin: KA input tiles (B operands); acc: NB output tiles (accumulators).
+// Forward: chunk accumulators start from the A-layer bias, get the activation, and their sign bits are
+// parked in LDS; backward: chunk accumulators start at 0 and are multiplied by the parked derivative.
+// Weight tiles are consumed in groups of GT = 2 CT tiles; the group after the current one is read from
+// LDS before the current group's MFMAs are issued (hipcc does not software-pipeline this by itself).
+template <int GT, int T0>
+__device__ __forceinline__ void load_group(f32x4 (&a)[GT], Ring& ring) {
+#pragma unroll
+    for (int i = 0; i < GT; ++i) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int t = (T0 + i) % SLOT_TILES;    // compile-time: T0 is a template constant, i unrolled
+        if (t == 0) ring_boundary(ring);
+        if (t == SLOT_TILES / 2) ring_midslot(ring);
+        a[i] = ring_tile(ring, t);
+    }
+}
+
+template <int KA, int CT, int NC, int NB, bool BWD>
+struct PhaseBody {
+    static constexpr int GT = 2 * CT;                 // tiles per group
+    static constexpr int NGA = KA / 2;                // part-A groups (two k-tiles each)
+    static constexpr int NGB = NB / 2;                // part-B groups (two output tiles each)
+    static constexpr int NG = NGA + NGB;
+    static constexpr int CHUNK_TILES = CT * KA + NB * CT;
+    static_assert(CHUNK_TILES % SLOT_TILES == 0, "chunk body must be whole slots");
+    static_assert(KA % 2 == 0 && NB % 2 == 0, "tiles are consumed in pairs");
+
+    // groups GI .. NG-1 of one chunk; `cur` holds group GI's tiles on entry and the next chunk's group 0
+    // (or garbage after the very last group) on exit.
+    template <int GI>
+    static __device__ __forceinline__ void groups(const f32x4 (&xin)[KA], f32x4 (&acc)[NB], f32x4 (&ch)[CT],
+                                                  f32x4 (&cur)[GT], Ring& ring, uint16_t* mask, float slope,
+                                                  int c) {
+        if constexpr (GI < NG) {
+            f32x4 nxt[GT];
+            constexpr int TNEXT = ((GI + 1) * GT) % CHUNK_TILES;
+            if (GI + 1 < NG || c + 1 < NC) load_group<GT, TNEXT>(nxt, ring);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE this group's MFMAs
+            if constexpr (GI < NGA) {
+                // ---- part A: two k-tiles of the chunk rows; tile order (kt, ci)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                        for (int ci = 0; ci < CT; ++ci)
+                            ch[ci] = mfma4(cur[k2 * CT + ci][s], xin[2 * GI + k2][s], ch[ci]);
+                    }
+                }
+                if constexpr (GI == NGA - 1) {
+                    // ---- chunk epilogue
+                    if (!BWD) {
+                        uint32_t bits = 0;
+#pragma unroll
+                        for (int ci = 0; ci < CT; ++ci) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                bool pos;
+                                ch[ci][r] = act_relu(ch[ci][r], slope, pos);
+                                bits |= pos ? (1u << (ci * 4 + r)) : 0u;
+                            }
+                        }
+                        mask[c * WG_THREADS] = (uint16_t)bits;
+                    } else {
+                        const uint32_t bits = mask[c * WG_THREADS];
+#pragma unroll
+                        for (int ci = 0; ci < CT; ++ci) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                ch[ci][r] = ((bits >> (ci * 4 + r)) & 1u) ? ch[ci][r] : ch[ci][r] * slope;
+                        }
+                    }
+                }
+            } else {
+                // ---- part B: two output tiles get this chunk's contribution; tile order (ci, h)
+                constexpr int nbp = GI - NGA;
+#pragma unroll
+                for (int ci = 0; ci < CT; ++ci) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            acc[2 * nbp + h] = mfma4(cur[ci * 2 + h][s], ch[ci][s], acc[2 * nbp + h]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < GT; ++i) cur[i] = nxt[i];
+            groups<GI + 1>(xin, acc, ch, cur, ring, mask, slope, c);
+        }
+    }
+};
+
+template <int KA, int CT, int NC, int NB, bool BWD>
+__device__ __forceinline__ void run_phase(const f32x4 (&xin)[KA], f32x4 (&acc)[NB], Ring& ring,
+                                          const float* biasA, uint16_t* mask, float slope, int g) {
+    using Body = PhaseBody<KA, CT, NC, NB, BWD>;
+    f32x4 cur[Body::GT];
+    load_group<Body::GT, 0>(cur, ring);
+    for (int c = 0; c < NC; ++c) {
+        f32x4 ch[CT];
+#pragma unroll
+        for (int ci = 0; ci < CT; ++ci) {
+            if (!BWD) ch[ci] = *(const f32x4*)(biasA + 16 * (c * CT + ci) + 4 * g);
+            else ch[ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        Body::template groups<0>(xin, acc, ch, cur, ring, mask, slope, c);
+    }
+}
+
+// ------------------------------------------------------------------ encoder (VALU, per lane = per pose)
+// Rolled loop over the 21 joints; all four lane groups of a pose compute the same values (the encoder is
+// 0.2 % of the FLOPs), per-pose state lives in LDS.  Weights are read from LDS at wave-uniform addresses
+// (broadcast).  A fully unrolled register version made hipcc hoist ~3.5k loads and spill.
+__device__ __forceinline__ int enc_block_off(int j) { return j < 3 ? 120 * j : 360 + 180 * (j - 3); }
+
+template <int IN>
+__device__ __forceinline__ void enc_joint_fwd(const float* w, const float (&in)[IN], float (&f)[FEAT],
+                                              uint32_t& bits, float slope) {
+    constexpr int B1 = HID * IN, W2 = B1 + 12, B2 = W2 + FEAT * HID;
+    float h[HID];
+    bits = 0;
+#pragma unroll
+    for (int u = 0; u < HID; ++u) {
+        float z = w[B1 + u];
+#pragma unroll
+        for (int i = 0; i < IN; ++i) z = fmaf(w[u * IN + i], in[i], z);
+        bool pos;
+        h[u] = act_relu(z, slope, pos);
+        bits |= pos ? (1u << u) : 0u;
+    }
+#pragma unroll
+    for (int o = 0; o < FEAT; ++o) {
+        float z = w[B2 + o];
+#pragma unroll
+        for (int u = 0; u < HID; ++u) z = fmaf(w[W2 + o * HID + u], h[u], z);
+        bool pos;
+        f[o] = act_relu(z, slope, pos);
+        bits |= pos ? (1u << (HID + o)) : 0u;
+    }
+}
+
+template <int IN>
+__device__ __forceinline__ void enc_joint_bwd(const float* w, const float (&gfj)[FEAT], float (&gin)[IN],
+                                              uint32_t bits, float slope) {
+    constexpr int W2 = HID * IN + 12;
+    float gz2[FEAT];
+#pragma unroll
+    for (int o = 0; o < FEAT; ++o) gz2[o] = ((bits >> (HID + o)) & 1u) ? gfj[o] : gfj[o] * slope;
+    float gz1[HID];
+#pragma unroll
+    for (int u = 0; u < HID; ++u) {
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < FEAT; ++o) s = fmaf(w[W2 + o * HID + u], gz2[o], s);
+        gz1[u] = ((bits >> u) & 1u) ? s : s * slope;
+    }
+#pragma unroll
+    for (int i = 0; i < IN; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < HID; ++u) s = fmaf(w[u * IN + i], gz1[u], s);
+        gin[i] = s;
+    }
+}
+
+// per-component denominators of F.normalize(pose, dim=1): max(||q[:, c]||_2 over joints, eps)
+__device__ __forceinline__ void joint_axis_norms(const float* my_q, float (&ss)[4]) {
+    ss[0] = ss[1] = ss[2] = ss[3] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const f32x4 v = *(const f32x4*)(my_q + 4 * j);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ss[c] = fmaf(v[c], v[c], ss[c]);
+    }
+}
+
+__device__ __forceinline__ void encoder_forward(const float* ew, const float* my_q, float* my_f,
+                                                uint16_t* my_em, const int* parent, float slope) {
+    float ss[4], denom[4];
+    joint_axis_norms(my_q, ss);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) denom[c] = fmaxf(sqrtf(ss[c]), 1e-12f);
+    for (int j = 0; j < NJ; ++j) {
+        const f32x4 qj = *(const f32x4*)(my_q + 4 * j);
+        const float* w = ew + enc_block_off(j);
+        float f[FEAT];
+        uint32_t bits;
+        if (j < 3) {
+            float in[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) in[c] = qj[c] / denom[c];
+            enc_joint_fwd<4>(w, in, f, bits, slope);
+        } else {
+            float in[10];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) in[c] = qj[c] / denom[c];
+            const float* pf = my_f + FEAT * parent[j];     // cat(quat, parent feature), net_modules.py:167
+#pragma unroll
+            for (int i = 0; i < FEAT; ++i) in[4 + i] = pf[i];
+            enc_joint_fwd<10>(w, in, f, bits, slope);
+        }
+#pragma unroll
+        for (int i = 0; i < FEAT; ++i) my_f[FEAT * j + i] = f[i];
+        my_em[j] = (uint16_t)bits;
+    }
+    my_f[126] = 0.f;
+    my_f[127] = 0.f;
+}
+
+// consumes d d / d feature in my_f (accumulating into parents), leaves d d / d n in my_gn
+__device__ __forceinline__ void encoder_backward(const float* ew, float* my_f, float* my_gn,
+                                                 const uint16_t* my_em, const int* parent, float slope) {
+    for (int j = NJ - 1; j >= 0; --j) {
+        const float* w = ew + enc_block_off(j);
+        const uint32_t bits = my_em[j];
+        float gfj[FEAT];
+#pragma unroll
+        for (int i = 0; i < FEAT; ++i) gfj[i] = my_f[FEAT * j + i];
+        if (j < 3) {
+            float gin[4];
+            enc_joint_bwd<4>(w, gfj, gin, bits, slope);
+            *(f32x4*)(my_gn + 4 * j) = f32x4{gin[0], gin[1], gin[2], gin[3]};
+        } else {
+            float gin[10];
+            enc_joint_bwd<10>(w, gfj, gin, bits, slope);
+            *(f32x4*)(my_gn + 4 * j) = f32x4{gin[0], gin[1], gin[2], gin[3]};
+            float* pf = my_f + FEAT * parent[j];
+#pragma unroll
+            for (int i = 0; i < FEAT; ++i) pf[i] += gin[4 + i];
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void load_bias(f32x4 (&acc)[NT], const float* bias, int g) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = *(const f32x4*)(bias + 16 * t + 4 * g);
+}
+
+// activation of an accumulator layer; derivative bits kept in registers (NT*4 bits)
+template <int NT>
+__device__ __forceinline__ void act_tiles(f32x4 (&x)[NT], uint32_t (&m)[(NT * 4 + 31) / 32], float slope) {
+#pragma unroll
+    for (int w = 0; w < (NT * 4 + 31) / 32; ++w) m[w] = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bool pos;
+            x[t][r] = act_relu(x[t][r], slope, pos);
+            m[(t * 4 + r) / 32] |= (pos ? 1u : 0u) << ((t * 4 + r) % 32);
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void dact_tiles(f32x4 (&gx)[NT], const uint32_t (&m)[(NT * 4 + 31) / 32], float slope) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            gx[t][r] = ((m[(t * 4 + r) / 32] >> ((t * 4 + r) % 32)) & 1u) ? gx[t][r] : gx[t][r] * slope;
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void dump_tiles(float* dbg, int off, const f32x4 (&x)[NT], int tid) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dbg[(size_t)(off + 4 * t + r) * WG_THREADS + tid] = x[t][r];
+    }
+}
+
+}  // namespace
+
+struct PndfKernelArgs {
+    const float* q_in;      // [B,84]
+    float* q_out;           // [B,84]  projected poses (PROJECT) or dd/dq * grad_out (FORWARD_GRAD)
+    float* d_out;           // [B]
+    const float* grad_out;  // [B] or null (FORWARD_GRAD only)
+    const char* stream;     // packed trunk weights, STEP_TILES KiB
+    const float* enc;       // ENC_FLOATS (padded layout of pndf_layout.h)
+    const float* bias;      // BIAS_FLOATS
+    float* dbg;             // null, or DBG_TOTAL*256 floats written by workgroup 0 (first step)
+    long long B;
+    int steps;
+    int mode;
+    float slope;            // 0 = relu, 0.01 = lrelu
+};
+
+__constant__ int PNDF_PARENT[NJ] = {-1, -1, -1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19};
+
+template <bool DBG>
+__device__ __forceinline__ void pndf_fused_relu_body(const PndfKernelArgs& args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;          // lane group = k_local of the MFMA
+    const int p = lane & 15;          // pose within the wave
+    const int wp = wave * 16 + p;     // pose within the workgroup
+    const float slope = args.slope;
+    const long long pose0 = (long long)blockIdx.x * WG_POSES;
+    float* const ew = (float*)(smem + LDS_ENC);
+    float* const lds_bias = (float*)(smem + LDS_BIAS);
+    uint16_t* const lds_mask = (uint16_t*)(smem + LDS_MASK) + tid;
+    float* const lds_q = (float*)(smem + LDS_Q);
+    float* const my_q = lds_q + wp * NQ;
+    float* const my_f = (float*)(smem + LDS_F) + wp * FSTRIDE;
+    float* const my_gn = (float*)(smem + LDS_GN) + wp * NQ;
+    uint16_t* const my_em = (uint16_t*)(smem + LDS_EM) + wp * NJ;
+    float* const dbg = (DBG && blockIdx.x == 0) ? args.dbg : nullptr;
+
+    Ring ring;
+    ring.gstream = args.stream;
+    ring.smem = smem;
+    ring.nslots = (args.mode == MODE_FORWARD) ? FWD_SLOTS : STEP_SLOTS;
+    ring.wave = wave;
+    ring.lane = lane;
+    ring_start(ring);   // slots 0 and 1 in flight; the __syncthreads() below makes them visible
+
+    // ---- stage encoder weights, biases and this workgroup's poses in LDS (coalesced)
+    for (int i = tid; i < ENC_FLOATS / 4; i += WG_THREADS) ((f32x4*)ew)[i] = ((const f32x4*)args.enc)[i];
+    for (int i = tid; i < BIAS_FLOATS / 4; i += WG_THREADS)
+        ((f32x4*)lds_bias)[i] = ((const f32x4*)args.bias)[i];
+    {
+        long long nvalid = args.B - pose0;
+        if (nvalid > WG_POSES) nvalid = WG_POSES;
+        const f32x4* src = (const f32x4*)(args.q_in + pose0 * NQ);
+        const int nvec = (int)nvalid * (NQ / 4);
+        for (int i = tid; i < WG_POSES * (NQ / 4); i += WG_THREADS) {
+            // poses past the end of the batch replicate the last valid pose (never written back)
+            const int src_i = i < nvec ? i : (nvec - (NQ / 4) + (i % (NQ / 4)));
+            ((f32x4*)lds_q)[i] = src[src_i];
+        }
+    }
+    ring_wait_dma();
+    __syncthreads();
+
+    const int nsteps = (args.mode == MODE_PROJECT) ? args.steps : 1;
+    float dval = 0.f;
+    for (int step = 0; step < nsteps; ++step) {
+        uint32_t m2[4], m4[4], m6[1];
+        f32x4 x6[4];
+        f32x4 x4[32];
+        {
+            f32x4 x2[32];
+            {
+                // ---------------- normalise + encoder forward (posendf.py:71, net_modules.py:162-169)
+                encoder_forward(ew, my_q, my_f, my_em, PNDF_PARENT, slope);
+                if (DBG && dbg && step == 0) {
+                    for (int i = 0; i < NFEAT; ++i) dbg[(size_t)(DBG_FEAT + i) * WG_THREADS + tid] = my_f[i];
+                }
+                // B operands of lin0: lane (g, p) holds features 16 kt + 4 g + s of pose p
+                f32x4 x0[8];
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt) x0[kt] = *(const f32x4*)(my_f + 16 * kt + 4 * g);
+                // ---------------- trunk forward
+                load_bias<32>(x2, lds_bias + BIAS_OFF[1], g);
+                run_phase<8, 2, 8, 32, false>(x0, x2, ring, lds_bias + BIAS_OFF[0],
+                                              lds_mask + MASK_BASE[0] * WG_THREADS, slope, g);
+            }
+            act_tiles<32>(x2, m2, slope);
+            if (DBG && dbg && step == 0) dump_tiles<32>(dbg, DBG_X2, x2, tid);
+            load_bias<32>(x4, lds_bias + BIAS_OFF[3], g);
+            run_phase<32, 2, 32, 32, false>(x2, x4, ring, lds_bias + BIAS_OFF[2],
+                                            lds_mask + MASK_BASE[1] * WG_THREADS, slope, g);
+        }
+        act_tiles<32>(x4, m4, slope);
+        if (DBG && dbg && step == 0) dump_tiles<32>(dbg, DBG_X4, x4, tid);
+        load_bias<4>(x6, lds_bias + BIAS_OFF[5], g);
+        run_phase<32, 4, 4, 4, false>(x4, x6, ring, lds_bias + BIAS_OFF[4],
+                                      lds_mask + MASK_BASE[2] * WG_THREADS, slope, g);
+        act_tiles<4>(x6, m6, slope);
+        if (DBG && dbg && step == 0) dump_tiles<4>(dbg, DBG_X6, x6, tid);
+
+        // ---------------- lin6 (64 -> 1) + output ReLU  (net_modules.py:64-69)
+        f32x4 w6[4];
+        load_bias<4>(w6, lds_bias + W6_OFF, g);
+        float part = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part = fmaf(w6[t][r], x6[t][r], part);
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        const float z7 = part + lds_bias[BIAS_OFF[6]];
+        dval = fmaxf(z7, 0.f);
+        if (DBG && dbg && step == 0) dbg[(size_t)DBG_D * WG_THREADS + tid] = dval;
+        if (args.mode == MODE_FORWARD) break;
+
+        // ---------------- trunk backward: d d / d x, masks from the forward pass
+        float gz7 = (z7 > 0.f) ? 1.f : 0.f;
+        if (args.mode == MODE_FORWARD_GRAD && args.grad_out) {
+            long long pidx = pose0 + wp;
+            if (pidx >= args.B) pidx = args.B - 1;
+            gz7 *= args.grad_out[pidx];
+        }
+        f32x4 g6[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) g6[t] = w6[t] * gz7;
+        dact_tiles<4>(g6, m6, slope);
+        {
+            f32x4 g0[8];
+            {
+                f32x4 g2[32];
+                {
+                    f32x4 g4[32];
+#pragma unroll
+                    for (int t = 0; t < 32; ++t) g4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    run_phase<4, 4, 4, 32, true>(g6, g4, ring, nullptr, lds_mask + MASK_BASE[2] * WG_THREADS, slope, g);
+                    dact_tiles<32>(g4, m4, slope);
+                    if (DBG && dbg && step == 0) dump_tiles<32>(dbg, DBG_G4, g4, tid);
+#pragma unroll
+                    for (int t = 0; t < 32; ++t) g2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    run_phase<32, 2, 32, 32, true>(g4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, slope, g);
+                }
+                dact_tiles<32>(g2, m2, slope);
+                if (DBG && dbg && step == 0) dump_tiles<32>(dbg, DBG_G2, g2, tid);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) g0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                run_phase<32, 2, 8, 8, true>(g2, g0, ring, nullptr, lds_mask + MASK_BASE[0] * WG_THREADS, slope, g);
+            }
+            if (DBG && dbg && step == 0) dump_tiles<8>(dbg, DBG_G0, g0, tid);
+            // d d / d feature back to the per-pose buffer: lane (g, p) owns features 16 t + 4 g + r
+#pragma unroll
+            for (int t = 0; t < 8; ++t) *(f32x4*)(my_f + 16 * t + 4 * g) = g0[t];
+        }
+        // The chunk masks (aliased by GN) are dead for every wave only after all waves have left the last
+        // backward phase; GN/F of a pose are touched by its own wave only.
+        __syncthreads();
+
+        // ---------------- encoder backward + normalise backward + update
+        encoder_backward(ew, my_f, my_gn, my_em, PNDF_PARENT, slope);
+        if (DBG && dbg && step == 0) {
+            for (int i = 0; i < NQ; ++i) dbg[(size_t)(DBG_GN + i) * WG_THREADS + tid] = my_gn[i];
+        }
+        {
+            // backward of x / clamp_min(||x||_joints, eps)  (model/posendf.py:71)
+            float ss[4], dot[4], denom[4], kk[4];
+            ss[0] = ss[1] = ss[2] = ss[3] = 0.f;
+            dot[0] = dot[1] = dot[2] = dot[3] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const f32x4 qv = *(const f32x4*)(my_q + 4 * j);
+                const f32x4 gv = *(const f32x4*)(my_gn + 4 * j);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ss[c] = fmaf(qv[c], qv[c], ss[c]);
+                    dot[c] = fmaf(gv[c], qv[c], dot[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float norm = sqrtf(ss[c]);
+                denom[c] = fmaxf(norm, 1e-12f);
+                kk[c] = (norm > 1e-12f) ? dot[c] / (denom[c] * denom[c] * norm) : 0.f;
+            }
+            // lane group g handles joints g, g+4, ...; results replace the pose tile in LDS
+            for (int j = g; j < NJ; j += 4) {
+                const f32x4 qv = *(const f32x4*)(my_q + 4 * j);
+                const f32x4 gv = *(const f32x4*)(my_gn + 4 * j);
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float dq = gv[c] / denom[c] - qv[c] * kk[c];
+                    if (DBG && dbg && step == 0) dbg[(size_t)(DBG_DQ + 4 * j + c) * WG_THREADS + tid] = dq;
+                    // q <- q - d * grad  (experiments/sample_poses.py:74: product rounded, then subtracted)
+                    o[c] = (args.mode == MODE_PROJECT) ? __fsub_rn(qv[c], __fmul_rn(dval, dq)) : dq;
+                }
+                *(f32x4*)(my_q + 4 * j) = o;
+            }
+        }
+        // GN (aliasing the chunk masks) must be consumed by every wave before the next step's masks land
+        __syncthreads();
+    }
+
+    // ---------------- write back (coalesced)
+    {
+        long long pidx = pose0 + wp;
+        if (g == 0 && pidx < args.B && args.d_out) args.d_out[pidx] = dval;
+    }
+    if (args.mode != MODE_FORWARD) {
+        __syncthreads();
+        long long nvalid = args.B - pose0;
+        if (nvalid > WG_POSES) nvalid = WG_POSES;
+        f32x4* dst = (f32x4*)(args.q_out + pose0 * NQ);
+        const int nvec = (int)nvalid * (NQ / 4);
+        for (int i = tid; i < nvec; i += WG_THREADS) dst[i] = ((const f32x4*)lds_q)[i];
+    }
+    // drain the DMA prefetch that is still in flight before the workgroup's LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1)
+pndf_fused_relu_kernel(PndfKernelArgs args) {
+    pndf_fused_relu_body<false>(args);
+}
+
+// Same kernel with per-stage register dumps from workgroup 0 (tests / bring-up only).
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1)
+pndf_fused_relu_kernel_dbg(PndfKernelArgs args) {
+    pndf_fused_relu_body<true>(args);
+}
+
+extern "C" int pndf_kernel_lds_bytes() { return LDS_TOTAL; }
+extern "C" int pndf_kernel_dbg_floats() { return DBG_TOTAL * WG_THREADS; }

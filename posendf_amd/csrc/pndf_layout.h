@@ -1,0 +1,90 @@
+// Shared host/device description of the packed weight stream consumed by the fused Pose-NDF kernel.
+//
+// The trunk (reference model/network/net_modules.py:46-72, dims configs/amass.yaml:26,30) is executed
+// TRANSPOSED: every wave owns 16 poses and keeps their activations in registers in the MFMA C/D
+// layout of v_mfma_f32_16x16x4_f32 (lane = (g, p): pose p = lane & 15, lane group g = lane >> 4;
+// register r of output tile t holds row 16 t + 4 g + r).  That D layout is exactly the B-operand layout
+// of the next layer's MFMA (k_local = g) provided the A operand (the weights) is fetched with the
+// matching k permutation -- so activations never leave the register file and are never transposed.
+// The only thing that streams is weights: one linear sequence of 1 KiB "tiles", pre-permuted on the
+// host into consumption order, DMA'd global->LDS in 16-tile slots and read with one ds_read_b128 per
+// lane per tile.
+//
+//   tile(M, nt, kt)[lane*4 + s] = M[16 nt + (lane & 15)][16 kt + 4 (lane >> 4) + s]      (M row-major)
+//
+// Layers are fused in pairs ("phases"): phase = (A: K_A -> R_A rows, chunked CT tiles at a time;
+// B: R_A -> N_B rows accumulated in registers), so the wider intermediate (256 / 1024 / 256 wide) is
+// never materialised beyond one chunk.  Backward phases use the transposed matrices.
+#pragma once
+
+namespace pndf {
+
+constexpr int NJ = 21;            // joints, reference net_utils.py:46
+constexpr int NQ = 84;            // 21 x 4 quaternion components
+constexpr int NFEAT = 126;        // 21 x 6 encoder features, net_modules.py:116,125
+constexpr int FEAT = 6;
+constexpr int HID = 10;
+constexpr int NLIN = 7;
+constexpr int DIMS[NLIN + 1] = {126, 256, 512, 1024, 512, 256, 64, 1};
+
+constexpr int TILE_FLOATS = 256;
+constexpr int TILE_BYTES = 1024;
+constexpr int SLOT_TILES = 16;    // tiles per LDS ring slot (16 KiB)
+constexpr int WG_POSES = 64;      // 4 waves x 16 poses
+constexpr int WG_THREADS = 256;
+
+// phase description: A-part K tiles, chunk tiles, number of chunks, B-part output tiles
+struct Phase {
+    int KA, CT, NC, NB;
+    int a_lin, b_lin;       // which dfnet.lin{l} supplies A / B
+    bool transposed;        // backward phases use W^T
+};
+
+// forward: (lin0,lin1) (lin2,lin3) (lin4,lin5); backward: (lin5^T,lin4^T) (lin3^T,lin2^T) (lin1^T,lin0^T)
+constexpr Phase PHASES[6] = {
+    {8, 2, 8, 32, 0, 1, false},
+    {32, 2, 32, 32, 2, 3, false},
+    {32, 4, 4, 4, 4, 5, false},
+    {4, 4, 4, 32, 5, 4, true},
+    {32, 2, 32, 32, 3, 2, true},
+    {32, 2, 8, 8, 1, 0, true},
+};
+
+constexpr int phase_chunk_tiles(const Phase& p) { return p.CT * p.KA + p.NB * p.CT; }
+constexpr int phase_tiles(const Phase& p) { return p.NC * phase_chunk_tiles(p); }
+constexpr int FWD_TILES = phase_tiles(PHASES[0]) + phase_tiles(PHASES[1]) + phase_tiles(PHASES[2]);
+constexpr int BWD_TILES = phase_tiles(PHASES[3]) + phase_tiles(PHASES[4]) + phase_tiles(PHASES[5]);
+constexpr int STEP_TILES = FWD_TILES + BWD_TILES;
+constexpr int FWD_SLOTS = FWD_TILES / SLOT_TILES;
+constexpr int STEP_SLOTS = STEP_TILES / SLOT_TILES;
+static_assert(FWD_TILES % SLOT_TILES == 0 && BWD_TILES % SLOT_TILES == 0, "slot alignment");
+static_assert(phase_chunk_tiles(PHASES[0]) % SLOT_TILES == 0, "chunk bodies are whole slots");
+static_assert(phase_chunk_tiles(PHASES[1]) % SLOT_TILES == 0, "chunk bodies are whole slots");
+static_assert(phase_chunk_tiles(PHASES[2]) % SLOT_TILES == 0, "chunk bodies are whole slots");
+static_assert(FWD_TILES == 5312 && STEP_TILES == 10624, "amass.yaml trunk");
+
+// bias block (floats) copied to LDS: b0..b5, then w6 (64), then b6
+constexpr int BIAS_OFF[NLIN] = {0, 256, 768, 1792, 2304, 2560, 2688};
+constexpr int W6_OFF = 2624;
+constexpr int BIAS_FLOATS = 2692;   // padded to a multiple of 4
+
+// encoder parameter block (floats), 16-byte aligned sub-blocks so that it can be read from LDS with
+// ds_read_b128: per joint W1[10][in] | b1[10] (+2 pad) | W2[6][10] | b2[6] (+2 pad)
+constexpr int PARENT[NJ] = {-1, -1, -1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19};
+constexpr int enc_in(int j) { return PARENT[j] < 0 ? 4 : 10; }
+constexpr int enc_b1(int j) { return HID * enc_in(j); }
+constexpr int enc_w2(int j) { return enc_b1(j) + 12; }
+constexpr int enc_b2(int j) { return enc_w2(j) + FEAT * HID; }
+constexpr int enc_size(int j) { return enc_b2(j) + 8; }
+constexpr int enc_off(int j) { return j == 0 ? 0 : enc_off(j - 1) + enc_size(j - 1); }
+constexpr int ENC_FLOATS = enc_off(NJ - 1) + enc_size(NJ - 1);
+static_assert(ENC_FLOATS == 3 * 120 + 18 * 180, "padded encoder block");
+static_assert(enc_size(0) % 4 == 0 && enc_size(3) % 4 == 0, "16-byte aligned joints");
+
+// chunk-mask slots (one u16 per lane per chunk) for the three chunked layers x1, x3, x5
+constexpr int MASK_BASE[3] = {0, 8, 40};
+constexpr int MASK_CHUNKS = 44;
+
+enum Act { ACT_RELU = 0, ACT_LRELU = 1, ACT_SOFTPLUS = 2 };
+
+}  // namespace pndf

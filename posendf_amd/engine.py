@@ -1,0 +1,145 @@
+"""ctypes binding of libposendf_amd.so (include/posendf_amd.h).
+
+This module is deliberately thin: tensors are passed as raw device pointers (`tensor.data_ptr()`),
+the current HIP stream as an integer handle.  There is NO CPU fallback: if the library is missing the
+import of `Engine` fails loudly, and if no gfx950 device is visible `Engine(...)` raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libposendf_amd.so")
+
+ACT_CODES = {"relu": 0, "lrelu": 1, "softplus": 2}
+
+
+class PndfConfig(ctypes.Structure):
+    _fields_ = [("act", c_int32), ("beta", c_float), ("num_joints", c_int32), ("n_dims", c_int32),
+                ("dims", c_int32 * 16), ("parent", c_int32 * 32)]
+
+
+class PndfError(RuntimeError):
+    pass
+
+
+def load_library(path: str | None = None) -> ctypes.CDLL:
+    path = path or _LIB_PATH
+    if not os.path.exists(path):
+        raise PndfError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). The engine has no fallback path.")
+    lib = ctypes.CDLL(path)
+    H = c_void_p
+    lib.pndf_default_config.argtypes = [POINTER(PndfConfig), c_int32, c_float]
+    lib.pndf_default_config.restype = None
+    lib.pndf_create.argtypes = [POINTER(H), POINTER(PndfConfig), c_int]
+    lib.pndf_destroy.argtypes = [H]
+    lib.pndf_load_weights.argtypes = [H, POINTER(c_void_p), POINTER(c_int64), c_int]
+    lib.pndf_forward.argtypes = [H, c_void_p, c_void_p, c_int64, c_void_p]
+    lib.pndf_forward_grad.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
+    lib.pndf_project.argtypes = [H, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]
+    lib.pndf_debug_forward_grad.argtypes = [H, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
+    lib.pndf_debug_floats.restype = c_int64
+    lib.pndf_packed_sizes.argtypes = [POINTER(c_int64)] * 3
+    lib.pndf_packed_sizes.restype = None
+    lib.pndf_pack_host.argtypes = [POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p, c_void_p, c_void_p]
+    lib.pndf_last_error.argtypes = [H]
+    lib.pndf_last_error.restype = c_char_p
+    lib.pndf_version.restype = c_char_p
+    for name in ("pndf_create", "pndf_destroy", "pndf_load_weights", "pndf_forward", "pndf_forward_grad",
+                 "pndf_project", "pndf_debug_forward_grad", "pndf_pack_host"):
+        getattr(lib, name).restype = c_int
+    return lib
+
+
+EXPORTS = ("pndf_default_config", "pndf_create", "pndf_destroy", "pndf_load_weights", "pndf_forward",
+           "pndf_forward_grad", "pndf_project", "pndf_debug_forward_grad", "pndf_debug_floats",
+           "pndf_packed_sizes", "pndf_pack_host", "pndf_last_error", "pndf_version")
+
+
+def state_dict_order():
+    """Keys in the order pndf_load_weights expects (== reference state_dict order)."""
+    from .synth import state_dict_shapes
+    return list(state_dict_shapes().keys())
+
+
+def _tensor_table(sd_np):
+    keys = state_dict_order()
+    arrs = [np.ascontiguousarray(np.asarray(sd_np[k], dtype=np.float32)) for k in keys]
+    ptrs = (c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    numel = (c_int64 * len(arrs))(*[a.size for a in arrs])
+    return arrs, ptrs, numel
+
+
+def pack_host(sd_np, lib=None):
+    """Host-only packing (no device): returns (stream[STEP_TILES*256], enc, bias) float32 arrays."""
+    lib = lib or load_library()
+    n = [c_int64(), c_int64(), c_int64()]
+    lib.pndf_packed_sizes(*[ctypes.byref(x) for x in n])
+    stream = np.empty(n[0].value, np.float32)
+    enc = np.empty(n[1].value, np.float32)
+    bias = np.empty(n[2].value, np.float32)
+    arrs, ptrs, numel = _tensor_table(sd_np)
+    rc = lib.pndf_pack_host(ptrs, numel, len(arrs), stream.ctypes.data, enc.ctypes.data, bias.ctypes.data)
+    if rc != 0:
+        raise PndfError(f"pndf_pack_host failed ({rc})")
+    return stream, enc, bias
+
+
+class Engine:
+    """One engine per device.  All compute methods take raw device pointers and a stream handle."""
+
+    def __init__(self, act: str = "lrelu", beta: float = 100.0, device: int = 0, lib=None):
+        self.lib = lib or load_library()
+        if act not in ACT_CODES:
+            raise PndfError(f"unknown activation {act!r}")
+        cfg = PndfConfig()
+        self.lib.pndf_default_config(ctypes.byref(cfg), ACT_CODES[act], float(beta))
+        self.handle = c_void_p()
+        rc = self.lib.pndf_create(ctypes.byref(self.handle), ctypes.byref(cfg), int(device))
+        if rc != 0:
+            msg = self.lib.pndf_last_error(None).decode()
+            self.handle = None
+            raise PndfError(f"pndf_create failed ({rc}): {msg}")
+        self.device = device
+        self.act = act
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PndfError(f"{what} failed ({rc}): {self.lib.pndf_last_error(self.handle).decode()}")
+
+    def load_weights(self, sd_np):
+        arrs, ptrs, numel = _tensor_table(sd_np)
+        self._check(self.lib.pndf_load_weights(self.handle, ptrs, numel, len(arrs)), "pndf_load_weights")
+
+    def forward(self, q_ptr, d_ptr, B, stream=0):
+        self._check(self.lib.pndf_forward(self.handle, q_ptr, d_ptr, B, stream), "pndf_forward")
+
+    def forward_grad(self, q_ptr, gout_ptr, d_ptr, dq_ptr, B, stream=0):
+        self._check(self.lib.pndf_forward_grad(self.handle, q_ptr, gout_ptr, d_ptr, dq_ptr, B, stream),
+                    "pndf_forward_grad")
+
+    def project(self, q_in_ptr, q_out_ptr, d_ptr, B, steps, stream=0):
+        self._check(self.lib.pndf_project(self.handle, q_in_ptr, q_out_ptr, d_ptr, B, int(steps), stream),
+                    "pndf_project")
+
+    def debug_forward_grad(self, q_ptr, d_ptr, dq_ptr, B, dump_ptr, stream=0):
+        self._check(self.lib.pndf_debug_forward_grad(self.handle, q_ptr, d_ptr, dq_ptr, B, dump_ptr, stream),
+                    "pndf_debug_forward_grad")
+
+    def debug_floats(self):
+        return int(self.lib.pndf_debug_floats())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.pndf_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,154 @@
+"""Lane-level numpy model of ONE wave of the fused kernel (posendf_amd/csrc/pndf_kernel.hip).
+
+It consumes the REAL packed weight stream produced by the library's host packer (pndf_pack_host) in the
+order the kernel consumes it and applies the documented semantics of v_mfma_f32_16x16x4_f32
+(cdna_hip_programming.md section 3: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+D[row = 4 (lane >> 4) + reg][col = lane & 15]).  It therefore checks, without a GPU, the three things a
+first GPU run would otherwise have to debug at once: the tile permutation, the phase/chunk order of the
+stream, and the claim that the D layout of one layer is the B layout of the next.
+
+Test infrastructure only.
+"""
+import numpy as np
+
+LANES = np.arange(64)
+G = LANES >> 4
+P = LANES & 15
+
+# mirrors pndf_layout.h PHASES: KA, CT, NC, NB
+PHASES = [(8, 2, 8, 32), (32, 2, 32, 32), (32, 4, 4, 4), (4, 4, 4, 32), (32, 2, 32, 32), (32, 2, 8, 8)]
+BIAS_OFF = [0, 256, 768, 1792, 2304, 2560, 2688]
+W6_OFF = 2624
+
+
+def mfma_16x16x4(a, b, c):
+    """a, b: [64] one VGPR each; c: [64,4].  Returns D = A.B + C in the C/D register layout."""
+    A = np.zeros((16, 4), np.float32)
+    B = np.zeros((4, 16), np.float32)
+    A[P, G] = a
+    B[G, P] = b
+    D = (A.astype(np.float64) @ B.astype(np.float64)).astype(np.float32)   # [row, col]
+    out = c.copy()
+    for r in range(4):
+        out[:, r] += D[4 * G + r, P]
+    return out
+
+
+class Stream:
+    def __init__(self, stream):
+        self.t = stream.reshape(-1, 64, 4)
+        self.pos = 0
+
+    def tile(self):
+        t = self.t[self.pos]
+        self.pos += 1
+        return t
+
+
+def run_phase(ph, xin, acc, st, bias_a, masks, slope, bwd):
+    KA, CT, NC, NB = PHASES[ph]
+    for c in range(NC):
+        ch = [np.zeros((64, 4), np.float32) for _ in range(CT)]
+        if not bwd:
+            for ci in range(CT):
+                for r in range(4):
+                    ch[ci][:, r] = bias_a[16 * (c * CT + ci) + 4 * G + r]
+        for kt in range(KA):
+            a = [st.tile() for _ in range(CT)]
+            for s in range(4):
+                for ci in range(CT):
+                    ch[ci] = mfma_16x16x4(a[ci][:, s], xin[kt][:, s], ch[ci])
+        if not bwd:
+            m = []
+            for ci in range(CT):
+                pos = ch[ci] > 0
+                m.append(pos)
+                ch[ci] = np.where(pos, ch[ci], ch[ci] * np.float32(slope))
+            masks[(ph, c)] = m
+        else:
+            m = masks[({3: 2, 4: 1, 5: 0}[ph], c)]
+            for ci in range(CT):
+                ch[ci] = np.where(m[ci], ch[ci], ch[ci] * np.float32(slope))
+        for nbp in range(NB // 2):
+            a = [[st.tile() for _ in range(2)] for _ in range(CT)]
+            for ci in range(CT):
+                for s in range(4):
+                    for h in range(2):
+                        acc[2 * nbp + h] = mfma_16x16x4(a[ci][h][:, s], ch[ci][:, s], acc[2 * nbp + h])
+
+
+def load_bias(bias, off, nt):
+    out = []
+    for t in range(nt):
+        x = np.zeros((64, 4), np.float32)
+        for r in range(4):
+            x[:, r] = bias[off + 16 * t + 4 * G + r]
+        out.append(x)
+    return out
+
+
+def act_tiles(x, slope):
+    m = [t > 0 for t in x]
+    return [np.where(mm, t, t * np.float32(slope)) for t, mm in zip(x, m)], m
+
+
+def dact_tiles(g, m, slope):
+    return [np.where(mm, t, t * np.float32(slope)) for t, mm in zip(g, m)]
+
+
+def decode(tiles):
+    """C/D-layout tiles -> [16 poses, 16*len(tiles)] matrix."""
+    out = np.zeros((16, 16 * len(tiles)), np.float32)
+    for t, x in enumerate(tiles):
+        for r in range(4):
+            out[P, 16 * t + 4 * G + r] = x[:, r]
+    return out
+
+
+def trunk_wave(feat16, stream, bias, slope):
+    """feat16: [16,126] encoder features of the wave's 16 poses.  Returns (d[16], gx0[16,128], stages)."""
+    f = np.zeros((16, 128), np.float32)
+    f[:, :126] = feat16
+    x0 = []
+    for kt in range(8):
+        x = np.zeros((64, 4), np.float32)
+        for s in range(4):
+            x[:, s] = f[P, 16 * kt + 4 * G + s]
+        x0.append(x)
+    st, masks, stages = Stream(stream), {}, {}
+    x2 = load_bias(bias, BIAS_OFF[1], 32)
+    run_phase(0, x0, x2, st, bias[BIAS_OFF[0]:], masks, slope, False)
+    x2, m2 = act_tiles(x2, slope)
+    stages["x2"] = decode(x2)
+    x4 = load_bias(bias, BIAS_OFF[3], 32)
+    run_phase(1, x2, x4, st, bias[BIAS_OFF[2]:], masks, slope, False)
+    x4, m4 = act_tiles(x4, slope)
+    stages["x4"] = decode(x4)
+    x6 = load_bias(bias, BIAS_OFF[5], 4)
+    run_phase(2, x4, x6, st, bias[BIAS_OFF[4]:], masks, slope, False)
+    x6, m6 = act_tiles(x6, slope)
+    stages["x6"] = decode(x6)
+    w6 = load_bias(bias, W6_OFF, 4)
+    part = np.zeros(64, np.float32)
+    for t in range(4):
+        for r in range(4):
+            part += w6[t][:, r] * x6[t][:, r]
+    tot = np.zeros(64, np.float32)
+    for l in range(64):
+        tot[l] = part[[(l & 15) + 16 * g for g in range(4)]].sum()
+    z7 = tot + bias[BIAS_OFF[6]]
+    d = np.maximum(z7, 0)
+    gz7 = (z7 > 0).astype(np.float32)
+    g6 = dact_tiles([w6[t] * gz7[:, None] for t in range(4)], m6, slope)
+    g4 = [np.zeros((64, 4), np.float32) for _ in range(32)]
+    run_phase(3, g6, g4, st, None, masks, slope, True)
+    g4 = dact_tiles(g4, m4, slope)
+    stages["g4"] = decode(g4)
+    g2 = [np.zeros((64, 4), np.float32) for _ in range(32)]
+    run_phase(4, g4, g2, st, None, masks, slope, True)
+    g2 = dact_tiles(g2, m2, slope)
+    stages["g2"] = decode(g2)
+    g0 = [np.zeros((64, 4), np.float32) for _ in range(8)]
+    run_phase(5, g2, g0, st, None, masks, slope, True)
+    assert st.pos == st.t.shape[0], (st.pos, st.t.shape)
+    return d[:16], decode(g0), stages
