@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Headline benchmark: projected poses/sec (100 gradient steps, 21-joint quaternion poses) on N MI355X.
+
+One "step" of this harness = one pass of the hot path over one batch: PoseNDF.project(q0, steps=100) on
+B = 65,536 synthetic poses per GPU (BASELINE.json configs[2]; the batch is sharded by rank with no data-path
+collective during the 100 steps; for N > 1 the projected poses are all-gathered over RCCL at the end of each
+pass, inside the timed region).  Inputs are resident in HBM before the timed region starts.
+
+Launch:  python bench.py --gpus 1 --steps 5 --warmup 1
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FLOP_PER_POSE_STEP = 5_450_416      # 2 x 1,362,604 MACs forward + the same for d d/d q
+PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+
+def cpu_baseline(act, sd, proj_steps, sample_b):
+    """The reference's CPU PyTorch path (restated in oracle/posendf_torch.py) on this box's host cores, on a
+    bounded sample of the same workload."""
+    import torch
+    from oracle.posendf_torch import RefNet, project
+    from posendf_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = RefNet(act)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    q = torch.from_numpy(synth.make_poses(sample_b, seed=1234))
+    project(net, q[:256], 2)                                    # warm-up
+    t0 = time.perf_counter()
+    project(net, q, proj_steps)
+    dt = time.perf_counter() - t0
+    return {"value": sample_b / dt, "unit": "projected poses/s", "cores": cores, "kind": "port",
+            "sample": f"B={sample_b} poses x {proj_steps} steps, PyTorch-CPU restatement of the reference "
+                      f"(oracle/posendf_torch.py), {torch.get_num_threads()} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=65536, help="poses per GPU")
+    ap.add_argument("--proj-steps", type=int, default=100)
+    ap.add_argument("--act", default="lrelu")
+    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from posendf_amd import PoseNDF, amass_config, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs MI355X GPUs; the engine has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    sd = synth.make_weights(0, 2.0, 0.1)                        # BASELINE.md section 3 "live regime"
+    cfg = amass_config(args.act, f"cuda:{local}")
+    net = PoseNDF(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    B = args.batch
+    # shard `rank` of the global batch: reference input distribution (sample_poses.py:96-97), seeded
+    q0 = torch.from_numpy(synth.make_poses(B, seed=1234, offset=rank)).to(dev)
+    gathered = [torch.empty_like(q0) for _ in range(world)] if world > 1 else None
+
+    def one_pass():
+        qp, d = net.project(q0, steps=args.proj_steps)
+        if world > 1:
+            dist.all_gather(gathered, qp)                       # the only collective: final gather over xGMI
+        return qp, d
+
+    for _ in range(args.warmup):
+        one_pass()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        qp, d = net.project(q0, steps=args.proj_steps)          # the dominant kernel, bracketed by HIP events
+        ev[k][1].record()
+        if world > 1:
+            dist.all_gather(gathered, qp)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        k = torch.tensor([kern_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+        kern_ms = float(k.item())
+
+    if rank == 0:
+        total = B * world * args.steps
+        achieved = B * args.proj_steps * FLOP_PER_POSE_STEP / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "projected poses/sec (100 grad steps, 21-joint quat)",
+            "value": total / elapsed,
+            "unit": "poses/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[2]: batch={B} poses/GPU, {args.proj_steps}-step "
+                                   f"project() loop, fp32, act={args.act}, amass.yaml arch, random-init weights "
+                                   f"(uniform +-2/sqrt(fan_in), lin6.bias=0.1)",
+                       "global_batch": B * world, "proj_steps": args.proj_steps,
+                       "parallelism": f"batch-sharded x{world}, final RCCL all_gather" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "pndf_fused_relu_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_flop_per_launch": B * args.proj_steps * FLOP_PER_POSE_STEP},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.act, sd, args.proj_steps, args.cpu_sample)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

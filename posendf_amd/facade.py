@@ -1,0 +1,138 @@
+"""`PoseNDF` -- drop-in for the reference class of the same name (reference model/posendf.py:30-101).
+
+Same constructor (`PoseNDF(opt)` reading the keys of configs/amass.yaml that the reference reads),
+same `forward(pose, dist_gt=None, man_poses=None, train=True, eikonal=0.0)` signature and return
+values, same parameter tree / state-dict keys.  With train=False the distance and its input gradient
+come from the fused HIP kernel through the C ABI (include/posendf_amd.h); `project()` runs the whole
+projection loop of experiments/sample_poses.py:67-74 in one persistent launch.
+
+There is no CPU or eager-PyTorch fallback on the inference path: without the built library or without a
+gfx950 device, train=False raises.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch.autograd.function import once_differentiable
+
+from .engine import Engine, PndfError, state_dict_order
+from .modules import DFNet, StructureEncoder
+
+
+def gradient(inputs, outputs):
+    """reference model/posendf.py:18-27: d(sum outputs)/d inputs with create_graph/retain_graph."""
+    ones = torch.ones_like(outputs, requires_grad=False, device=outputs.device)
+    return torch.autograd.grad(outputs=outputs, inputs=inputs, grad_outputs=ones, create_graph=True,
+                               retain_graph=True, only_inputs=True)[0]
+
+
+class _Distance(torch.autograd.Function):
+    """dist_pred = f(pose) with first-order autograd: backward(g) = g * d dist / d pose.
+    Both come from ONE kernel launch; double backward is not provided (train=True path has it)."""
+
+    @staticmethod
+    def forward(ctx, pose, owner):
+        q = pose.detach()
+        if q.dtype != torch.float32 or not q.is_contiguous():
+            q = q.float().contiguous()
+        B = q.shape[0]
+        d = torch.empty(B, device=q.device, dtype=torch.float32)
+        eng = owner._engine_for(q.device)
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+        if ctx.needs_input_grad[0]:     # one launch yields d and d d/d pose
+            dq = torch.empty_like(q)
+            eng.forward_grad(q.data_ptr(), None, d.data_ptr(), dq.data_ptr(), B, stream)
+            ctx.save_for_backward(dq)
+        else:
+            eng.forward(q.data_ptr(), d.data_ptr(), B, stream)
+        ctx.pose_dtype = pose.dtype
+        return d.view(B, 1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        (dq,) = ctx.saved_tensors
+        return (grad_out.reshape(-1, 1, 1).to(dq.dtype) * dq).to(ctx.pose_dtype), None
+
+
+class PoseNDF(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.device = opt["train"]["device"]                       # posendf.py:35
+        self.enc = None
+        if opt["model"]["StrEnc"]["use"]:                          # posendf.py:41-42
+            self.enc = StructureEncoder(opt["model"]["StrEnc"]).to(self.device)
+        self.dfnet = DFNet(opt["model"]["DFNet"]).to(self.device)  # posendf.py:44
+        self.loss = opt["train"]["loss_type"]
+        self.batch_size = opt["train"]["batch_size"]
+        if self.loss == "l1":
+            self.loss_l1 = nn.L1Loss()
+        elif self.loss == "l2":
+            self.loss_l1 = nn.MSELoss()
+        self._act = opt["model"]["DFNet"]["act"]
+        self._beta = float(opt["model"]["DFNet"].get("beta", 100.0))
+        if self.enc is not None and opt["model"]["StrEnc"]["act"] != self._act:
+            raise PndfError("StrEnc.act and DFNet.act differ; the fused kernel uses one activation family")
+        self._engines = {}          # device index -> (Engine, weight fingerprint)
+
+    # ---- nn.Module conveniences the reference callers rely on -----------------------------------
+    def train(self, mode=True):     # the reference override returns None (posendf.py:58-59); returning
+        super().train(mode)         # self keeps statement-style callers working and fixes chaining
+        return self
+
+    # ---- engine plumbing -----------------------------------------------------------------------
+    def _fingerprint(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _engine_for(self, device):
+        if self.enc is None:
+            raise PndfError("StrEnc.use=False (in_dim=84) is not implemented by the HIP engine")
+        if device.type != "cuda":
+            raise PndfError("PoseNDF inference runs on the HIP engine only; no CPU path exists")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        fp = self._fingerprint()
+        entry = self._engines.get(idx)
+        if entry is None:
+            entry = [Engine(self._act, self._beta, idx), None]
+            self._engines[idx] = entry
+        if entry[1] != fp:          # first use, load_state_dict, optimiser step, .to(): re-pack the weights
+            sd = self.state_dict()
+            entry[0].load_weights({k: sd[k].detach().float().cpu().numpy() for k in state_dict_order()})
+            entry[1] = fp
+        return entry[0]
+
+    # ---- reference API -------------------------------------------------------------------------
+    def forward(self, pose, dist_gt=None, man_poses=None, train=True, eikonal=0.0):
+        pose = pose.to(device=self.device).reshape(-1, 21, 4)      # posendf.py:64
+        if not train:
+            return {"dist_pred": _Distance.apply(pose, self)}      # posendf.py:100-101
+        # ------ training objective: stock PyTorch modules (posendf.py:65-99)
+        pose.requires_grad = True
+        dist_gt = dist_gt.to(device=self.device).reshape(-1)
+        x = torch.nn.functional.normalize(pose, dim=1)             # joint-axis normalisation, posendf.py:71
+        if self.enc:
+            x = self.enc(x)
+        dist_pred = self.dfnet(x)
+        man = man_poses.to(device=self.device).reshape(-1, 21, 4)
+        dist_man = self.dfnet(self.enc(man) if self.enc else man)
+        loss = self.loss_l1(dist_pred[:, 0], dist_gt)
+        loss_man = dist_man.abs().mean()
+        grad_val = gradient(pose, dist_pred)
+        if eikonal > 0.0:
+            eik = ((grad_val.norm(2, dim=-1) - 1) ** 2).mean()
+            return loss, {"dist": loss, "man_loss": loss_man, "eikonal": eik}
+        return loss, {"dist": loss}
+
+    # ---- added surface (north_star: `.project` on the model) -------------------------------------
+    @torch.no_grad()
+    def project(self, noisy_poses, steps=100, return_dist=True):
+        """experiments/sample_poses.py:67-74 as ONE persistent kernel: `steps` times
+        q <- q - dist_pred(q) * d dist_pred / d q.  Returns (poses [B,21,4], dist [B,1] of the last
+        iteration)."""
+        q = noisy_poses.to(device=self.device).reshape(-1, 21, 4).float().contiguous()
+        out = torch.empty_like(q)
+        d = torch.empty(q.shape[0], device=q.device, dtype=torch.float32)
+        eng = self._engine_for(q.device)
+        eng.project(q.data_ptr(), out.data_ptr(), d.data_ptr(), q.shape[0], int(steps),
+                    torch.cuda.current_stream(q.device).cuda_stream)
+        return (out, d.view(-1, 1)) if return_dist else out

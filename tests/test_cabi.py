@@ -1,0 +1,96 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol include/posendf_amd.h declares,
+validates arguments, and refuses to run without a gfx950 device (no CPU fallback).  No compute calls."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from posendf_amd import engine
+    return engine.load_library()
+
+
+def test_exports_match_header(lib):
+    hdr = open(os.path.join(REPO, "include", "posendf_amd.h")).read()
+    declared = set(re.findall(r"\b(pndf_[a-z_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    from posendf_amd import engine
+    assert set(engine.EXPORTS) == declared
+
+
+def test_default_config(lib):
+    from posendf_amd.engine import PndfConfig
+    cfg = PndfConfig()
+    lib.pndf_default_config(ctypes.byref(cfg), 1, 100.0)
+    assert cfg.num_joints == 21 and cfg.n_dims == 8
+    assert list(cfg.dims[:8]) == [126, 256, 512, 1024, 512, 256, 64, 1]
+    assert list(cfg.parent[:21]) == [-1, -1, -1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19]
+
+
+def test_create_rejects_unsupported(lib):
+    from posendf_amd.engine import PndfConfig
+    h = ctypes.c_void_p()
+    cfg = PndfConfig()
+    lib.pndf_default_config(ctypes.byref(cfg), 2, 100.0)            # softplus
+    assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -4
+    assert b"activation" in lib.pndf_last_error(None)
+    lib.pndf_default_config(ctypes.byref(cfg), 1, 100.0)
+    cfg.dims[2] = 384                                               # other architecture
+    assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -4
+    cfg.dims[2] = 512
+    cfg.parent[3] = 0
+    assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -4
+
+
+def test_no_device_is_a_loud_error(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from posendf_amd.engine import Engine, PndfError
+    with pytest.raises(PndfError, match="no HIP device|no CPU fallback"):
+        Engine("lrelu")
+
+
+def test_pack_host_rejects_bad_tables(lib):
+    from posendf_amd import engine, synth
+    sd = synth.make_weights(1)
+    stream, enc, bias = engine.pack_host(sd, lib)
+    assert np.isfinite(stream).all()
+    bad = dict(sd)
+    bad["dfnet.lin3.weight"] = bad["dfnet.lin3.weight"][:, :-1]
+    with pytest.raises(engine.PndfError):
+        engine.pack_host(bad, lib)
+
+
+def test_facade_surface_cpu():
+    """Reference-compatible surface without touching the engine: state-dict keys, train=True objective
+    (pinned against the reference in tests/golden), loud failure of train=False on CPU."""
+    import torch
+    from conftest import golden_weights, load_golden
+    from posendf_amd import PoseNDF, amass_config, synth
+    from posendf_amd.engine import PndfError
+    net = PoseNDF(amass_config("lrelu", "cpu"))
+    assert list(net.state_dict().keys()) == list(synth.state_dict_shapes().keys())
+    assert sum(p.numel() for p in net.parameters()) == 1365565
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in golden_weights("live").items()})
+    assert net.eval() is net
+    g = load_golden("lrelu", "live")
+    loss, ld = net(torch.from_numpy(g["train_q"]).clone(), torch.from_numpy(g["train_dist"]),
+                   torch.from_numpy(g["train_man"]), train=True, eikonal=1.0)
+    assert abs(loss.item() - g["train_loss"]) < 1e-6
+    assert abs(ld["man_loss"].item() - g["train_man_loss"]) < 1e-6
+    assert abs(ld["eikonal"].item() - g["train_eikonal"]) < 1e-5
+    loss.backward()                                                 # weight gradients flow (train_posendf.py:98)
+    assert net.dfnet.lin0.weight.grad is not None
+    with pytest.raises(PndfError):
+        net(torch.from_numpy(g["q"]), train=False)

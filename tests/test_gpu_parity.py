@@ -1,0 +1,208 @@
+"""GPU parity tests (run by the driver with -m gpu on a real MI355X).  Everything goes through the C ABI
+(posendf_amd.engine -> libposendf_amd.so); the checker is the numpy oracle and the committed golden
+vectors generated from the reference.  Tolerance: 1e-4 relative (BASELINE.json north_star), with the
+distance floor of conftest.d_err."""
+import numpy as np
+import pytest
+
+from conftest import REGIMES, d_err, golden_weights, load_golden, rel_err, rel_err_rows
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (no CPU fallback exists)")
+    return torch
+
+
+def make_net(torch, act, regime=None, sd=None):
+    from posendf_amd import PoseNDF, amass_config
+    net = PoseNDF(amass_config(act, "cuda:0"))
+    sd = sd if sd is not None else golden_weights(regime)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    return net
+
+
+@pytest.mark.parametrize("act", ["lrelu", "relu"])
+@pytest.mark.parametrize("regime", list(REGIMES))
+def test_golden_single_step(torch_cuda, act, regime):
+    torch = torch_cuda
+    g = load_golden(act, regime)
+    net = make_net(torch, act, regime)
+    q = torch.from_numpy(g["q"]).cuda().requires_grad_(True)
+    d = net(q, train=False)["dist_pred"]
+    assert d.shape == (len(g["q"]), 1)
+    (dq,) = torch.autograd.grad(d, q, grad_outputs=torch.ones_like(d))
+    assert d_err(d.detach().cpu().numpy(), g["d_f32"]) < TOL
+    assert rel_err(dq.cpu().numpy(), g["dq_f32"]) < TOL
+    # forward-only launch gives the same distances as the forward+grad launch
+    with torch.no_grad():
+        d2 = net(torch.from_numpy(g["q"]), train=False)["dist_pred"]      # CPU tensor is moved (posendf.py:64)
+    assert torch.equal(d2, d.detach())
+    # clipped poses: exactly zero distance and exactly zero gradient
+    z = g["d_f32"][:, 0] == 0
+    assert np.array_equal(d.detach().cpu().numpy()[:, 0] == 0, z)
+    assert np.all(dq.cpu().numpy()[z] == 0)
+
+
+@pytest.mark.parametrize("act", ["lrelu", "relu"])
+def test_golden_autograd_contract(torch_cuda, act):
+    """backward with an arbitrary upstream gradient (motion_denoise.py:82-83,97-98) and the pose-prior
+    objective 1e7 c^2 / (1 + it) of motion_denoise.py:33."""
+    torch = torch_cuda
+    g = load_golden(act, "mixed")
+    net = make_net(torch, act, "mixed")
+    q = torch.from_numpy(g["q"]).cuda().requires_grad_(True)
+    (net(q, train=False)["dist_pred"] * torch.from_numpy(g["grad_out"]).cuda()).sum().backward()
+    assert rel_err(q.grad.cpu().numpy(), g["grad_pose_f32"]) < TOL
+    for it in (0, 3):
+        q = torch.from_numpy(g["q"]).cuda().requires_grad_(True)
+        c = torch.mean(net(q, train=False)["dist_pred"])
+        obj = 10.0 ** 7 * c * c / (1 + it)
+        obj.backward()
+        assert abs(obj.item() - g[f"prior_obj_it{it}"]) <= TOL * abs(g[f"prior_obj_it{it}"])
+        assert rel_err(q.grad.cpu().numpy(), g[f"prior_grad_it{it}"]) < 2 * TOL
+
+
+@pytest.mark.parametrize("act", ["lrelu", "relu"])
+@pytest.mark.parametrize("regime", list(REGIMES))
+def test_golden_projection(torch_cuda, act, regime):
+    """1/10/100-step projection vs the reference.  Single step: 1e-4.  Free-running: measured against the
+    reference's fp64 trajectory with the reference's own fp32 run as the envelope (LeakyReLU/ReLU kinks make
+    a per-pose 1e-4 gate fail for the reference against itself)."""
+    torch = torch_cuda
+    g = load_golden(act, regime)
+    net = make_net(torch, act, regime)
+    q0 = torch.from_numpy(g["q"]).cuda()
+    for steps in (1, 10, 100):
+        qp, dl = net.project(q0, steps=steps)
+        qp = qp.cpu().numpy()
+        truth = g[f"q{steps}_f64"]
+        mine = rel_err_rows(qp, truth)
+        ref = rel_err_rows(g[f"q{steps}_f32"], truth)
+        if steps == 1:
+            assert rel_err(qp, g["q1_f32"]) < TOL
+        assert np.median(mine) < 1e-5
+        assert np.percentile(mine, 90) < TOL
+        assert (mine > TOL).mean() <= 2 * (ref > TOL).mean() + 0.03, (steps, mine.max(), ref.max())
+        # d_last is dist_pred of the last iteration (before its update)
+        assert d_err(dl.cpu().numpy()[:, 0], g["dtrace_f64"][steps - 1], floor_frac=0.05) < 20 * TOL if steps > 1 \
+            else d_err(dl.cpu().numpy()[:, 0], g["dtrace_f32"][0]) < TOL
+
+
+@pytest.mark.parametrize("B", [1, 15, 63, 64, 65, 257, 1000])
+def test_ragged_batches_match_oracle(torch_cuda, B):
+    torch = torch_cuda
+    from oracle import posendf_np as onp
+    from posendf_amd import synth
+    sd = golden_weights("mixed")
+    net = make_net(torch, "lrelu", sd=sd)
+    qn = synth.make_poses(B, seed=100 + B, signed=True)
+    q = torch.from_numpy(qn).cuda().requires_grad_(True)
+    d = net(q, train=False)["dist_pred"]
+    (dq,) = torch.autograd.grad(d.sum(), q)
+    do, go = onp.forward_grad(qn, sd, "lrelu")
+    assert d_err(d.detach().cpu().numpy(), do) < TOL
+    assert rel_err(dq.cpu().numpy(), go) < TOL
+    qp, _ = net.project(q.detach(), steps=4)
+    qo, _ = onp.project(qn, sd, steps=4)
+    assert rel_err(qp.cpu().numpy(), qo) < TOL
+
+
+def test_teacher_forced_steps(torch_cuda):
+    """Per-step parity along the reference's own fp32 trajectory (BASELINE.md gate 2): feed q_k of the
+    oracle trajectory, compare one engine step with the oracle's next iterate."""
+    torch = torch_cuda
+    from oracle import posendf_np as onp
+    from posendf_amd import synth
+    sd = golden_weights("live")
+    net = make_net(torch, "lrelu", sd=sd)
+    q = synth.make_poses(128, seed=9)
+    for k in range(12):
+        d, dq = onp.forward_grad(q, sd, "lrelu")
+        nxt = q - (d * dq.reshape(-1, 84)).reshape(-1, 21, 4)
+        got, dl = net.project(torch.from_numpy(q), steps=1)
+        assert rel_err(got.cpu().numpy(), nxt) < TOL, k
+        assert d_err(dl.cpu().numpy(), d) < TOL, k
+        q = nxt.astype(np.float32)
+
+
+def test_full_size_properties(torch_cuda):
+    """BASELINE.json configs 2-3 size (B = 65,536): size-independent properties instead of an oracle run."""
+    torch = torch_cuda
+    from oracle import posendf_np as onp
+    from posendf_amd import synth
+    sd = golden_weights("live")
+    net = make_net(torch, "lrelu", sd=sd)
+    B = 65536
+    qn = synth.make_poses(B, seed=1234)
+    q = torch.from_numpy(qn).cuda()
+    # (1) per-pose independence: a permuted batch gives the permuted result, bit for bit
+    perm = torch.randperm(B, device="cuda", generator=torch.Generator("cuda").manual_seed(0))
+    q10, d10 = net.project(q, steps=10)
+    q10p, d10p = net.project(q[perm].contiguous(), steps=10)
+    assert torch.equal(q10[perm], q10p) and torch.equal(d10[perm], d10p)
+    # (2) determinism and in-place operation
+    q10b, _ = net.project(q, steps=10)
+    assert torch.equal(q10, q10b)
+    buf = q.clone()
+    eng = net._engine_for(q.device)
+    eng.project(buf.data_ptr(), buf.data_ptr(), 0, B, 10, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(buf, q10)
+    # (3) composition: 10 steps == 4 steps followed by 6 steps
+    q4, _ = net.project(q, steps=4)
+    q46, _ = net.project(q4, steps=6)
+    assert torch.equal(q46, q10)
+    # (4) a random sample of the full-size result against the oracle
+    idx = np.random.default_rng(0).choice(B, 256, replace=False)
+    qo, do = onp.project(qn[idx], sd, steps=10)
+    assert rel_err(q10[idx].cpu().numpy(), qo) < TOL
+    # (5) the projection decreases the predicted distance on average (it is a descent on d^2 / 2)
+    d0 = net(q, train=False)["dist_pred"]
+    d100 = net(net.project(q, steps=100)[0], train=False)["dist_pred"]
+    assert d100.mean() < d0.mean()
+    # (6) steps = 0 is the identity
+    q0, _ = net.project(q, steps=0)
+    assert torch.equal(q0, q)
+
+
+def test_weight_reload_and_errors(torch_cuda):
+    torch = torch_cuda
+    from posendf_amd import PoseNDF, amass_config, synth
+    from posendf_amd.engine import PndfError
+    net = make_net(torch, "lrelu", "live")
+    q = torch.from_numpy(synth.make_poses(64, seed=2)).cuda()
+    d_a = net(q, train=False)["dist_pred"].clone()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in golden_weights("mixed").items()})
+    d_b = net(q, train=False)["dist_pred"]
+    assert not torch.equal(d_a, d_b)                       # re-packed after load_state_dict
+    with torch.no_grad():
+        net.dfnet.lin6.bias.add_(1.0)                      # in-place parameter update is seen too
+    d_c = net(q, train=False)["dist_pred"]
+    assert torch.allclose(d_c, d_b + 1.0, atol=1e-5)
+    with pytest.raises(PndfError):                         # softplus: not implemented -> loud failure
+        sp = PoseNDF(amass_config("softplus", "cuda:0"))
+        sp(q, train=False)
+    with pytest.raises(RuntimeError):                      # no double backward on the engine path
+        qq = q.clone().requires_grad_(True)
+        dd = net(qq, train=False)["dist_pred"]
+        (g1,) = torch.autograd.grad(dd.sum(), qq, create_graph=True)
+        g1.sum().backward()
+
+
+def test_debug_stages(torch_cuda):
+    """Stage-by-stage register dumps of workgroup 0 against the oracle's intermediates."""
+    import subprocess
+    import sys
+    import os
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "gpu_selfcheck.py"), "lrelu"],
+                       capture_output=True, text=True, timeout=900)
+    print(r.stdout[-4000:])
+    assert "MISMATCH" not in r.stdout and r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
