@@ -23,24 +23,32 @@ FLOP_PER_POSE_STEP = 5_450_416      # 2 x 1,362,604 MACs forward
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 
 
-def cpu_baseline(act, sd, proj_steps, sample_b):
+def cpu_baseline(act, sd, proj_steps, budget_s=20.0):
     """The reference's CPU PyTorch path (restated in oracle/posendf_torch.py) on this box's host cores, on a
-    bounded sample of the same workload."""
+    bounded sample of the same workload: the full 100-step projection of as many poses as fit in ~budget_s."""
     import torch
     from oracle.posendf_torch import RefNet, project
     from posendf_amd import synth
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    torch.set_num_threads(threads)
     net = RefNet(act)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    q = torch.from_numpy(synth.make_poses(sample_b, seed=1234))
-    project(net, q[:256], 2)                                    # warm-up
+    q = torch.from_numpy(synth.make_poses(4096, seed=1234))
+    project(net, q[:256], 1)                                    # warm-up
     t0 = time.perf_counter()
-    project(net, q, proj_steps)
+    project(net, q[:512], 2)                                    # calibration: pose-steps per second
+    rate = 512 * 2 / (time.perf_counter() - t0)
+    sample_b = int(min(4096, max(64, rate * budget_s / proj_steps)))
+    t0 = time.perf_counter()
+    project(net, q[:sample_b], proj_steps)
     dt = time.perf_counter() - t0
-    return {"value": sample_b / dt, "unit": "projected poses/s", "cores": cores, "kind": "port",
-            "sample": f"B={sample_b} poses x {proj_steps} steps, PyTorch-CPU restatement of the reference "
-                      f"(oracle/posendf_torch.py), {torch.get_num_threads()} threads, {dt:.1f} s"}
+    return {"value": sample_b / dt, "unit": "projected poses/s", "cores": threads, "kind": "port",
+            "sample": f"B={sample_b} poses x {proj_steps} steps in {dt:.1f} s; PyTorch-CPU restatement of the "
+                      f"reference (oracle/posendf_torch.py), {threads} threads on {cores} visible cores"}
 
 
 def main():
@@ -51,7 +59,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="poses per GPU")
     ap.add_argument("--proj-steps", type=int, default=100)
     ap.add_argument("--act", default="lrelu")
-    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -143,7 +151,7 @@ def main():
                          "algorithmic_flop_per_launch": B * args.proj_steps * FLOP_PER_POSE_STEP},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.act, sd, args.proj_steps, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(args.act, sd, args.proj_steps, args.cpu_budget)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -5,7 +5,7 @@ distance floor of conftest.d_err."""
 import numpy as np
 import pytest
 
-from conftest import REGIMES, d_err, golden_weights, load_golden, rel_err, rel_err_rows
+from conftest import REGIMES, d_err, golden_weights, load_golden, outlier_gate, rel_err, rel_err_rows
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -39,7 +39,7 @@ def test_golden_single_step(torch_cuda, act, regime):
     assert d.shape == (len(g["q"]), 1)
     (dq,) = torch.autograd.grad(d, q, grad_outputs=torch.ones_like(d))
     assert d_err(d.detach().cpu().numpy(), g["d_f32"]) < TOL
-    assert rel_err(dq.cpu().numpy(), g["dq_f32"]) < TOL
+    outlier_gate(rel_err_rows(dq.cpu().numpy(), g["dq_f64"]), rel_err_rows(g["dq_f32"], g["dq_f64"]), TOL, "dq")
     # forward-only launch gives the same distances as the forward+grad launch
     with torch.no_grad():
         d2 = net(torch.from_numpy(g["q"]), train=False)["dist_pred"]      # CPU tensor is moved (posendf.py:64)
@@ -59,14 +59,18 @@ def test_golden_autograd_contract(torch_cuda, act):
     net = make_net(torch, act, "mixed")
     q = torch.from_numpy(g["q"]).cuda().requires_grad_(True)
     (net(q, train=False)["dist_pred"] * torch.from_numpy(g["grad_out"]).cuda()).sum().backward()
-    assert rel_err(q.grad.cpu().numpy(), g["grad_pose_f32"]) < TOL
+    truth = g["dq_f64"] * g["grad_out"].reshape(-1, 1, 1)
+    outlier_gate(rel_err_rows(q.grad.cpu().numpy(), truth), rel_err_rows(g["grad_pose_f32"], truth), TOL, "grad_out")
     for it in (0, 3):
         q = torch.from_numpy(g["q"]).cuda().requires_grad_(True)
         c = torch.mean(net(q, train=False)["dist_pred"])
         obj = 10.0 ** 7 * c * c / (1 + it)
         obj.backward()
         assert abs(obj.item() - g[f"prior_obj_it{it}"]) <= TOL * abs(g[f"prior_obj_it{it}"])
-        assert rel_err(q.grad.cpu().numpy(), g[f"prior_grad_it{it}"]) < 2 * TOL
+        scale = 2e7 * g["d_f64"].mean() / ((1 + it) * len(g["q"]))
+        truth = g["dq_f64"] * scale
+        outlier_gate(rel_err_rows(q.grad.cpu().numpy(), truth), rel_err_rows(g[f"prior_grad_it{it}"], truth),
+                     2 * TOL, "prior")
 
 
 @pytest.mark.parametrize("act", ["lrelu", "relu"])
@@ -85,11 +89,8 @@ def test_golden_projection(torch_cuda, act, regime):
         truth = g[f"q{steps}_f64"]
         mine = rel_err_rows(qp, truth)
         ref = rel_err_rows(g[f"q{steps}_f32"], truth)
-        if steps == 1:
-            assert rel_err(qp, g["q1_f32"]) < TOL
-        assert np.median(mine) < 1e-5
+        outlier_gate(mine, ref, TOL, f"project{steps}")
         assert np.percentile(mine, 90) < TOL
-        assert (mine > TOL).mean() <= 2 * (ref > TOL).mean() + 0.03, (steps, mine.max(), ref.max())
         # d_last is dist_pred of the last iteration (before its update)
         assert d_err(dl.cpu().numpy()[:, 0], g["dtrace_f64"][steps - 1], floor_frac=0.05) < 20 * TOL if steps > 1 \
             else d_err(dl.cpu().numpy()[:, 0], g["dtrace_f32"][0]) < TOL
@@ -107,11 +108,13 @@ def test_ragged_batches_match_oracle(torch_cuda, B):
     d = net(q, train=False)["dist_pred"]
     (dq,) = torch.autograd.grad(d.sum(), q)
     do, go = onp.forward_grad(qn, sd, "lrelu")
+    _, g64 = onp.forward_grad(qn, sd, "lrelu", dtype=np.float64)
     assert d_err(d.detach().cpu().numpy(), do) < TOL
-    assert rel_err(dq.cpu().numpy(), go) < TOL
+    outlier_gate(rel_err_rows(dq.cpu().numpy(), g64), rel_err_rows(go, g64), TOL, "dq")
     qp, _ = net.project(q.detach(), steps=4)
-    qo, _ = onp.project(qn, sd, steps=4)
-    assert rel_err(qp.cpu().numpy(), qo) < TOL
+    q64, _ = onp.project(qn, sd, steps=4, dtype=np.float64)
+    q32, _ = onp.project(qn, sd, steps=4)
+    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project4")
 
 
 def test_teacher_forced_steps(torch_cuda):
@@ -126,8 +129,10 @@ def test_teacher_forced_steps(torch_cuda):
     for k in range(12):
         d, dq = onp.forward_grad(q, sd, "lrelu")
         nxt = q - (d * dq.reshape(-1, 84)).reshape(-1, 21, 4)
+        d64, dq64 = onp.forward_grad(q, sd, "lrelu", dtype=np.float64)
+        nxt64 = q.astype(np.float64) - (d64 * dq64.reshape(-1, 84)).reshape(-1, 21, 4)
         got, dl = net.project(torch.from_numpy(q), steps=1)
-        assert rel_err(got.cpu().numpy(), nxt) < TOL, k
+        outlier_gate(rel_err_rows(got.cpu().numpy(), nxt64), rel_err_rows(nxt, nxt64), TOL, f"step{k}")
         assert d_err(dl.cpu().numpy(), d) < TOL, k
         q = nxt.astype(np.float32)
 
@@ -161,8 +166,9 @@ def test_full_size_properties(torch_cuda):
     assert torch.equal(q46, q10)
     # (4) a random sample of the full-size result against the oracle
     idx = np.random.default_rng(0).choice(B, 256, replace=False)
-    qo, do = onp.project(qn[idx], sd, steps=10)
-    assert rel_err(q10[idx].cpu().numpy(), qo) < TOL
+    q64, _ = onp.project(qn[idx], sd, steps=10, dtype=np.float64)
+    q32, _ = onp.project(qn[idx], sd, steps=10)
+    outlier_gate(rel_err_rows(q10[idx].cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project10")
     # (5) the projection decreases the predicted distance on average (it is a descent on d^2 / 2)
     d0 = net(q, train=False)["dist_pred"]
     d100 = net(net.project(q, steps=100)[0], train=False)["dist_pred"]
@@ -176,12 +182,13 @@ def test_weight_reload_and_errors(torch_cuda):
     torch = torch_cuda
     from posendf_amd import PoseNDF, amass_config, synth
     from posendf_amd.engine import PndfError
-    net = make_net(torch, "lrelu", "live")
+    net = make_net(torch, "lrelu", "mixed")
     q = torch.from_numpy(synth.make_poses(64, seed=2)).cuda()
     d_a = net(q, train=False)["dist_pred"].clone()
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in golden_weights("mixed").items()})
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in golden_weights("live").items()})
     d_b = net(q, train=False)["dist_pred"]
     assert not torch.equal(d_a, d_b)                       # re-packed after load_state_dict
+    assert (d_b > 0).all()
     with torch.no_grad():
         net.dfnet.lin6.bias.add_(1.0)                      # in-place parameter update is seen too
     d_c = net(q, train=False)["dist_pred"]
