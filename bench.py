@@ -90,12 +90,12 @@ def main():
     B = args.batch
     # shard `rank` of the global batch: reference input distribution (sample_poses.py:96-97), seeded
     q0 = torch.from_numpy(synth.make_poses(B, seed=1234, offset=rank)).to(dev)
-    gathered = [torch.empty_like(q0) for _ in range(world)] if world > 1 else None
+    from posendf_amd.sharding import all_gather_blocks
 
     def one_pass():
         qp, d = net.project(q0, steps=args.proj_steps)
         if world > 1:
-            dist.all_gather(gathered, qp)                       # the only collective: final gather over xGMI
+            all_gather_blocks(qp, B * world)                    # the only collective: final gather over xGMI
         return qp, d
 
     for _ in range(args.warmup):
@@ -110,7 +110,7 @@ def main():
         qp, d = net.project(q0, steps=args.proj_steps)          # the dominant kernel, bracketed by HIP events
         ev[k][1].record()
         if world > 1:
-            dist.all_gather(gathered, qp)
+            all_gather_blocks(qp, B * world)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
