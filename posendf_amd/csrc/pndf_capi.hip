@@ -26,8 +26,12 @@ struct PndfKernelArgs {
     int steps;
     int mode;
     float slope;
+    float beta;
+    float* scratch;
 };
 extern "C" __global__ void pndf_fused_relu_kernel(PndfKernelArgs args);
+extern "C" __global__ void pndf_fused_softplus_kernel(PndfKernelArgs args);
+extern "C" long long pndf_kernel_softplus_scratch_floats_per_wg();
 extern "C" __global__ void pndf_fused_relu_kernel_dbg(PndfKernelArgs args);
 extern "C" int pndf_kernel_lds_bytes();
 extern "C" int pndf_kernel_dbg_floats();
@@ -41,6 +45,8 @@ struct pndf_engine {
     char* d_stream = nullptr;   // STEP_TILES KiB
     float* d_enc = nullptr;
     float* d_bias = nullptr;
+    float* d_scratch = nullptr;     // softplus derivative scratch, grown on demand
+    int64_t scratch_wgs = 0;
     std::string err;
 };
 
@@ -58,7 +64,7 @@ static int fail(pndf_engine* h, int code, const std::string& msg) {
             return fail(h, PNDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-extern "C" const char* pndf_version(void) { return "posendf_amd 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
+extern "C" const char* pndf_version(void) { return "posendf_amd 0.2 (gfx950, fp32 MFMA 16x16x4; relu, lrelu, softplus)"; }
 
 extern "C" const char* pndf_last_error(pndf_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
@@ -81,8 +87,10 @@ static int check_config(pndf_engine* h, const pndf_config* cfg) {
             return fail(h, PNDF_ERR_UNSUPPORTED, "DFNet dims must be 126,256,512,1024,512,256,64,1 (StrEnc.use=True)");
     for (int i = 0; i < NJ; ++i)
         if (cfg->parent[i] != PARENT[i]) return fail(h, PNDF_ERR_UNSUPPORTED, "parent table must be get_parent_mapping('smpl')");
-    if (cfg->act != PNDF_ACT_RELU && cfg->act != PNDF_ACT_LRELU)
-        return fail(h, PNDF_ERR_UNSUPPORTED, "activation not implemented by the HIP kernels (relu and lrelu are)");
+    if (cfg->act != PNDF_ACT_RELU && cfg->act != PNDF_ACT_LRELU && cfg->act != PNDF_ACT_SOFTPLUS)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "unknown activation (relu, lrelu and softplus are implemented)");
+    if (cfg->act == PNDF_ACT_SOFTPLUS && !(cfg->beta > 0.f))
+        return fail(h, PNDF_ERR_BAD_ARG, "softplus beta must be positive");
     return PNDF_OK;
 }
 
@@ -108,6 +116,8 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)pndf_fused_softplus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_relu_kernel_dbg, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e != hipSuccess) {
         std::string m = std::string("pndf_create: ") + hipGetErrorString(e);
@@ -124,6 +134,7 @@ extern "C" int pndf_destroy(pndf_handle h) {
     if (h->d_stream) (void)hipFree(h->d_stream);
     if (h->d_enc) (void)hipFree(h->d_enc);
     if (h->d_bias) (void)hipFree(h->d_bias);
+    if (h->d_scratch) (void)hipFree(h->d_scratch);
     delete h;
     return PNDF_OK;
 }
@@ -239,6 +250,10 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
     a.stream = h->d_stream; a.enc = h->d_enc; a.bias = h->d_bias; a.dbg = dbg;
     a.B = B; a.steps = steps; a.mode = mode;
     a.slope = (h->cfg.act == PNDF_ACT_LRELU) ? 0.01f : 0.0f;   // nn.LeakyReLU() default slope, net_modules.py:31
+    a.beta = h->cfg.beta;
+    a.scratch = nullptr;
+    const bool softplus = h->cfg.act == PNDF_ACT_SOFTPLUS;
+    if (softplus && dbg) return fail(h, PNDF_ERR_UNSUPPORTED, "the debug dump exists for the relu-family kernel only");
     if (mode == MODE_PROJECT && steps == 0) {
         // zero iterations: the loop body never runs (sample_poses.py:70); poses pass through
         if (qo != q) HIP_TRY(h, hipMemcpyAsync(qo, q, (size_t)B * NQ * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -246,6 +261,23 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
         return PNDF_OK;
     }
     const dim3 grid((unsigned)((B + WG_POSES - 1) / WG_POSES)), block(WG_THREADS);
+    if (softplus) {
+        // derivative scratch: one block per workgroup; grown (synchronously) when a larger batch arrives
+        if ((int64_t)grid.x > h->scratch_wgs) {
+            HIP_TRY(h, hipSetDevice(h->device));
+            HIP_TRY(h, hipDeviceSynchronize());
+            if (h->d_scratch) HIP_TRY(h, hipFree(h->d_scratch));
+            h->d_scratch = nullptr;
+            h->scratch_wgs = 0;
+            HIP_TRY(h, hipMalloc((void**)&h->d_scratch,
+                                 (size_t)grid.x * pndf_kernel_softplus_scratch_floats_per_wg() * sizeof(float)));
+            h->scratch_wgs = grid.x;
+        }
+        a.scratch = h->d_scratch;
+        hipLaunchKernelGGL(pndf_fused_softplus_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+        HIP_TRY(h, hipGetLastError());
+        return PNDF_OK;
+    }
     if (dbg) hipLaunchKernelGGL(pndf_fused_relu_kernel_dbg, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else hipLaunchKernelGGL(pndf_fused_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     HIP_TRY(h, hipGetLastError());

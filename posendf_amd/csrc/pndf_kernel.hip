@@ -124,6 +124,29 @@ __device__ __forceinline__ float act_relu(float z, float slope, bool& pos) {
     return pos ? z : z * slope;
 }
 
+// nn.Softplus(beta, threshold=20) (net_modules.py:39-40): x if beta x > 20 else log1p(exp(beta x)) / beta;
+// derivative as PyTorch's softplus_backward: e / (e + 1) with e = exp(beta x), 1 above the threshold.
+__device__ __forceinline__ float act_softplus(float z, float beta, float& deriv) {
+    const float bz = z * beta;
+    const float e = expf(fminf(bz, 20.0f));
+    const bool lin = bz > 20.0f;
+    deriv = lin ? 1.0f : e / (e + 1.0f);
+    return lin ? z : log1pf(e) / beta;
+}
+
+// Activation parameters + where derivatives are parked between the forward and the backward pass.
+//   relu family : sign bits (chunk layers: one u16 per lane per chunk in LDS; accumulator layers: registers)
+//   softplus    : fp32 derivatives in a per-workgroup global scratch, one float4 per lane per tile ("slot")
+struct ActP {
+    float slope;        // relu family
+    float beta;         // softplus
+    f32x4* sp;          // softplus: this thread's column of the scratch ([slot][256] float4), else null
+};
+constexpr int SP_SLOT_CHUNK[3] = {0, 16, 80};      // chunk layers x1 (8x2), x3 (32x2), x5 (4x4)
+constexpr int SP_SLOT_X2 = 96, SP_SLOT_X4 = 128, SP_SLOT_X6 = 160, SP_SLOTS = 164;
+constexpr int SP_ENC_FLOATS = NJ * 16 * WG_POSES;   // encoder derivatives: [joint][4 float4][64 poses]
+constexpr int SP_WG_FLOATS = SP_SLOTS * WG_THREADS * 4 + SP_ENC_FLOATS;
+
 // One fused layer pair.  xin: KA input tiles (B operands); acc: NB output tiles (accumulators).
 // Forward: chunk accumulators start from the A-layer bias, get the activation, and their sign bits are
 // parked in LDS; backward: chunk accumulators start at 0 and are multiplied by the parked derivative.
@@ -142,7 +165,7 @@ __device__ __forceinline__ void load_group(f32x4 (&a)[GT], Ring& ring) {
     }
 }
 
-template <int KA, int CT, int NC, int NB, bool BWD>
+template <int KA, int CT, int NC, int NB, bool BWD, bool SP>
 struct PhaseBody {
     static constexpr int GT = 2 * CT;                 // tiles per group
     static constexpr int NGA = KA / 2;                // part-A groups (two k-tiles each)
@@ -156,8 +179,8 @@ struct PhaseBody {
     // (or garbage after the very last group) on exit.
     template <int GI>
     static __device__ __forceinline__ void groups(const f32x4 (&xin)[KA], f32x4 (&acc)[NB], f32x4 (&ch)[CT],
-                                                  f32x4 (&cur)[GT], Ring& ring, uint16_t* mask, float slope,
-                                                  int c) {
+                                                  f32x4 (&cur)[GT], Ring& ring, uint16_t* mask, const ActP& ap,
+                                                  int spslot, int c) {
         if constexpr (GI < NG) {
             f32x4 nxt[GT];
             constexpr int TNEXT = ((GI + 1) * GT) % CHUNK_TILES;
@@ -176,14 +199,31 @@ struct PhaseBody {
                 }
                 if constexpr (GI == NGA - 1) {
                     // ---- chunk epilogue
-                    if (!BWD) {
+                    if constexpr (SP) {
+#pragma unroll
+                        for (int ci = 0; ci < CT; ++ci) {
+                            f32x4* slot = ap.sp + (size_t)(spslot + c * CT + ci) * WG_THREADS;
+                            if (!BWD) {
+                                f32x4 dv;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    float dr;
+                                    ch[ci][r] = act_softplus(ch[ci][r], ap.beta, dr);
+                                    dv[r] = dr;
+                                }
+                                *slot = dv;
+                            } else {
+                                ch[ci] = ch[ci] * *slot;
+                            }
+                        }
+                    } else if (!BWD) {
                         uint32_t bits = 0;
 #pragma unroll
                         for (int ci = 0; ci < CT; ++ci) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 bool pos;
-                                ch[ci][r] = act_relu(ch[ci][r], slope, pos);
+                                ch[ci][r] = act_relu(ch[ci][r], ap.slope, pos);
                                 bits |= pos ? (1u << (ci * 4 + r)) : 0u;
                             }
                         }
@@ -194,7 +234,7 @@ struct PhaseBody {
                         for (int ci = 0; ci < CT; ++ci) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                ch[ci][r] = ((bits >> (ci * 4 + r)) & 1u) ? ch[ci][r] : ch[ci][r] * slope;
+                                ch[ci][r] = ((bits >> (ci * 4 + r)) & 1u) ? ch[ci][r] : ch[ci][r] * ap.slope;
                         }
                     }
                 }
@@ -214,15 +254,15 @@ struct PhaseBody {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < GT; ++i) cur[i] = nxt[i];
-            groups<GI + 1>(xin, acc, ch, cur, ring, mask, slope, c);
+            groups<GI + 1>(xin, acc, ch, cur, ring, mask, ap, spslot, c);
         }
     }
 };
 
-template <int KA, int CT, int NC, int NB, bool BWD>
+template <int KA, int CT, int NC, int NB, bool BWD, bool SP>
 __device__ __forceinline__ void run_phase(const f32x4 (&xin)[KA], f32x4 (&acc)[NB], Ring& ring,
-                                          const float* biasA, uint16_t* mask, float slope, int g) {
-    using Body = PhaseBody<KA, CT, NC, NB, BWD>;
+                                          const float* biasA, uint16_t* mask, const ActP& ap, int spslot, int g) {
+    using Body = PhaseBody<KA, CT, NC, NB, BWD, SP>;
     f32x4 cur[Body::GT];
     load_group<Body::GT, 0>(cur, ring);
     for (int c = 0; c < NC; ++c) {
@@ -232,7 +272,7 @@ __device__ __forceinline__ void run_phase(const f32x4 (&xin)[KA], f32x4 (&acc)[N
             if (!BWD) ch[ci] = *(const f32x4*)(biasA + 16 * (c * CT + ci) + 4 * g);
             else ch[ci] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        Body::template groups<0>(xin, acc, ch, cur, ring, mask, slope, c);
+        Body::template groups<0>(xin, acc, ch, cur, ring, mask, ap, spslot, c);
     }
 }
 
@@ -242,46 +282,65 @@ __device__ __forceinline__ void run_phase(const f32x4 (&xin)[KA], f32x4 (&acc)[N
 // (broadcast).  A fully unrolled register version made hipcc hoist ~3.5k loads and spill.
 __device__ __forceinline__ int enc_block_off(int j) { return j < 3 ? 120 * j : 360 + 180 * (j - 3); }
 
-template <int IN>
+// Derivative record of one joint: relu family = 16 sign bits, softplus = 16 floats (10 hidden + 6 output).
+template <bool SP>
+struct JointD {
+    uint32_t bits;
+    float dv[SP ? 16 : 1];
+};
+
+template <int IN, bool SP>
 __device__ __forceinline__ void enc_joint_fwd(const float* w, const float (&in)[IN], float (&f)[FEAT],
-                                              uint32_t& bits, float slope) {
+                                              JointD<SP>& jd, const ActP& ap) {
     constexpr int B1 = HID * IN, W2 = B1 + 12, B2 = W2 + FEAT * HID;
     float h[HID];
-    bits = 0;
+    jd.bits = 0;
 #pragma unroll
     for (int u = 0; u < HID; ++u) {
         float z = w[B1 + u];
 #pragma unroll
         for (int i = 0; i < IN; ++i) z = fmaf(w[u * IN + i], in[i], z);
-        bool pos;
-        h[u] = act_relu(z, slope, pos);
-        bits |= pos ? (1u << u) : 0u;
+        if constexpr (SP) {
+            h[u] = act_softplus(z, ap.beta, jd.dv[u]);
+        } else {
+            bool pos;
+            h[u] = act_relu(z, ap.slope, pos);
+            jd.bits |= pos ? (1u << u) : 0u;
+        }
     }
 #pragma unroll
     for (int o = 0; o < FEAT; ++o) {
         float z = w[B2 + o];
 #pragma unroll
         for (int u = 0; u < HID; ++u) z = fmaf(w[W2 + o * HID + u], h[u], z);
-        bool pos;
-        f[o] = act_relu(z, slope, pos);
-        bits |= pos ? (1u << (HID + o)) : 0u;
+        if constexpr (SP) {
+            f[o] = act_softplus(z, ap.beta, jd.dv[HID + o]);
+        } else {
+            bool pos;
+            f[o] = act_relu(z, ap.slope, pos);
+            jd.bits |= pos ? (1u << (HID + o)) : 0u;
+        }
     }
 }
 
-template <int IN>
+template <int IN, bool SP>
 __device__ __forceinline__ void enc_joint_bwd(const float* w, const float (&gfj)[FEAT], float (&gin)[IN],
-                                              uint32_t bits, float slope) {
+                                              const JointD<SP>& jd, const ActP& ap) {
     constexpr int W2 = HID * IN + 12;
     float gz2[FEAT];
 #pragma unroll
-    for (int o = 0; o < FEAT; ++o) gz2[o] = ((bits >> (HID + o)) & 1u) ? gfj[o] : gfj[o] * slope;
+    for (int o = 0; o < FEAT; ++o) {
+        if constexpr (SP) gz2[o] = gfj[o] * jd.dv[HID + o];
+        else gz2[o] = ((jd.bits >> (HID + o)) & 1u) ? gfj[o] : gfj[o] * ap.slope;
+    }
     float gz1[HID];
 #pragma unroll
     for (int u = 0; u < HID; ++u) {
         float s = 0.f;
 #pragma unroll
         for (int o = 0; o < FEAT; ++o) s = fmaf(w[W2 + o * HID + u], gz2[o], s);
-        gz1[u] = ((bits >> u) & 1u) ? s : s * slope;
+        if constexpr (SP) gz1[u] = s * jd.dv[u];
+        else gz1[u] = ((jd.bits >> u) & 1u) ? s : s * ap.slope;
     }
 #pragma unroll
     for (int i = 0; i < IN; ++i) {
@@ -303,8 +362,11 @@ __device__ __forceinline__ void joint_axis_norms(const float* my_q, float (&ss)[
     }
 }
 
+// softplus: encoder derivatives of pose wp live in the workgroup scratch as [joint][4][64 poses] float4
+template <bool SP>
 __device__ __forceinline__ void encoder_forward(const float* ew, const float* my_q, float* my_f,
-                                                uint16_t* my_em, const int* parent, float slope) {
+                                                uint16_t* my_em, f32x4* enc_sp, bool writer, const int* parent,
+                                                const ActP& ap) {
     float ss[4], denom[4];
     joint_axis_norms(my_q, ss);
 #pragma unroll
@@ -313,12 +375,12 @@ __device__ __forceinline__ void encoder_forward(const float* ew, const float* my
         const f32x4 qj = *(const f32x4*)(my_q + 4 * j);
         const float* w = ew + enc_block_off(j);
         float f[FEAT];
-        uint32_t bits;
+        JointD<SP> jd;
         if (j < 3) {
             float in[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) in[c] = qj[c] / denom[c];
-            enc_joint_fwd<4>(w, in, f, bits, slope);
+            enc_joint_fwd<4, SP>(w, in, f, jd, ap);
         } else {
             float in[10];
 #pragma unroll
@@ -326,32 +388,52 @@ __device__ __forceinline__ void encoder_forward(const float* ew, const float* my
             const float* pf = my_f + FEAT * parent[j];     // cat(quat, parent feature), net_modules.py:167
 #pragma unroll
             for (int i = 0; i < FEAT; ++i) in[4 + i] = pf[i];
-            enc_joint_fwd<10>(w, in, f, bits, slope);
+            enc_joint_fwd<10, SP>(w, in, f, jd, ap);
         }
 #pragma unroll
         for (int i = 0; i < FEAT; ++i) my_f[FEAT * j + i] = f[i];
-        my_em[j] = (uint16_t)bits;
+        if constexpr (SP) {
+            if (writer) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    enc_sp[(j * 4 + k) * WG_POSES] = f32x4{jd.dv[4 * k], jd.dv[4 * k + 1], jd.dv[4 * k + 2], jd.dv[4 * k + 3]};
+            }
+        } else {
+            my_em[j] = (uint16_t)jd.bits;
+        }
     }
     my_f[126] = 0.f;
     my_f[127] = 0.f;
 }
 
 // consumes d d / d feature in my_f (accumulating into parents), leaves d d / d n in my_gn
+template <bool SP>
 __device__ __forceinline__ void encoder_backward(const float* ew, float* my_f, float* my_gn,
-                                                 const uint16_t* my_em, const int* parent, float slope) {
+                                                 const uint16_t* my_em, const f32x4* enc_sp, const int* parent,
+                                                 const ActP& ap) {
     for (int j = NJ - 1; j >= 0; --j) {
         const float* w = ew + enc_block_off(j);
-        const uint32_t bits = my_em[j];
+        JointD<SP> jd;
+        if constexpr (SP) {
+            jd.bits = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 v = enc_sp[(j * 4 + k) * WG_POSES];
+                jd.dv[4 * k] = v[0]; jd.dv[4 * k + 1] = v[1]; jd.dv[4 * k + 2] = v[2]; jd.dv[4 * k + 3] = v[3];
+            }
+        } else {
+            jd.bits = my_em[j];
+        }
         float gfj[FEAT];
 #pragma unroll
         for (int i = 0; i < FEAT; ++i) gfj[i] = my_f[FEAT * j + i];
         if (j < 3) {
             float gin[4];
-            enc_joint_bwd<4>(w, gfj, gin, bits, slope);
+            enc_joint_bwd<4, SP>(w, gfj, gin, jd, ap);
             *(f32x4*)(my_gn + 4 * j) = f32x4{gin[0], gin[1], gin[2], gin[3]};
         } else {
             float gin[10];
-            enc_joint_bwd<10>(w, gfj, gin, bits, slope);
+            enc_joint_bwd<10, SP>(w, gfj, gin, jd, ap);
             *(f32x4*)(my_gn + 4 * j) = f32x4{gin[0], gin[1], gin[2], gin[3]};
             float* pf = my_f + FEAT * parent[j];
 #pragma unroll
@@ -366,29 +448,48 @@ __device__ __forceinline__ void load_bias(f32x4 (&acc)[NT], const float* bias, i
     for (int t = 0; t < NT; ++t) acc[t] = *(const f32x4*)(bias + 16 * t + 4 * g);
 }
 
-// activation of an accumulator layer; derivative bits kept in registers (NT*4 bits)
-template <int NT>
-__device__ __forceinline__ void act_tiles(f32x4 (&x)[NT], uint32_t (&m)[(NT * 4 + 31) / 32], float slope) {
+// activation of an accumulator layer; relu family: derivative bits kept in registers (NT*4 bits);
+// softplus: derivatives to the scratch slots [spslot, spslot + NT)
+template <int NT, bool SP>
+__device__ __forceinline__ void act_tiles(f32x4 (&x)[NT], uint32_t (&m)[(NT * 4 + 31) / 32], const ActP& ap, int spslot) {
+    if constexpr (SP) {
 #pragma unroll
-    for (int w = 0; w < (NT * 4 + 31) / 32; ++w) m[w] = 0;
+        for (int t = 0; t < NT; ++t) {
+            f32x4 dv;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+            for (int r = 0; r < 4; ++r) {
+                float dr;
+                x[t][r] = act_softplus(x[t][r], ap.beta, dr);
+                dv[r] = dr;
+            }
+            ap.sp[(size_t)(spslot + t) * WG_THREADS] = dv;
+        }
+    } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            bool pos;
-            x[t][r] = act_relu(x[t][r], slope, pos);
-            m[(t * 4 + r) / 32] |= (pos ? 1u : 0u) << ((t * 4 + r) % 32);
+        for (int w = 0; w < (NT * 4 + 31) / 32; ++w) m[w] = 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bool pos;
+                x[t][r] = act_relu(x[t][r], ap.slope, pos);
+                m[(t * 4 + r) / 32] |= (pos ? 1u : 0u) << ((t * 4 + r) % 32);
+            }
         }
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void dact_tiles(f32x4 (&gx)[NT], const uint32_t (&m)[(NT * 4 + 31) / 32], float slope) {
+template <int NT, bool SP>
+__device__ __forceinline__ void dact_tiles(f32x4 (&gx)[NT], const uint32_t (&m)[(NT * 4 + 31) / 32], const ActP& ap, int spslot) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+        if constexpr (SP) {
+            gx[t] = gx[t] * ap.sp[(size_t)(spslot + t) * WG_THREADS];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            gx[t][r] = ((m[(t * 4 + r) / 32] >> ((t * 4 + r) % 32)) & 1u) ? gx[t][r] : gx[t][r] * slope;
+            for (int r = 0; r < 4; ++r)
+                gx[t][r] = ((m[(t * 4 + r) / 32] >> ((t * 4 + r) % 32)) & 1u) ? gx[t][r] : gx[t][r] * ap.slope;
+        }
     }
 }
 
@@ -416,12 +517,14 @@ struct PndfKernelArgs {
     int steps;
     int mode;
     float slope;            // 0 = relu, 0.01 = lrelu
+    float beta;             // softplus beta
+    float* scratch;         // softplus: gridDim.x * SP_WG_FLOATS floats of derivative scratch, else null
 };
 
 __constant__ int PNDF_PARENT[NJ] = {-1, -1, -1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19};
 
-template <bool DBG>
-__device__ __forceinline__ void pndf_fused_relu_body(const PndfKernelArgs& args) {
+template <bool DBG, bool SP>
+__device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -429,7 +532,12 @@ __device__ __forceinline__ void pndf_fused_relu_body(const PndfKernelArgs& args)
     const int g = lane >> 4;          // lane group = k_local of the MFMA
     const int p = lane & 15;          // pose within the wave
     const int wp = wave * 16 + p;     // pose within the workgroup
-    const float slope = args.slope;
+    ActP ap;
+    ap.slope = args.slope;
+    ap.beta = args.beta;
+    float* const wg_scratch = SP ? args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS : nullptr;
+    ap.sp = SP ? (f32x4*)wg_scratch + tid : nullptr;
+    f32x4* const enc_sp = SP ? (f32x4*)(wg_scratch + SP_SLOTS * WG_THREADS * 4) + wp : nullptr;
     const long long pose0 = (long long)blockIdx.x * WG_POSES;
     float* const ew = (float*)(smem + LDS_ENC);
     float* const lds_bias = (float*)(smem + LDS_BIAS);
@@ -477,7 +585,7 @@ __device__ __forceinline__ void pndf_fused_relu_body(const PndfKernelArgs& args)
             f32x4 x2[32];
             {
                 // ---------------- normalise + encoder forward (posendf.py:71, net_modules.py:162-169)
-                encoder_forward(ew, my_q, my_f, my_em, PNDF_PARENT, slope);
+                encoder_forward<SP>(ew, my_q, my_f, my_em, enc_sp, g == 0, PNDF_PARENT, ap);
                 if (DBG && dbg && step == 0) {
                     for (int i = 0; i < NFEAT; ++i) dbg[(size_t)(DBG_FEAT + i) * WG_THREADS + tid] = my_f[i];
                 }
@@ -487,21 +595,21 @@ __device__ __forceinline__ void pndf_fused_relu_body(const PndfKernelArgs& args)
                 for (int kt = 0; kt < 8; ++kt) x0[kt] = *(const f32x4*)(my_f + 16 * kt + 4 * g);
                 // ---------------- trunk forward
                 load_bias<32>(x2, lds_bias + BIAS_OFF[1], g);
-                run_phase<8, 2, 8, 32, false>(x0, x2, ring, lds_bias + BIAS_OFF[0],
-                                              lds_mask + MASK_BASE[0] * WG_THREADS, slope, g);
+                run_phase<8, 2, 8, 32, false, SP>(x0, x2, ring, lds_bias + BIAS_OFF[0],
+                                                  lds_mask + MASK_BASE[0] * WG_THREADS, ap, SP_SLOT_CHUNK[0], g);
             }
-            act_tiles<32>(x2, m2, slope);
+            act_tiles<32, SP>(x2, m2, ap, SP_SLOT_X2);
             if (DBG && dbg && step == 0) dump_tiles<32>(dbg, DBG_X2, x2, tid);
             load_bias<32>(x4, lds_bias + BIAS_OFF[3], g);
-            run_phase<32, 2, 32, 32, false>(x2, x4, ring, lds_bias + BIAS_OFF[2],
-                                            lds_mask + MASK_BASE[1] * WG_THREADS, slope, g);
+            run_phase<32, 2, 32, 32, false, SP>(x2, x4, ring, lds_bias + BIAS_OFF[2],
+                                                lds_mask + MASK_BASE[1] * WG_THREADS, ap, SP_SLOT_CHUNK[1], g);
         }
-        act_tiles<32>(x4, m4, slope);
+        act_tiles<32, SP>(x4, m4, ap, SP_SLOT_X4);
         if (DBG && dbg && step == 0) dump_tiles<32>(dbg, DBG_X4, x4, tid);
         load_bias<4>(x6, lds_bias + BIAS_OFF[5], g);
-        run_phase<32, 4, 4, 4, false>(x4, x6, ring, lds_bias + BIAS_OFF[4],
-                                      lds_mask + MASK_BASE[2] * WG_THREADS, slope, g);
-        act_tiles<4>(x6, m6, slope);
+        run_phase<32, 4, 4, 4, false, SP>(x4, x6, ring, lds_bias + BIAS_OFF[4],
+                                          lds_mask + MASK_BASE[2] * WG_THREADS, ap, SP_SLOT_CHUNK[2], g);
+        act_tiles<4, SP>(x6, m6, ap, SP_SLOT_X6);
         if (DBG && dbg && step == 0) dump_tiles<4>(dbg, DBG_X6, x6, tid);
 
         // ---------------- lin6 (64 -> 1) + output ReLU  (net_modules.py:64-69)
@@ -516,12 +624,17 @@ __device__ __forceinline__ void pndf_fused_relu_body(const PndfKernelArgs& args)
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);
         const float z7 = part + lds_bias[BIAS_OFF[6]];
-        dval = fmaxf(z7, 0.f);
+        float gz7;
+        if constexpr (SP) {
+            dval = act_softplus(z7, ap.beta, gz7);      // output Softplus, net_modules.py:39-41,69
+        } else {
+            dval = fmaxf(z7, 0.f);                       // output ReLU for relu AND lrelu, net_modules.py:30-37
+            gz7 = (z7 > 0.f) ? 1.f : 0.f;
+        }
         if (DBG && dbg && step == 0) dbg[(size_t)DBG_D * WG_THREADS + tid] = dval;
         if (args.mode == MODE_FORWARD) break;
 
         // ---------------- trunk backward: d d / d x, masks from the forward pass
-        float gz7 = (z7 > 0.f) ? 1.f : 0.f;
         if (args.mode == MODE_FORWARD_GRAD && args.grad_out) {
             long long pidx = pose0 + wp;
             if (pidx >= args.B) pidx = args.B - 1;
@@ -530,7 +643,7 @@ __device__ __forceinline__ void pndf_fused_relu_body(const PndfKernelArgs& args)
         f32x4 g6[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) g6[t] = w6[t] * gz7;
-        dact_tiles<4>(g6, m6, slope);
+        dact_tiles<4, SP>(g6, m6, ap, SP_SLOT_X6);
         {
             f32x4 g0[8];
             {
@@ -539,18 +652,21 @@ __device__ __forceinline__ void pndf_fused_relu_body(const PndfKernelArgs& args)
                     f32x4 g4[32];
 #pragma unroll
                     for (int t = 0; t < 32; ++t) g4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    run_phase<4, 4, 4, 32, true>(g6, g4, ring, nullptr, lds_mask + MASK_BASE[2] * WG_THREADS, slope, g);
-                    dact_tiles<32>(g4, m4, slope);
+                    run_phase<4, 4, 4, 32, true, SP>(g6, g4, ring, nullptr, lds_mask + MASK_BASE[2] * WG_THREADS, ap,
+                                                     SP_SLOT_CHUNK[2], g);
+                    dact_tiles<32, SP>(g4, m4, ap, SP_SLOT_X4);
                     if (DBG && dbg && step == 0) dump_tiles<32>(dbg, DBG_G4, g4, tid);
 #pragma unroll
                     for (int t = 0; t < 32; ++t) g2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    run_phase<32, 2, 32, 32, true>(g4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, slope, g);
+                    run_phase<32, 2, 32, 32, true, SP>(g4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, ap,
+                                                       SP_SLOT_CHUNK[1], g);
                 }
-                dact_tiles<32>(g2, m2, slope);
+                dact_tiles<32, SP>(g2, m2, ap, SP_SLOT_X2);
                 if (DBG && dbg && step == 0) dump_tiles<32>(dbg, DBG_G2, g2, tid);
 #pragma unroll
                 for (int t = 0; t < 8; ++t) g0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                run_phase<32, 2, 8, 8, true>(g2, g0, ring, nullptr, lds_mask + MASK_BASE[0] * WG_THREADS, slope, g);
+                run_phase<32, 2, 8, 8, true, SP>(g2, g0, ring, nullptr, lds_mask + MASK_BASE[0] * WG_THREADS, ap,
+                                                 SP_SLOT_CHUNK[0], g);
             }
             if (DBG && dbg && step == 0) dump_tiles<8>(dbg, DBG_G0, g0, tid);
             // d d / d feature back to the per-pose buffer: lane (g, p) owns features 16 t + 4 g + r
@@ -562,7 +678,7 @@ __device__ __forceinline__ void pndf_fused_relu_body(const PndfKernelArgs& args)
         __syncthreads();
 
         // ---------------- encoder backward + normalise backward + update
-        encoder_backward(ew, my_f, my_gn, my_em, PNDF_PARENT, slope);
+        encoder_backward<SP>(ew, my_f, my_gn, my_em, enc_sp, PNDF_PARENT, ap);
         if (DBG && dbg && step == 0) {
             for (int i = 0; i < NQ; ++i) dbg[(size_t)(DBG_GN + i) * WG_THREADS + tid] = my_gn[i];
         }
@@ -626,14 +742,21 @@ __device__ __forceinline__ void pndf_fused_relu_body(const PndfKernelArgs& args)
 
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1)
 pndf_fused_relu_kernel(PndfKernelArgs args) {
-    pndf_fused_relu_body<false>(args);
+    pndf_fused_body<false, false>(args);
 }
 
-// Same kernel with per-stage register dumps from workgroup 0 (tests / bring-up only).
+// Softplus(beta) variant (the reference's published checkpoints): fp32 derivatives go through `scratch`.
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1)
+pndf_fused_softplus_kernel(PndfKernelArgs args) {
+    pndf_fused_body<false, true>(args);
+}
+
+// relu-family kernel with per-stage register dumps from workgroup 0 (tests / bring-up only).
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1)
 pndf_fused_relu_kernel_dbg(PndfKernelArgs args) {
-    pndf_fused_relu_body<true>(args);
+    pndf_fused_body<true, false>(args);
 }
 
 extern "C" int pndf_kernel_lds_bytes() { return LDS_TOTAL; }
 extern "C" int pndf_kernel_dbg_floats() { return DBG_TOTAL * WG_THREADS; }
+extern "C" long long pndf_kernel_softplus_scratch_floats_per_wg() { return SP_WG_FLOATS; }

@@ -41,9 +41,11 @@ def test_create_rejects_unsupported(lib):
     from posendf_amd.engine import PndfConfig
     h = ctypes.c_void_p()
     cfg = PndfConfig()
-    lib.pndf_default_config(ctypes.byref(cfg), 2, 100.0)            # softplus
+    lib.pndf_default_config(ctypes.byref(cfg), 7, 100.0)            # unknown activation code
     assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -4
     assert b"activation" in lib.pndf_last_error(None)
+    lib.pndf_default_config(ctypes.byref(cfg), 2, -1.0)             # softplus needs beta > 0
+    assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -1
     lib.pndf_default_config(ctypes.byref(cfg), 1, 100.0)
     cfg.dims[2] = 384                                               # other architecture
     assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -4

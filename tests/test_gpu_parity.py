@@ -28,7 +28,10 @@ def make_net(torch, act, regime=None, sd=None):
     return net
 
 
-@pytest.mark.parametrize("act", ["lrelu", "relu"])
+ALL_ACTS = ["lrelu", "relu", "softplus"]
+
+
+@pytest.mark.parametrize("act", ALL_ACTS)
 @pytest.mark.parametrize("regime", list(REGIMES))
 def test_golden_single_step(torch_cuda, act, regime):
     torch = torch_cuda
@@ -44,13 +47,14 @@ def test_golden_single_step(torch_cuda, act, regime):
     with torch.no_grad():
         d2 = net(torch.from_numpy(g["q"]), train=False)["dist_pred"]      # CPU tensor is moved (posendf.py:64)
     assert torch.equal(d2, d.detach())
-    # clipped poses: exactly zero distance and exactly zero gradient
-    z = g["d_f32"][:, 0] == 0
-    assert np.array_equal(d.detach().cpu().numpy()[:, 0] == 0, z)
-    assert np.all(dq.cpu().numpy()[z] == 0)
+    if act != "softplus":
+        # clipped poses: exactly zero distance and exactly zero gradient
+        z = g["d_f32"][:, 0] == 0
+        assert np.array_equal(d.detach().cpu().numpy()[:, 0] == 0, z)
+        assert np.all(dq.cpu().numpy()[z] == 0)
 
 
-@pytest.mark.parametrize("act", ["lrelu", "relu"])
+@pytest.mark.parametrize("act", ALL_ACTS)
 def test_golden_autograd_contract(torch_cuda, act):
     """backward with an arbitrary upstream gradient (motion_denoise.py:82-83,97-98) and the pose-prior
     objective 1e7 c^2 / (1 + it) of motion_denoise.py:33."""
@@ -73,7 +77,7 @@ def test_golden_autograd_contract(torch_cuda, act):
                      2 * TOL, "prior")
 
 
-@pytest.mark.parametrize("act", ["lrelu", "relu"])
+@pytest.mark.parametrize("act", ALL_ACTS)
 @pytest.mark.parametrize("regime", list(REGIMES))
 def test_golden_projection(torch_cuda, act, regime):
     """1/10/100-step projection vs the reference.  Single step: 1e-4.  Free-running: measured against the
@@ -96,24 +100,25 @@ def test_golden_projection(torch_cuda, act, regime):
             else d_err(dl.cpu().numpy()[:, 0], g["dtrace_f32"][0]) < TOL
 
 
+@pytest.mark.parametrize("act", ["lrelu", "softplus"])
 @pytest.mark.parametrize("B", [1, 15, 63, 64, 65, 257, 1000])
-def test_ragged_batches_match_oracle(torch_cuda, B):
+def test_ragged_batches_match_oracle(torch_cuda, B, act):
     torch = torch_cuda
     from oracle import posendf_np as onp
     from posendf_amd import synth
     sd = golden_weights("mixed")
-    net = make_net(torch, "lrelu", sd=sd)
+    net = make_net(torch, act, sd=sd)
     qn = synth.make_poses(B, seed=100 + B, signed=True)
     q = torch.from_numpy(qn).cuda().requires_grad_(True)
     d = net(q, train=False)["dist_pred"]
     (dq,) = torch.autograd.grad(d.sum(), q)
-    do, go = onp.forward_grad(qn, sd, "lrelu")
-    _, g64 = onp.forward_grad(qn, sd, "lrelu", dtype=np.float64)
+    do, go = onp.forward_grad(qn, sd, act)
+    _, g64 = onp.forward_grad(qn, sd, act, dtype=np.float64)
     assert d_err(d.detach().cpu().numpy(), do) < TOL
     outlier_gate(rel_err_rows(dq.cpu().numpy(), g64), rel_err_rows(go, g64), TOL, "dq")
     qp, _ = net.project(q.detach(), steps=4)
-    q64, _ = onp.project(qn, sd, steps=4, dtype=np.float64)
-    q32, _ = onp.project(qn, sd, steps=4)
+    q64, _ = onp.project(qn, sd, steps=4, act=act, dtype=np.float64)
+    q32, _ = onp.project(qn, sd, steps=4, act=act)
     outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project4")
 
 
@@ -193,9 +198,11 @@ def test_weight_reload_and_errors(torch_cuda):
         net.dfnet.lin6.bias.add_(1.0)                      # in-place parameter update is seen too
     d_c = net(q, train=False)["dist_pred"]
     assert torch.allclose(d_c, d_b + 1.0, atol=1e-5)
-    with pytest.raises(PndfError):                         # softplus: not implemented -> loud failure
-        sp = PoseNDF(amass_config("softplus", "cuda:0"))
-        sp(q, train=False)
+    cfg = amass_config("lrelu", "cuda:0")
+    cfg["model"]["StrEnc"]["use"] = False                  # in_dim = 84 variant: not implemented -> loud failure
+    cfg["model"]["DFNet"]["in_dim"] = 84
+    with pytest.raises(PndfError):
+        PoseNDF(cfg)(q, train=False)
     with pytest.raises(RuntimeError):                      # no double backward on the engine path
         qq = q.clone().requires_grad_(True)
         dd = net(qq, train=False)["dist_pred"]
