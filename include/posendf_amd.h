@@ -82,6 +82,13 @@ int pndf_debug_forward_grad(pndf_handle h, const float* q, float* d, float* dq, 
                             void* stream);
 int64_t pndf_debug_floats(void);
 
+/* Performance analysis aid: pndf_project through a kernel instrumented with s_memtime stamps.
+ * cycles[(workgroup * 4 + wave) * pndf_debug_timing_regions() + r] = shader cycles spent in region r
+ * (device buffer of ceil(B/64) * 4 * regions uint64). */
+int pndf_debug_project_timing(pndf_handle h, const float* q_in, float* q_out, int64_t B, int steps,
+                              unsigned long long* cycles, void* stream);
+int pndf_debug_timing_regions(void);
+
 /* Host-only weight packer (what pndf_load_weights uploads); needs no device.  Output sizes in floats come
  * from pndf_packed_sizes.  Used by the CPU tests that check the MFMA tile order against a lane-level model. */
 void pndf_packed_sizes(int64_t* stream_floats, int64_t* enc_floats, int64_t* bias_floats);

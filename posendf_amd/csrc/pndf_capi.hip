@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -28,9 +29,12 @@ struct PndfKernelArgs {
     float slope;
     float beta;
     float* scratch;
+    int dbg_nslots;
 };
 extern "C" __global__ void pndf_fused_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_softplus_kernel(PndfKernelArgs args);
+extern "C" __global__ void pndf_fused_relu_kernel_timing(PndfKernelArgs args);
+extern "C" int pndf_kernel_timing_regions();
 extern "C" long long pndf_kernel_softplus_scratch_floats_per_wg();
 extern "C" __global__ void pndf_fused_relu_kernel_dbg(PndfKernelArgs args);
 extern "C" int pndf_kernel_lds_bytes();
@@ -117,6 +121,8 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
         e = hipFuncSetAttribute((const void*)pndf_fused_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_softplus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)pndf_fused_relu_kernel_timing, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_relu_kernel_dbg, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e != hipSuccess) {
@@ -236,7 +242,7 @@ extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, con
 
 // ------------------------------------------------------------------------------------------ launches
 static int launch(pndf_engine* h, int mode, const float* q, const float* gout, float* qo, float* d, int64_t B,
-                  int steps, float* dbg, void* stream) {
+                  int steps, float* dbg, void* stream, bool timing = false) {
     if (!h) return PNDF_ERR_BAD_ARG;
     if (!h->have_weights) return fail(h, PNDF_ERR_NO_WEIGHTS, "pndf_load_weights has not been called");
     if (B < 0 || steps < 0) return fail(h, PNDF_ERR_BAD_ARG, "negative batch or step count");
@@ -252,6 +258,8 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
     a.slope = (h->cfg.act == PNDF_ACT_LRELU) ? 0.01f : 0.0f;   // nn.LeakyReLU() default slope, net_modules.py:31
     a.beta = h->cfg.beta;
     a.scratch = nullptr;
+    a.dbg_nslots = 0;
+    if (const char* e = getenv("PNDF_DEBUG_NSLOTS")) a.dbg_nslots = atoi(e);   // timing experiments only
     const bool softplus = h->cfg.act == PNDF_ACT_SOFTPLUS;
     if (softplus && dbg) return fail(h, PNDF_ERR_UNSUPPORTED, "the debug dump exists for the relu-family kernel only");
     if (mode == MODE_PROJECT && steps == 0) {
@@ -278,7 +286,8 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
         HIP_TRY(h, hipGetLastError());
         return PNDF_OK;
     }
-    if (dbg) hipLaunchKernelGGL(pndf_fused_relu_kernel_dbg, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+    if (timing) hipLaunchKernelGGL(pndf_fused_relu_kernel_timing, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+    else if (dbg) hipLaunchKernelGGL(pndf_fused_relu_kernel_dbg, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else hipLaunchKernelGGL(pndf_fused_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     HIP_TRY(h, hipGetLastError());
     return PNDF_OK;
@@ -304,4 +313,14 @@ extern "C" int pndf_debug_forward_grad(pndf_handle h, const float* q, float* d, 
                                        void* stream) {
     if (!dump) return fail(h, PNDF_ERR_BAD_ARG, "dump is null");
     return launch(h, MODE_FORWARD_GRAD, q, nullptr, dq, d, B, 1, dump, stream);
+}
+
+extern "C" int pndf_debug_timing_regions(void) { return pndf_kernel_timing_regions(); }
+
+// project() through the instrumented kernel; cycles[(wg * 4 + wave) * regions + r] = shader cycles
+extern "C" int pndf_debug_project_timing(pndf_handle h, const float* q_in, float* q_out, int64_t B, int steps,
+                                         unsigned long long* cycles, void* stream) {
+    if (!cycles) return fail(h, PNDF_ERR_BAD_ARG, "cycles is null");
+    if (h && h->cfg.act == PNDF_ACT_SOFTPLUS) return fail(h, PNDF_ERR_UNSUPPORTED, "timing kernel is relu-family only");
+    return launch(h, MODE_PROJECT, q_in, nullptr, q_out, nullptr, B, steps, (float*)cycles, stream, true);
 }

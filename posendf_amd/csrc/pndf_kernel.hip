@@ -104,9 +104,14 @@ __device__ __forceinline__ void ring_start(Ring& r) {
 __device__ __forceinline__ void ring_boundary(Ring& r) { r.cur = (r.cur == 2) ? 0 : r.cur + 1; }
 
 // tile 8 of a slot: one barrier, then prefetch two slots ahead into the buffer of the previous slot
+// A raw s_barrier, not __syncthreads(): the latter's fence adds `s_waitcnt lgkmcnt(0)`, i.e. it waits for the
+// tile prefetch issued a few instructions earlier.  What the barrier has to order is already ordered: every
+// wave's DMA share of the next slot has landed (its own vmcnt(0) above), and every read of the previous slot
+// returned long ago (its data has been consumed by MFMAs issued before this point).
 __device__ __forceinline__ void ring_midslot(Ring& r) {
     ring_wait_dma();
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     ring_dma(r, (r.cur == 0) ? 2 : r.cur - 1);
 }
 
@@ -123,6 +128,19 @@ __device__ __forceinline__ float act_relu(float z, float slope, bool& pos) {
     pos = z > 0.0f;
     return pos ? z : z * slope;
 }
+
+// Branch-free form used on the MFMA path: step(z) = (z > 0 ? 1.0f : 0.0f) EXACTLY for every finite z, built
+// from two multiplies with the free [0,1] clamp output modifier (no v_cmp / VCC / v_cndmask chain).
+// z = +-0 -> 0, z < 0 -> 0, smallest denormal 2^-149 * 2^64 * 2^127 >= 1 -> 1.
+__device__ __forceinline__ float step01(float z) {
+    float t;
+    asm("v_mul_f32 %0, %1, %2 clamp" : "=v"(t) : "v"(z), "s"(0x1p64f));
+    float u;
+    asm("v_mul_f32 %0, %1, %2 clamp" : "=v"(u) : "v"(t), "s"(0x1p127f));
+    return u;
+}
+// derivative factor (1 or slope) from the step; activation = z * factor (relu: -0 for z < 0)
+__device__ __forceinline__ float relu_factor(float step, float slope) { return fmaf(step, 1.0f - slope, slope); }
 
 // nn.Softplus(beta, threshold=20) (net_modules.py:39-40): x if beta x > 20 else log1p(exp(beta x)) / beta;
 // derivative as PyTorch's softplus_backward: e / (e + 1) with e = exp(beta x), 1 above the threshold.
@@ -152,6 +170,23 @@ constexpr int SP_WG_FLOATS = SP_SLOTS * WG_THREADS * 4 + SP_ENC_FLOATS;
 // parked in LDS; backward: chunk accumulators start at 0 and are multiplied by the parked derivative.
 // Weight tiles are consumed in groups of GT = 2 CT tiles; the group after the current one is read from
 // LDS before the current group's MFMAs are issued (hipcc does not software-pipeline this by itself).
+constexpr int TIMING_REGIONS = 12;
+constexpr int TIMING_GROUPS = 32;     // per-group stamps inside the (lin2,lin3) phase
+// s_memtime stamps at region boundaries (TIMING instantiation only): accumulates shader cycles per region
+struct RegionClock {
+    unsigned long long acc[TIMING_REGIONS];
+    unsigned long long grp[TIMING_GROUPS];
+    unsigned long long last;
+};
+template <bool TIMING>
+__device__ __forceinline__ void tick(RegionClock& rc, int region) {
+    if constexpr (TIMING) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        rc.acc[region] += now - rc.last;
+        rc.last = now;
+    }
+}
+
 template <int GT, int T0>
 __device__ __forceinline__ void load_group(f32x4 (&a)[GT], Ring& ring) {
 #pragma unroll
@@ -165,7 +200,7 @@ __device__ __forceinline__ void load_group(f32x4 (&a)[GT], Ring& ring) {
     }
 }
 
-template <int KA, int CT, int NC, int NB, bool BWD, bool SP>
+template <int KA, int CT, int NC, int NB, bool BWD, bool SP, bool GTIME = false>
 struct PhaseBody {
     static constexpr int GT = 2 * CT;                 // tiles per group
     static constexpr int NGA = KA / 2;                // part-A groups (two k-tiles each)
@@ -180,7 +215,7 @@ struct PhaseBody {
     template <int GI>
     static __device__ __forceinline__ void groups(const f32x4 (&xin)[KA], f32x4 (&acc)[NB], f32x4 (&ch)[CT],
                                                   f32x4 (&cur)[GT], Ring& ring, uint16_t* mask, const ActP& ap,
-                                                  int spslot, int c) {
+                                                  int spslot, int c, RegionClock* rc) {
         if constexpr (GI < NG) {
             f32x4 nxt[GT];
             constexpr int TNEXT = ((GI + 1) * GT) % CHUNK_TILES;
@@ -217,24 +252,26 @@ struct PhaseBody {
                             }
                         }
                     } else if (!BWD) {
-                        uint32_t bits = 0;
+                        // sign bits are summed as st * 2^k in ONE fp32 chain (exact below 2^24): a float chain cannot
+                        // be reassociated or deferred piecewise, so every step value dies at once
+                        float bitsum = 0.f;
 #pragma unroll
                         for (int ci = 0; ci < CT; ++ci) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                bool pos;
-                                ch[ci][r] = act_relu(ch[ci][r], ap.slope, pos);
-                                bits |= pos ? (1u << (ci * 4 + r)) : 0u;
+                                const float st = step01(ch[ci][r]);
+                                ch[ci][r] = ch[ci][r] * relu_factor(st, ap.slope);
+                                bitsum = fmaf(st, (float)(1u << (ci * 4 + r)), bitsum);
                             }
                         }
-                        mask[c * WG_THREADS] = (uint16_t)bits;
+                        mask[c * WG_THREADS] = (uint16_t)(uint32_t)bitsum;
                     } else {
                         const uint32_t bits = mask[c * WG_THREADS];
 #pragma unroll
                         for (int ci = 0; ci < CT; ++ci) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                ch[ci][r] = ((bits >> (ci * 4 + r)) & 1u) ? ch[ci][r] : ch[ci][r] * ap.slope;
+                                ch[ci][r] = ch[ci][r] * relu_factor((float)((bits >> (ci * 4 + r)) & 1u), ap.slope);
                         }
                     }
                 }
@@ -254,15 +291,21 @@ struct PhaseBody {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < GT; ++i) cur[i] = nxt[i];
-            groups<GI + 1>(xin, acc, ch, cur, ring, mask, ap, spslot, c);
+            if constexpr (GTIME) {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                rc->grp[GI] += now - rc->last;
+                rc->last = now;
+            }
+            groups<GI + 1>(xin, acc, ch, cur, ring, mask, ap, spslot, c, rc);
         }
     }
 };
 
-template <int KA, int CT, int NC, int NB, bool BWD, bool SP>
+template <int KA, int CT, int NC, int NB, bool BWD, bool SP, bool GTIME = false>
 __device__ __forceinline__ void run_phase(const f32x4 (&xin)[KA], f32x4 (&acc)[NB], Ring& ring,
-                                          const float* biasA, uint16_t* mask, const ActP& ap, int spslot, int g) {
-    using Body = PhaseBody<KA, CT, NC, NB, BWD, SP>;
+                                          const float* biasA, uint16_t* mask, const ActP& ap, int spslot, int g,
+                                          RegionClock* rc = nullptr) {
+    using Body = PhaseBody<KA, CT, NC, NB, BWD, SP, GTIME>;
     f32x4 cur[Body::GT];
     load_group<Body::GT, 0>(cur, ring);
     for (int c = 0; c < NC; ++c) {
@@ -272,7 +315,8 @@ __device__ __forceinline__ void run_phase(const f32x4 (&xin)[KA], f32x4 (&acc)[N
             if (!BWD) ch[ci] = *(const f32x4*)(biasA + 16 * (c * CT + ci) + 4 * g);
             else ch[ci] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        Body::template groups<0>(xin, acc, ch, cur, ring, mask, ap, spslot, c);
+        if constexpr (GTIME) rc->last = __builtin_amdgcn_s_memtime();
+        Body::template groups<0>(xin, acc, ch, cur, ring, mask, ap, spslot, c, rc);
     }
 }
 
@@ -465,16 +509,27 @@ __device__ __forceinline__ void act_tiles(f32x4 (&x)[NT], uint32_t (&m)[(NT * 4 
             ap.sp[(size_t)(spslot + t) * WG_THREADS] = dv;
         }
     } else {
+        constexpr int NW = (NT * 4 + 31) / 32;
+        float lo[NW], hi[NW];      // 16 sign bits each, summed as st * 2^k in fp32 chains (see run_phase)
 #pragma unroll
-        for (int w = 0; w < (NT * 4 + 31) / 32; ++w) m[w] = 0;
+        for (int w = 0; w < NW; ++w) lo[w] = hi[w] = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                bool pos;
-                x[t][r] = act_relu(x[t][r], ap.slope, pos);
-                m[(t * 4 + r) / 32] |= (pos ? 1u : 0u) << ((t * 4 + r) % 32);
+                const float st = step01(x[t][r]);
+                x[t][r] = x[t][r] * relu_factor(st, ap.slope);
+                const int w = (t * 4 + r) / 32, b = (t * 4 + r) % 32;
+                if (b < 16) lo[w] = fmaf(st, (float)(1u << b), lo[w]);
+                else hi[w] = fmaf(st, (float)(1u << (b - 16)), hi[w]);
             }
+        }
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            m[w] = (uint32_t)lo[w] | ((uint32_t)hi[w] << 16);
+            // pin the packing HERE: LLVM otherwise sinks the whole chain to its first use in the backward pass
+            // and keeps (spills) all 128 step values until then (each reload = a memory round trip)
+            asm volatile("" : "+v"(m[w]));
         }
     }
 }
@@ -488,7 +543,7 @@ __device__ __forceinline__ void dact_tiles(f32x4 (&gx)[NT], const uint32_t (&m)[
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                gx[t][r] = ((m[(t * 4 + r) / 32] >> ((t * 4 + r) % 32)) & 1u) ? gx[t][r] : gx[t][r] * ap.slope;
+                gx[t][r] = gx[t][r] * relu_factor((float)((m[(t * 4 + r) / 32] >> ((t * 4 + r) % 32)) & 1u), ap.slope);
         }
     }
 }
@@ -519,11 +574,12 @@ struct PndfKernelArgs {
     float slope;            // 0 = relu, 0.01 = lrelu
     float beta;             // softplus beta
     float* scratch;         // softplus: gridDim.x * SP_WG_FLOATS floats of derivative scratch, else null
+    int dbg_nslots;         // 0, or (timing experiments only, wrong results) wrap the weight stream after n slots
 };
 
 __constant__ int PNDF_PARENT[NJ] = {-1, -1, -1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19};
 
-template <bool DBG, bool SP>
+template <bool DBG, bool SP, bool TIMING = false>
 __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -553,6 +609,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     ring.gstream = args.stream;
     ring.smem = smem;
     ring.nslots = (args.mode == MODE_FORWARD) ? FWD_SLOTS : STEP_SLOTS;
+    if (args.dbg_nslots > 0) ring.nslots = args.dbg_nslots;
     ring.wave = wave;
     ring.lane = lane;
     ring_start(ring);   // slots 0 and 1 in flight; the __syncthreads() below makes them visible
@@ -577,6 +634,14 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
 
     const int nsteps = (args.mode == MODE_PROJECT) ? args.steps : 1;
     float dval = 0.f;
+    RegionClock rc;
+    if constexpr (TIMING) {
+#pragma unroll
+        for (int i = 0; i < TIMING_REGIONS; ++i) rc.acc[i] = 0;
+#pragma unroll
+        for (int i = 0; i < TIMING_GROUPS; ++i) rc.grp[i] = 0;
+        rc.last = __builtin_amdgcn_s_memtime();
+    }
     for (int step = 0; step < nsteps; ++step) {
         uint32_t m2[4], m4[4], m6[1];
         f32x4 x6[4];
@@ -593,22 +658,28 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
                 f32x4 x0[8];
 #pragma unroll
                 for (int kt = 0; kt < 8; ++kt) x0[kt] = *(const f32x4*)(my_f + 16 * kt + 4 * g);
+                tick<TIMING>(rc, 0);
                 // ---------------- trunk forward
                 load_bias<32>(x2, lds_bias + BIAS_OFF[1], g);
                 run_phase<8, 2, 8, 32, false, SP>(x0, x2, ring, lds_bias + BIAS_OFF[0],
                                                   lds_mask + MASK_BASE[0] * WG_THREADS, ap, SP_SLOT_CHUNK[0], g);
             }
+            tick<TIMING>(rc, 1);
             act_tiles<32, SP>(x2, m2, ap, SP_SLOT_X2);
+            tick<TIMING>(rc, 2);
             if (DBG && dbg && step == 0) dump_tiles<32>(dbg, DBG_X2, x2, tid);
             load_bias<32>(x4, lds_bias + BIAS_OFF[3], g);
-            run_phase<32, 2, 32, 32, false, SP>(x2, x4, ring, lds_bias + BIAS_OFF[2],
-                                                lds_mask + MASK_BASE[1] * WG_THREADS, ap, SP_SLOT_CHUNK[1], g);
+            run_phase<32, 2, 32, 32, false, SP, TIMING>(x2, x4, ring, lds_bias + BIAS_OFF[2],
+                                                        lds_mask + MASK_BASE[1] * WG_THREADS, ap, SP_SLOT_CHUNK[1], g, &rc);
         }
+        tick<TIMING>(rc, 3);
         act_tiles<32, SP>(x4, m4, ap, SP_SLOT_X4);
+        tick<TIMING>(rc, 4);
         if (DBG && dbg && step == 0) dump_tiles<32>(dbg, DBG_X4, x4, tid);
         load_bias<4>(x6, lds_bias + BIAS_OFF[5], g);
         run_phase<32, 4, 4, 4, false, SP>(x4, x6, ring, lds_bias + BIAS_OFF[4],
                                           lds_mask + MASK_BASE[2] * WG_THREADS, ap, SP_SLOT_CHUNK[2], g);
+        tick<TIMING>(rc, 5);
         act_tiles<4, SP>(x6, m6, ap, SP_SLOT_X6);
         if (DBG && dbg && step == 0) dump_tiles<4>(dbg, DBG_X6, x6, tid);
 
@@ -644,6 +715,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) g6[t] = w6[t] * gz7;
         dact_tiles<4, SP>(g6, m6, ap, SP_SLOT_X6);
+        tick<TIMING>(rc, 6);
         {
             f32x4 g0[8];
             {
@@ -655,6 +727,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
                     run_phase<4, 4, 4, 32, true, SP>(g6, g4, ring, nullptr, lds_mask + MASK_BASE[2] * WG_THREADS, ap,
                                                      SP_SLOT_CHUNK[2], g);
                     dact_tiles<32, SP>(g4, m4, ap, SP_SLOT_X4);
+                    tick<TIMING>(rc, 7);
                     if (DBG && dbg && step == 0) dump_tiles<32>(dbg, DBG_G4, g4, tid);
 #pragma unroll
                     for (int t = 0; t < 32; ++t) g2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -662,6 +735,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
                                                        SP_SLOT_CHUNK[1], g);
                 }
                 dact_tiles<32, SP>(g2, m2, ap, SP_SLOT_X2);
+                tick<TIMING>(rc, 8);
                 if (DBG && dbg && step == 0) dump_tiles<32>(dbg, DBG_G2, g2, tid);
 #pragma unroll
                 for (int t = 0; t < 8; ++t) g0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -677,11 +751,13 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
         // backward phase; GN/F of a pose are touched by its own wave only.
         __syncthreads();
 
+        tick<TIMING>(rc, 9);
         // ---------------- encoder backward + normalise backward + update
         encoder_backward<SP>(ew, my_f, my_gn, my_em, enc_sp, PNDF_PARENT, ap);
         if (DBG && dbg && step == 0) {
             for (int i = 0; i < NQ; ++i) dbg[(size_t)(DBG_GN + i) * WG_THREADS + tid] = my_gn[i];
         }
+        tick<TIMING>(rc, 10);
         {
             // backward of x / clamp_min(||x||_joints, eps)  (model/posendf.py:71)
             float ss[4], dot[4], denom[4], kk[4];
@@ -720,6 +796,16 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
         }
         // GN (aliasing the chunk masks) must be consumed by every wave before the next step's masks land
         __syncthreads();
+        tick<TIMING>(rc, 11);
+    }
+    if constexpr (TIMING) {
+        if (lane == 0 && args.dbg) {
+            unsigned long long* out = (unsigned long long*)args.dbg + ((size_t)blockIdx.x * 4 + wave) * (TIMING_REGIONS + TIMING_GROUPS);
+#pragma unroll
+            for (int i = 0; i < TIMING_REGIONS; ++i) out[i] = rc.acc[i];
+#pragma unroll
+            for (int i = 0; i < TIMING_GROUPS; ++i) out[TIMING_REGIONS + i] = rc.grp[i];
+        }
     }
 
     // ---------------- write back (coalesced)
@@ -757,6 +843,13 @@ pndf_fused_relu_kernel_dbg(PndfKernelArgs args) {
     pndf_fused_body<true, false>(args);
 }
 
+// relu-family kernel with s_memtime region stamps (performance analysis only)
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1)
+pndf_fused_relu_kernel_timing(PndfKernelArgs args) {
+    pndf_fused_body<false, false, true>(args);
+}
+
+extern "C" int pndf_kernel_timing_regions() { return TIMING_REGIONS + TIMING_GROUPS; }
 extern "C" int pndf_kernel_lds_bytes() { return LDS_TOTAL; }
 extern "C" int pndf_kernel_dbg_floats() { return DBG_TOTAL * WG_THREADS; }
 extern "C" long long pndf_kernel_softplus_scratch_floats_per_wg() { return SP_WG_FLOATS; }

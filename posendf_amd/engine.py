@@ -43,6 +43,9 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.pndf_project.argtypes = [H, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]
     lib.pndf_debug_forward_grad.argtypes = [H, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
     lib.pndf_debug_floats.restype = c_int64
+    lib.pndf_debug_project_timing.argtypes = [H, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]
+    lib.pndf_debug_project_timing.restype = c_int
+    lib.pndf_debug_timing_regions.restype = c_int
     lib.pndf_packed_sizes.argtypes = [POINTER(c_int64)] * 3
     lib.pndf_packed_sizes.restype = None
     lib.pndf_pack_host.argtypes = [POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p, c_void_p, c_void_p]
@@ -57,6 +60,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
 
 EXPORTS = ("pndf_default_config", "pndf_create", "pndf_destroy", "pndf_load_weights", "pndf_forward",
            "pndf_forward_grad", "pndf_project", "pndf_debug_forward_grad", "pndf_debug_floats",
+           "pndf_debug_project_timing", "pndf_debug_timing_regions",
            "pndf_packed_sizes", "pndf_pack_host", "pndf_last_error", "pndf_version")
 
 

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Per-region shader-cycle breakdown of one projection step (s_memtime-instrumented kernel), vs the ideal
+MFMA issue time of each region (32 cycles per v_mfma_f32_16x16x4_f32)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from posendf_amd import PoseNDF, amass_config, synth  # noqa: E402
+
+NAMES = ["enc fwd + x0", "P1 lin0,lin1", "act x2", "P2 lin2,lin3", "act x4", "P3 lin4,lin5", "act x6+lin6+g6",
+         "P4 lin5T,lin4T +dact", "P5 lin3T,lin2T +dact", "P6 lin1T,lin0T", "enc bwd", "norm bwd+update+sync"]
+TILES = [0, 640, 0, 4096, 0, 576, 0, 576, 4096, 640, 0, 0]
+
+
+def main():
+    B, steps = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    net = PoseNDF(amass_config("lrelu", "cuda:0"))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(0, 2.0, 0.1).items()})
+    q = torch.from_numpy(synth.make_poses(B, seed=1)).cuda()
+    eng = net._engine_for(q.device)
+    R = eng.lib.pndf_debug_timing_regions()
+    cyc = torch.zeros((B // 64) * 4 * R, dtype=torch.int64, device="cuda")
+    out = torch.empty_like(q)
+    rc = eng.lib.pndf_debug_project_timing(eng.handle, q.data_ptr(), out.data_ptr(), B, steps, cyc.data_ptr(), 0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    call = cyc.cpu().numpy().reshape(-1, R).astype(np.float64) / steps
+    c = call[:, :12]
+    mean = c.mean(0)
+    tot = mean.sum()
+    print(f"per wave-step: total {tot:,.0f} shader cycles; ideal MFMA {sum(TILES) * 4 * 32:,} ({sum(TILES) * 128 / tot * 100:.1f} %)")
+    for n, m, t in zip(NAMES, mean, TILES):
+        ideal = t * 4 * 32
+        extra = f"  ideal {ideal:9,d}  eff {ideal / m * 100:5.1f} %  over {m - ideal:9,.0f}" if t else f"  {'':40s}"
+        print(f"{n:24s} {m:11,.0f} cyc {m / tot * 100:5.1f} %{extra}")
+    grp = call[:, 12:].mean(0) / 32          # per chunk of the (lin2,lin3) phase; ideal = 16 MFMAs = 512 cycles
+    print("per-group cycles inside one (lin2,lin3) chunk (ideal 512; includes the s_memtime stamp itself):")
+    print("  part A:", " ".join(f"{x:5.0f}" for x in grp[:16]))
+    print("  part B:", " ".join(f"{x:5.0f}" for x in grp[16:]))
+    print("spread over waves (min/max of total):", c.sum(1).min(), c.sum(1).max())
+
+
+if __name__ == "__main__":
+    main()
