@@ -70,25 +70,38 @@ struct Ring {
 // degrades every `s_waitcnt lgkmcnt(N)` of the tile prefetch to lgkmcnt(0), which serialises ds_read and
 // MFMA.  Consequence (cdna_hip_programming.md 5.7): the compiler does not count these loads, so every
 // consumer-side barrier is preceded by an explicit `s_waitcnt vmcnt(0)`.
-__device__ __forceinline__ void ring_dma(Ring& r, int buf) {
-    const char* src = r.gstream + (size_t)r.next * SLOT_BYTES + r.wave * (4 * TILE_BYTES) + r.lane * 16;
-    const uint32_t lds_base = (uint32_t)(size_t)(PNDF_LDS char*)(r.smem + LDS_RING);
-    const uint32_t dst = lds_base + buf * SLOT_BYTES + r.wave * (4 * TILE_BYTES);
+// One 1-KiB piece (tile 4*wave + j of the slot).  M0 is written in the same statement that uses it
+// (cdna_hip_programming.md 5.7: M0 is compiler-owned outside the statement).
+__device__ __forceinline__ void ring_dma_piece(const char* src, uint32_t dst, int j) {
     uint32_t keep;
-    // the instruction offset applies to BOTH the global and the LDS address, so M0 stays put
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-        "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-        "global_load_lds_dwordx4 %1, off offset:3072\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(src), "s"(dst)
-        : "memory");
+    if (j == 0)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    else if (j == 1)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    else if (j == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+
+// source / destination of this wave's share of the next slot to fetch; advances r.next
+__device__ __forceinline__ void ring_dma_begin(Ring& r, int buf, const char*& src, uint32_t& dst) {
+    src = r.gstream + (size_t)r.next * SLOT_BYTES + r.wave * (4 * TILE_BYTES) + r.lane * 16;
+    const uint32_t lds_base = (uint32_t)(size_t)(PNDF_LDS char*)(r.smem + LDS_RING);
+    dst = lds_base + buf * SLOT_BYTES + r.wave * (4 * TILE_BYTES);
     r.next = (r.next + 1 == r.nslots) ? 0 : r.next + 1;
+}
+
+__device__ __forceinline__ void ring_dma(Ring& r, int buf) {
+    const char* src;
+    uint32_t dst;
+    ring_dma_begin(r, buf, src, dst);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ring_dma_piece(src, dst, j);
 }
 
 __device__ __forceinline__ void ring_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -108,11 +121,10 @@ __device__ __forceinline__ void ring_boundary(Ring& r) { r.cur = (r.cur == 2) ? 
 // tile prefetch issued a few instructions earlier.  What the barrier has to order is already ordered: every
 // wave's DMA share of the next slot has landed (its own vmcnt(0) above), and every read of the previous slot
 // returned long ago (its data has been consumed by MFMAs issued before this point).
-__device__ __forceinline__ void ring_midslot(Ring& r) {
+__device__ __forceinline__ void ring_midslot_sync(Ring& r) {
     ring_wait_dma();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    ring_dma(r, (r.cur == 0) ? 2 : r.cur - 1);
 }
 
 __device__ __forceinline__ f32x4 ring_tile(const Ring& r, int t_in_slot) {
@@ -187,15 +199,21 @@ __device__ __forceinline__ void tick(RegionClock& rc, int region) {
     }
 }
 
+// does the tile group [T0, T0 + GT) contain the mid-slot tile?
+template <int GT, int T0>
+constexpr bool group_has_mid() {
+    for (int i = 0; i < GT; ++i)
+        if ((T0 + i) % SLOT_TILES == SLOT_TILES / 2) return true;
+    return false;
+}
+
 template <int GT, int T0>
 __device__ __forceinline__ void load_group(f32x4 (&a)[GT], Ring& ring) {
 #pragma unroll
     for (int i = 0; i < GT; ++i) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int t = (T0 + i) % SLOT_TILES;    // compile-time: T0 is a template constant, i unrolled
         if (t == 0) ring_boundary(ring);
-        if (t == SLOT_TILES / 2) ring_midslot(ring);
+        if (t == SLOT_TILES / 2) ring_midslot_sync(ring);
         a[i] = ring_tile(ring, t);
     }
 }
@@ -219,7 +237,16 @@ struct PhaseBody {
         if constexpr (GI < NG) {
             f32x4 nxt[GT];
             constexpr int TNEXT = ((GI + 1) * GT) % CHUNK_TILES;
-            if (GI + 1 < NG || c + 1 < NC) load_group<GT, TNEXT>(nxt, ring);
+            constexpr bool MID = group_has_mid<GT, TNEXT>();
+            const bool loaded = (GI + 1 < NG || c + 1 < NC);
+            if (loaded) load_group<GT, TNEXT>(nxt, ring);
+            // the slot fetch that follows a mid-slot barrier: four 1-KiB DMA instructions, each issued behind
+            // an MFMA of this group (a VMEM issue blocks the wave ~16+ cycles; back to back they starve the
+            // MFMA pipe, behind an MFMA they are free)
+            const char* dsrc = nullptr;
+            uint32_t ddst = 0;
+            if (MID && loaded) ring_dma_begin(ring, (ring.cur == 0) ? 2 : ring.cur - 1, dsrc, ddst);
+            int piece = 0;
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE this group's MFMAs
             if constexpr (GI < NGA) {
                 // ---- part A: two k-tiles of the chunk rows; tile order (kt, ci)
@@ -230,6 +257,11 @@ struct PhaseBody {
 #pragma unroll
                         for (int ci = 0; ci < CT; ++ci)
                             ch[ci] = mfma4(cur[k2 * CT + ci][s], xin[2 * GI + k2][s], ch[ci]);
+                        if (MID && s < 2 && loaded) {      // 2 k-tiles x 2 = 4 pieces
+                            __builtin_amdgcn_sched_barrier(0);
+                            ring_dma_piece(dsrc, ddst, piece++);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
                 if constexpr (GI == NGA - 1) {
@@ -285,6 +317,11 @@ struct PhaseBody {
 #pragma unroll
                         for (int h = 0; h < 2; ++h)
                             acc[2 * nbp + h] = mfma4(cur[ci * 2 + h][s], ch[ci][s], acc[2 * nbp + h]);
+                        if (MID && ci < 2 && s < 2 && loaded) {   // 4 pieces
+                            __builtin_amdgcn_sched_barrier(0);
+                            ring_dma_piece(dsrc, ddst, piece++);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
             }
