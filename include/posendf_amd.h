@@ -91,9 +91,9 @@ int pndf_debug_timing_regions(void);
 
 /* Host-only weight packer (what pndf_load_weights uploads); needs no device.  Output sizes in floats come
  * from pndf_packed_sizes.  Used by the CPU tests that check the MFMA tile order against a lane-level model. */
-void pndf_packed_sizes(int64_t* stream_floats, int64_t* enc_floats, int64_t* bias_floats);
+void pndf_packed_sizes(int64_t* stream_floats, int64_t* bias_floats);
 int pndf_pack_host(const float* const* tensors, const int64_t* numel, int n_tensors, float* stream,
-                   float* enc, float* bias);
+                   float* bias);
 
 const char* pndf_last_error(pndf_handle h);   /* h may be NULL: last error of a failed pndf_create */
 const char* pndf_version(void);

@@ -20,7 +20,6 @@ struct PndfKernelArgs {
     float* d_out;
     const float* grad_out;
     const char* stream;
-    const float* enc;
     const float* bias;
     float* dbg;
     long long B;
@@ -47,7 +46,6 @@ struct pndf_engine {
     int device = 0;
     bool have_weights = false;
     char* d_stream = nullptr;   // STEP_TILES KiB
-    float* d_enc = nullptr;
     float* d_bias = nullptr;
     float* d_scratch = nullptr;     // softplus derivative scratch, grown on demand
     int64_t scratch_wgs = 0;
@@ -115,7 +113,6 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
     h->device = device;
     HIP_TRY(nullptr, hipSetDevice(device));
     hipError_t e = hipMalloc((void**)&h->d_stream, (size_t)STEP_TILES * TILE_BYTES);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_enc, ENC_FLOATS * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias, BIAS_FLOATS * sizeof(float));
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
@@ -138,7 +135,6 @@ extern "C" int pndf_destroy(pndf_handle h) {
     if (!h) return PNDF_OK;
     (void)hipSetDevice(h->device);
     if (h->d_stream) (void)hipFree(h->d_stream);
-    if (h->d_enc) (void)hipFree(h->d_enc);
     if (h->d_bias) (void)hipFree(h->d_bias);
     if (h->d_scratch) (void)hipFree(h->d_scratch);
     delete h;
@@ -166,11 +162,33 @@ void emit_tile(const Mat& m, int nt, int kt, float* dst) {
 
 }  // namespace
 
-extern "C" void pndf_packed_sizes(int64_t* stream_floats, int64_t* enc_floats, int64_t* bias_floats) {
+extern "C" void pndf_packed_sizes(int64_t* stream_floats, int64_t* bias_floats) {
     if (stream_floats) *stream_floats = (int64_t)STEP_TILES * TILE_FLOATS;
-    if (enc_floats) *enc_floats = ENC_FLOATS;
     if (bias_floats) *bias_floats = BIAS_FLOATS;
 }
+
+namespace {
+// 16x16 logical matrices of one encoder joint (zero padded), see pndf_layout.h "encoder on the MFMA pipe"
+struct EncMat {
+    const float* w1;   // [10][in]
+    const float* w2;   // [6][10]
+    int in;
+    int kind;          // 0: W1 (rows = hidden, k = input)   1: W2 (rows 4..9 = feature, k = hidden)
+                       // 2: W2^T (rows = hidden, k = feature row 4..9)   3: W1^T (rows = input, k = hidden)
+    float at(int r, int c) const {
+        switch (kind) {
+            case 0: return (r < HID && c < in) ? w1[r * in + c] : 0.f;
+            case 1: return (r >= ENC_FEAT_ROW && r < ENC_FEAT_ROW + FEAT && c < HID) ? w2[(r - ENC_FEAT_ROW) * HID + c] : 0.f;
+            case 2: return (r < HID && c >= ENC_FEAT_ROW && c < ENC_FEAT_ROW + FEAT) ? w2[(c - ENC_FEAT_ROW) * HID + r] : 0.f;
+            default: return (r < in && c < HID) ? w1[c * in + r] : 0.f;
+        }
+    }
+};
+void emit_enc_tile(const EncMat& m, float* dst) {
+    for (int lane = 0; lane < 64; ++lane)
+        for (int s = 0; s < 4; ++s) dst[lane * 4 + s] = m.at(lane & 15, 4 * (lane >> 4) + s);
+}
+}  // namespace
 
 static const char* check_tensors(const float* const* tensors, const int64_t* numel, int n) {
     if (!tensors || !numel) return "tensors / numel is null";
@@ -191,25 +209,26 @@ static const char* check_tensors(const float* const* tensors, const int64_t* num
 }
 
 extern "C" int pndf_pack_host(const float* const* tensors, const int64_t* numel, int n_tensors, float* stream,
-                              float* enc, float* bias) {
-    if (check_tensors(tensors, numel, n_tensors) || !stream || !enc || !bias) return PNDF_ERR_BAD_SHAPE;
-    // ---- encoder block: per joint W1[10][in] | b1[10] +2 | W2[6][10] | b2[6] +2
-    memset(enc, 0, ENC_FLOATS * sizeof(float));
-    for (int j = 0; j < NJ; ++j) {
-        float* e = enc + enc_off(j);
-        memcpy(e, tensors[4 * j + 0], sizeof(float) * HID * enc_in(j));
-        memcpy(e + enc_b1(j), tensors[4 * j + 1], sizeof(float) * HID);
-        memcpy(e + enc_w2(j), tensors[4 * j + 2], sizeof(float) * FEAT * HID);
-        memcpy(e + enc_b2(j), tensors[4 * j + 3], sizeof(float) * FEAT);
-    }
-    // ---- bias block: b0..b5 | w6 | b6
+                              float* bias) {
+    if (check_tensors(tensors, numel, n_tensors) || !stream || !bias) return PNDF_ERR_BAD_SHAPE;
+    // ---- bias block: b0..b5 | w6 | b6 | per joint: b1 padded to 16, b2 on rows 4..9 of 16
     memset(bias, 0, BIAS_FLOATS * sizeof(float));
     const float* const* lin = tensors + 4 * NJ;
     for (int l = 0; l < NLIN - 1; ++l) memcpy(bias + BIAS_OFF[l], lin[2 * l + 1], sizeof(float) * DIMS[l + 1]);
     memcpy(bias + W6_OFF, lin[2 * (NLIN - 1)], sizeof(float) * DIMS[NLIN - 1]);
     bias[BIAS_OFF[NLIN - 1]] = lin[2 * (NLIN - 1) + 1][0];
-    // ---- trunk stream: tiles in the exact order run_phase consumes them
+    for (int j = 0; j < NJ; ++j) {
+        memcpy(bias + ENCB_OFF + 32 * j, tensors[4 * j + 1], sizeof(float) * HID);
+        memcpy(bias + ENCB_OFF + 32 * j + 16 + ENC_FEAT_ROW, tensors[4 * j + 3], sizeof(float) * FEAT);
+    }
+    // ---- stream: encoder forward tiles | trunk phases | encoder backward tiles, in consumption order
     float* dst = stream;
+    memset(stream, 0, (size_t)STEP_TILES * TILE_FLOATS * sizeof(float));
+    for (int j = 0; j < NJ; ++j) {                                  // forward: joint order, W1 then W2
+        for (int kind = 0; kind < 2; ++kind, dst += TILE_FLOATS)
+            emit_enc_tile(EncMat{tensors[4 * j], tensors[4 * j + 2], enc_in(j), kind}, dst);
+    }
+    dst = stream + (size_t)ENC_TILES_PADDED * TILE_FLOATS;
     for (int ph = 0; ph < 6; ++ph) {
         const Phase& P = PHASES[ph];
         const Mat A{lin[2 * P.a_lin], DIMS[P.a_lin + 1], DIMS[P.a_lin], P.transposed};
@@ -222,19 +241,23 @@ extern "C" int pndf_pack_host(const float* const* tensors, const int64_t* numel,
                     for (int hh = 0; hh < 2; ++hh, dst += TILE_FLOATS) emit_tile(B, 2 * nbp + hh, c * P.CT + ci, dst);
         }
     }
-    return (dst - stream == (ptrdiff_t)STEP_TILES * TILE_FLOATS) ? PNDF_OK : PNDF_ERR_BAD_SHAPE;
+    if (dst - stream != (ptrdiff_t)(ENC_TILES_PADDED + TRUNK_FWD_TILES + TRUNK_BWD_TILES) * TILE_FLOATS) return PNDF_ERR_BAD_SHAPE;
+    for (int j = NJ - 1; j >= 0; --j) {                             // backward: reverse joint order, W2^T then W1^T
+        for (int kind = 2; kind < 4; ++kind, dst += TILE_FLOATS)
+            emit_enc_tile(EncMat{tensors[4 * j], tensors[4 * j + 2], enc_in(j), kind}, dst);
+    }
+    return PNDF_OK;
 }
 
 extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, const int64_t* numel, int n_tensors) {
     if (!h) return PNDF_ERR_BAD_ARG;
     if (const char* why = check_tensors(tensors, numel, n_tensors)) return fail(h, PNDF_ERR_BAD_SHAPE, why);
-    std::vector<float> stream((size_t)STEP_TILES * TILE_FLOATS), enc(ENC_FLOATS), bias(BIAS_FLOATS);
-    if (pndf_pack_host(tensors, numel, n_tensors, stream.data(), enc.data(), bias.data()) != PNDF_OK)
+    std::vector<float> stream((size_t)STEP_TILES * TILE_FLOATS), bias(BIAS_FLOATS);
+    if (pndf_pack_host(tensors, numel, n_tensors, stream.data(), bias.data()) != PNDF_OK)
         return fail(h, PNDF_ERR_BAD_SHAPE, "internal: packed stream length mismatch");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());   // no launch may still be reading the old weights
     HIP_TRY(h, hipMemcpy(h->d_stream, stream.data(), stream.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->d_enc, enc.data(), enc.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
     h->have_weights = true;
     return PNDF_OK;
@@ -253,7 +276,7 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
     if (((uintptr_t)d | (uintptr_t)gout) & 3) return fail(h, PNDF_ERR_BAD_ARG, "misaligned distance buffer");
     PndfKernelArgs a;
     a.q_in = q; a.q_out = qo; a.d_out = d; a.grad_out = gout;
-    a.stream = h->d_stream; a.enc = h->d_enc; a.bias = h->d_bias; a.dbg = dbg;
+    a.stream = h->d_stream; a.bias = h->d_bias; a.dbg = dbg;
     a.B = B; a.steps = steps; a.mode = mode;
     a.slope = (h->cfg.act == PNDF_ACT_LRELU) ? 0.01f : 0.0f;   // nn.LeakyReLU() default slope, net_modules.py:31
     a.beta = h->cfg.beta;

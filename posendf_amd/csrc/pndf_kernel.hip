@@ -29,16 +29,13 @@ constexpr int SLOT_BYTES = SLOT_TILES * TILE_BYTES;          // 16 KiB
 constexpr int FSTRIDE = 132;                                 // floats per pose in the feature buffer (bank skew)
 constexpr int RING_SLOTS = 3;
 constexpr int LDS_RING = 0;                                  // 3 slots of 16 KiB (DMA target, lowest addresses)
-constexpr int LDS_ENC = LDS_RING + RING_SLOTS * SLOT_BYTES;  // ENC_FLOATS floats
-constexpr int LDS_BIAS = LDS_ENC + ENC_FLOATS * 4;           // BIAS_FLOATS floats
+constexpr int LDS_BIAS = LDS_RING + RING_SLOTS * SLOT_BYTES; // BIAS_FLOATS floats (trunk + encoder biases)
 constexpr int LDS_MASK = LDS_BIAS + BIAS_FLOATS * 4;         // u16 [MASK_CHUNKS][256]; aliased by GN after the trunk
 constexpr int LDS_GN = LDS_MASK;                             // float [64][84]  d d / d n per pose
 constexpr int LDS_Q = LDS_MASK + MASK_CHUNKS * WG_THREADS * 2;   // float [64][84]  the pose tile
 constexpr int LDS_F = LDS_Q + WG_POSES * NQ * 4;             // float [64][FSTRIDE]  features, then d d / d feature
-constexpr int LDS_EM = LDS_F + WG_POSES * FSTRIDE * 4;       // u16 [64][21] encoder derivative bits
-constexpr int LDS_TOTAL = LDS_EM + WG_POSES * NJ * 2;
-static_assert(LDS_BIAS % 16 == 0 && LDS_MASK % 16 == 0 && LDS_Q % 16 == 0 && LDS_F % 16 == 0 &&
-              LDS_EM % 16 == 0 && LDS_ENC % 16 == 0, "16-byte LDS carve");
+constexpr int LDS_TOTAL = LDS_F + WG_POSES * FSTRIDE * 4;
+static_assert(LDS_BIAS % 16 == 0 && LDS_MASK % 16 == 0 && LDS_Q % 16 == 0 && LDS_F % 16 == 0, "16-byte LDS carve");
 static_assert(WG_POSES * NQ * 4 <= MASK_CHUNKS * WG_THREADS * 2, "GN aliases the chunk-mask region");
 static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
 
@@ -131,6 +128,16 @@ __device__ __forceinline__ f32x4 ring_tile(const Ring& r, int t_in_slot) {
     return *(const f32x4*)(r.smem + LDS_RING + r.cur * SLOT_BYTES + t_in_slot * TILE_BYTES + r.lane * 16);
 }
 
+// Lanes of ONE wave exchange data through LDS (lane group 0 stores, all lane groups load).  The hardware
+// executes a wave's LDS operations in order, but for the compiler this is inter-thread communication: without
+// a fence it may satisfy the later loads from before the (other lanes') stores -- it did: lane groups 1..3 read
+// stale d d / d n.  A wavefront-scope fence costs no instructions and restores the ordering.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -173,9 +180,9 @@ struct ActP {
     f32x4* sp;          // softplus: this thread's column of the scratch ([slot][256] float4), else null
 };
 constexpr int SP_SLOT_CHUNK[3] = {0, 16, 80};      // chunk layers x1 (8x2), x3 (32x2), x5 (4x4)
-constexpr int SP_SLOT_X2 = 96, SP_SLOT_X4 = 128, SP_SLOT_X6 = 160, SP_SLOTS = 164;
-constexpr int SP_ENC_FLOATS = NJ * 16 * WG_POSES;   // encoder derivatives: [joint][4 float4][64 poses]
-constexpr int SP_WG_FLOATS = SP_SLOTS * WG_THREADS * 4 + SP_ENC_FLOATS;
+constexpr int SP_SLOT_X2 = 96, SP_SLOT_X4 = 128, SP_SLOT_X6 = 160, SP_SLOT_ENC = 164;   // encoder: 2 tiles per joint
+constexpr int SP_SLOTS = SP_SLOT_ENC + 2 * NJ;
+constexpr int SP_WG_FLOATS = SP_SLOTS * WG_THREADS * 4;
 
 // One fused layer pair.  xin: KA input tiles (B operands); acc: NB output tiles (accumulators).
 // Forward: chunk accumulators start from the A-layer bias, get the activation, and their sign bits are
@@ -357,79 +364,23 @@ __device__ __forceinline__ void run_phase(const f32x4 (&xin)[KA], f32x4 (&acc)[N
     }
 }
 
-// ------------------------------------------------------------------ encoder (VALU, per lane = per pose)
-// Rolled loop over the 21 joints; all four lane groups of a pose compute the same values (the encoder is
-// 0.2 % of the FLOPs), per-pose state lives in LDS.  Weights are read from LDS at wave-uniform addresses
-// (broadcast).  A fully unrolled register version made hipcc hoist ~3.5k loads and spill.
-__device__ __forceinline__ int enc_block_off(int j) { return j < 3 ? 120 * j : 360 + 180 * (j - 3); }
-
-// Derivative record of one joint: relu family = 16 sign bits, softplus = 16 floats (10 hidden + 6 output).
-template <bool SP>
-struct JointD {
-    uint32_t bits;
-    float dv[SP ? 16 : 1];
-};
-
-template <int IN, bool SP>
-__device__ __forceinline__ void enc_joint_fwd(const float* w, const float (&in)[IN], float (&f)[FEAT],
-                                              JointD<SP>& jd, const ActP& ap) {
-    constexpr int B1 = HID * IN, W2 = B1 + 12, B2 = W2 + FEAT * HID;
-    float h[HID];
-    jd.bits = 0;
-#pragma unroll
-    for (int u = 0; u < HID; ++u) {
-        float z = w[B1 + u];
-#pragma unroll
-        for (int i = 0; i < IN; ++i) z = fmaf(w[u * IN + i], in[i], z);
-        if constexpr (SP) {
-            h[u] = act_softplus(z, ap.beta, jd.dv[u]);
-        } else {
-            bool pos;
-            h[u] = act_relu(z, ap.slope, pos);
-            jd.bits |= pos ? (1u << u) : 0u;
-        }
+// ------------------------------------------------------------------ encoder on the MFMA pipe
+// Joint J, forward (reference net_modules.py:75-111,162-168), batched over the wave's 16 poses:
+//   X  (B layout, k = 4g+s): lane group 0 = normalised quaternion of the joint, groups 1-2 = the parent's
+//       six features -- which is exactly where the parent's output tile holds them (rows 4..9)
+//   H  = act(W1 X + b1)    rows 0..9  = hidden units        (tile 2J of the encoder slots)
+//   F  = act(W2 H + b2)    rows 4..9  = features            (tile 2J+1)
+// All padded rows/columns carry zero weights, so padding values never reach a real output.
+// Derivatives: relu family = 8 sign bits per lane per joint (registers); softplus = two scratch slots.
+template <int T>
+__device__ __forceinline__ f32x4 enc_tile(Ring& ring) {
+    constexpr int t = T % SLOT_TILES;
+    if (t == 0) ring_boundary(ring);
+    if (t == SLOT_TILES / 2) {
+        ring_midslot_sync(ring);
+        ring_dma(ring, (ring.cur == 0) ? 2 : ring.cur - 1);
     }
-#pragma unroll
-    for (int o = 0; o < FEAT; ++o) {
-        float z = w[B2 + o];
-#pragma unroll
-        for (int u = 0; u < HID; ++u) z = fmaf(w[W2 + o * HID + u], h[u], z);
-        if constexpr (SP) {
-            f[o] = act_softplus(z, ap.beta, jd.dv[HID + o]);
-        } else {
-            bool pos;
-            f[o] = act_relu(z, ap.slope, pos);
-            jd.bits |= pos ? (1u << (HID + o)) : 0u;
-        }
-    }
-}
-
-template <int IN, bool SP>
-__device__ __forceinline__ void enc_joint_bwd(const float* w, const float (&gfj)[FEAT], float (&gin)[IN],
-                                              const JointD<SP>& jd, const ActP& ap) {
-    constexpr int W2 = HID * IN + 12;
-    float gz2[FEAT];
-#pragma unroll
-    for (int o = 0; o < FEAT; ++o) {
-        if constexpr (SP) gz2[o] = gfj[o] * jd.dv[HID + o];
-        else gz2[o] = ((jd.bits >> (HID + o)) & 1u) ? gfj[o] : gfj[o] * ap.slope;
-    }
-    float gz1[HID];
-#pragma unroll
-    for (int u = 0; u < HID; ++u) {
-        float s = 0.f;
-#pragma unroll
-        for (int o = 0; o < FEAT; ++o) s = fmaf(w[W2 + o * HID + u], gz2[o], s);
-        if constexpr (SP) gz1[u] = s * jd.dv[u];
-        else gz1[u] = ((jd.bits >> u) & 1u) ? s : s * ap.slope;
-    }
-#pragma unroll
-    for (int i = 0; i < IN; ++i) {
-        float s = 0.f;
-#pragma unroll
-        for (int u = 0; u < HID; ++u) s = fmaf(w[u * IN + i], gz1[u], s);
-        gin[i] = s;
-    }
+    return ring_tile(ring, t);
 }
 
 // per-component denominators of F.normalize(pose, dim=1): max(||q[:, c]||_2 over joints, eps)
@@ -443,84 +394,151 @@ __device__ __forceinline__ void joint_axis_norms(const float* my_q, float (&ss)[
     }
 }
 
-// softplus: encoder derivatives of pose wp live in the workgroup scratch as [joint][4][64 poses] float4
+// activation of one encoder tile; returns 4 derivative bits (relu family) or stores the derivative (softplus)
 template <bool SP>
-__device__ __forceinline__ void encoder_forward(const float* ew, const float* my_q, float* my_f,
-                                                uint16_t* my_em, f32x4* enc_sp, bool writer, const int* parent,
-                                                const ActP& ap) {
+__device__ __forceinline__ float enc_act(f32x4& z, const ActP& ap, int spslot) {
+    float bitsum = 0.f;
+    if constexpr (SP) {
+        f32x4 dv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float dr;
+            z[r] = act_softplus(z[r], ap.beta, dr);
+            dv[r] = dr;
+        }
+        ap.sp[(size_t)spslot * WG_THREADS] = dv;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float st = step01(z[r]);
+            z[r] = z[r] * relu_factor(st, ap.slope);
+            bitsum = fmaf(st, (float)(1u << r), bitsum);
+        }
+    }
+    return bitsum;
+}
+
+template <bool SP>
+__device__ __forceinline__ void enc_dact(f32x4& gz, uint32_t bits4, const ActP& ap, int spslot) {
+    if constexpr (SP) {
+        gz = gz * ap.sp[(size_t)spslot * WG_THREADS];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gz[r] = gz[r] * relu_factor((float)((bits4 >> r) & 1u), ap.slope);
+    }
+}
+
+template <int J, bool SP>
+__device__ __forceinline__ void enc_fwd_joint(const float* my_q, float* my_f, const float* encb,
+                                              const float (&denom)[4], f32x4 (&F)[NJ], float (&ebf)[NJ],
+                                              f32x4 t1, f32x4 t2, Ring& ring, const ActP& ap, int g) {
+    f32x4 n1 = t1, n2 = t2;
+    if constexpr (J + 1 < NJ) {            // prefetch the next joint's two tiles
+        n1 = enc_tile<2 * (J + 1)>(ring);
+        n2 = enc_tile<2 * (J + 1) + 1>(ring);
+    }
+    const f32x4 qj = *(const f32x4*)(my_q + 4 * J);
+    f32x4 X;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) X[c] = qj[c] / denom[c];       // posendf.py:71
+    if constexpr (PARENT[J] >= 0) {
+        X = (g == 0) ? X : F[PARENT[J]];                       // cat(quat, parent feature), net_modules.py:167
+    } else {
+        X = (g == 0) ? X : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 H = *(const f32x4*)(encb + 32 * J + 4 * g);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) H = mfma4(t1[s], X[s], H);
+    const float hb = enc_act<SP>(H, ap, SP_SLOT_ENC + 2 * J);
+    f32x4 Fj = *(const f32x4*)(encb + 32 * J + 16 + 4 * g);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) Fj = mfma4(t2[s], H[s], Fj);
+    const float fb = enc_act<SP>(Fj, ap, SP_SLOT_ENC + 2 * J + 1);
+    ebf[J] = fmaf(fb, 16.f, hb);            // 8 derivative bits of this joint, as an exact small float
+    F[J] = Fj;
+    // features of the joint -> per-pose buffer (rows 4..7 live in lane group 1, rows 8..9 in lane group 2)
+    if (g == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) my_f[FEAT * J + r] = Fj[r];
+    } else if (g == 2) {
+        my_f[FEAT * J + 4] = Fj[0];
+        my_f[FEAT * J + 5] = Fj[1];
+    }
+    if constexpr (J + 1 < NJ) enc_fwd_joint<J + 1, SP>(my_q, my_f, encb, denom, F, ebf, n1, n2, ring, ap, g);
+}
+
+template <bool SP>
+__device__ __forceinline__ void encoder_forward(const float* my_q, float* my_f, const float* encb,
+                                                uint32_t (&eb)[6], Ring& ring, const ActP& ap, int g) {
     float ss[4], denom[4];
     joint_axis_norms(my_q, ss);
 #pragma unroll
     for (int c = 0; c < 4; ++c) denom[c] = fmaxf(sqrtf(ss[c]), 1e-12f);
-    for (int j = 0; j < NJ; ++j) {
-        const f32x4 qj = *(const f32x4*)(my_q + 4 * j);
-        const float* w = ew + enc_block_off(j);
-        float f[FEAT];
-        JointD<SP> jd;
-        if (j < 3) {
-            float in[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) in[c] = qj[c] / denom[c];
-            enc_joint_fwd<4, SP>(w, in, f, jd, ap);
-        } else {
-            float in[10];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) in[c] = qj[c] / denom[c];
-            const float* pf = my_f + FEAT * parent[j];     // cat(quat, parent feature), net_modules.py:167
-#pragma unroll
-            for (int i = 0; i < FEAT; ++i) in[4 + i] = pf[i];
-            enc_joint_fwd<10, SP>(w, in, f, jd, ap);
-        }
-#pragma unroll
-        for (int i = 0; i < FEAT; ++i) my_f[FEAT * j + i] = f[i];
-        if constexpr (SP) {
-            if (writer) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    enc_sp[(j * 4 + k) * WG_POSES] = f32x4{jd.dv[4 * k], jd.dv[4 * k + 1], jd.dv[4 * k + 2], jd.dv[4 * k + 3]};
-            }
-        } else {
-            my_em[j] = (uint16_t)jd.bits;
-        }
+    f32x4 F[NJ];
+    float ebf[NJ];
+    const f32x4 t1 = enc_tile<0>(ring);
+    const f32x4 t2 = enc_tile<1>(ring);
+    enc_fwd_joint<0, SP>(my_q, my_f, encb, denom, F, ebf, t1, t2, ring, ap, g);
+    if (g == 0) {
+        my_f[126] = 0.f;
+        my_f[127] = 0.f;
     }
-    my_f[126] = 0.f;
-    my_f[127] = 0.f;
+    wave_lds_fence();      // features written by lane groups 1-2 are read by all lane groups (x0)
+#pragma unroll
+    for (int w = 0; w < 6; ++w) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * w + k < NJ) v |= (uint32_t)ebf[4 * w + k] << (8 * k);
+        eb[w] = v;
+        asm volatile("" : "+v"(eb[w]));      // pin the packing here (see act_tiles)
+    }
 }
 
-// consumes d d / d feature in my_f (accumulating into parents), leaves d d / d n in my_gn
-template <bool SP>
-__device__ __forceinline__ void encoder_backward(const float* ew, float* my_f, float* my_gn,
-                                                 const uint16_t* my_em, const f32x4* enc_sp, const int* parent,
-                                                 const ActP& ap) {
-    for (int j = NJ - 1; j >= 0; --j) {
-        const float* w = ew + enc_block_off(j);
-        JointD<SP> jd;
-        if constexpr (SP) {
-            jd.bits = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const f32x4 v = enc_sp[(j * 4 + k) * WG_POSES];
-                jd.dv[4 * k] = v[0]; jd.dv[4 * k + 1] = v[1]; jd.dv[4 * k + 2] = v[2]; jd.dv[4 * k + 3] = v[3];
-            }
-        } else {
-            jd.bits = my_em[j];
-        }
-        float gfj[FEAT];
-#pragma unroll
-        for (int i = 0; i < FEAT; ++i) gfj[i] = my_f[FEAT * j + i];
-        if (j < 3) {
-            float gin[4];
-            enc_joint_bwd<4, SP>(w, gfj, gin, jd, ap);
-            *(f32x4*)(my_gn + 4 * j) = f32x4{gin[0], gin[1], gin[2], gin[3]};
-        } else {
-            float gin[10];
-            enc_joint_bwd<10, SP>(w, gfj, gin, jd, ap);
-            *(f32x4*)(my_gn + 4 * j) = f32x4{gin[0], gin[1], gin[2], gin[3]};
-            float* pf = my_f + FEAT * parent[j];
-#pragma unroll
-            for (int i = 0; i < FEAT; ++i) pf[i] += gin[4 + i];
-        }
+// Joint J, backward: GF[J] (rows 4..9 = d d / d feature, from the trunk plus the children) ->
+//   gz2 = GF * act'(z2);  GH = W2^T gz2 (rows = hidden);  gz1 = GH * act'(z1);  GI = W1^T gz1
+//   GI rows 0..3 = d d / d n_J (lane group 0 -> LDS), rows 4..9 = contribution to the parent's GF.
+template <int J, bool SP>
+__device__ __forceinline__ void enc_bwd_joint(float* my_gn, f32x4 (&GF)[NJ], const uint32_t (&eb)[6],
+                                              f32x4 t1, f32x4 t2, Ring& ring, const ActP& ap, int g) {
+    f32x4 n1 = t1, n2 = t2;
+    if constexpr (J > 0) {
+        n1 = enc_tile<2 * (NJ - J)>(ring);          // tiles of joint J-1: stream order is joint 20 .. 0
+        n2 = enc_tile<2 * (NJ - J) + 1>(ring);
     }
+    const uint32_t byte = (eb[J / 4] >> (8 * (J % 4))) & 0xffu;
+    f32x4 gz2 = GF[J];
+    enc_dact<SP>(gz2, byte >> 4, ap, SP_SLOT_ENC + 2 * J + 1);
+    f32x4 GH = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) GH = mfma4(t1[s], gz2[s], GH);
+    enc_dact<SP>(GH, byte & 0xfu, ap, SP_SLOT_ENC + 2 * J);
+    f32x4 GI = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) GI = mfma4(t2[s], GH[s], GI);
+    if (g == 0) *(f32x4*)(my_gn + 4 * J) = GI;
+    if constexpr (PARENT[J] >= 0) GF[PARENT[J]] = GF[PARENT[J]] + GI;   // rows 0..3 of GF are never read back
+    if constexpr (J > 0) enc_bwd_joint<J - 1, SP>(my_gn, GF, eb, n1, n2, ring, ap, g);
+}
+
+// consumes d d / d feature from my_f, leaves d d / d n in my_gn
+template <bool SP>
+__device__ __forceinline__ void encoder_backward(float* my_f, float* my_gn, const uint32_t (&eb)[6], Ring& ring,
+                                                 const ActP& ap, int g) {
+    f32x4 GF[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        // rows 4..7 <- lane group 1, rows 8..9 <- lane group 2, everything else 0
+        const float* src = my_f + FEAT * j + ((g == 2) ? 4 : 0);
+        const float a = src[0], b = src[1];
+        const float c = (g == 1) ? src[2] : 0.f, d = (g == 1) ? src[3] : 0.f;
+        const bool live = (g == 1) || (g == 2);
+        GF[j] = live ? f32x4{a, b, c, d} : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const f32x4 t1 = enc_tile<0>(ring);
+    const f32x4 t2 = enc_tile<1>(ring);
+    enc_bwd_joint<NJ - 1, SP>(my_gn, GF, eb, t1, t2, ring, ap, g);
+    wave_lds_fence();      // d d / d n written by lane group 0 is read by all lane groups
 }
 
 template <int NT>
@@ -602,7 +620,6 @@ struct PndfKernelArgs {
     float* d_out;           // [B]
     const float* grad_out;  // [B] or null (FORWARD_GRAD only)
     const char* stream;     // packed trunk weights, STEP_TILES KiB
-    const float* enc;       // ENC_FLOATS (padded layout of pndf_layout.h)
     const float* bias;      // BIAS_FLOATS
     float* dbg;             // null, or DBG_TOTAL*256 floats written by workgroup 0 (first step)
     long long B;
@@ -613,8 +630,6 @@ struct PndfKernelArgs {
     float* scratch;         // softplus: gridDim.x * SP_WG_FLOATS floats of derivative scratch, else null
     int dbg_nslots;         // 0, or (timing experiments only, wrong results) wrap the weight stream after n slots
 };
-
-__constant__ int PNDF_PARENT[NJ] = {-1, -1, -1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19};
 
 template <bool DBG, bool SP, bool TIMING = false>
 __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
@@ -630,16 +645,13 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     ap.beta = args.beta;
     float* const wg_scratch = SP ? args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS : nullptr;
     ap.sp = SP ? (f32x4*)wg_scratch + tid : nullptr;
-    f32x4* const enc_sp = SP ? (f32x4*)(wg_scratch + SP_SLOTS * WG_THREADS * 4) + wp : nullptr;
     const long long pose0 = (long long)blockIdx.x * WG_POSES;
-    float* const ew = (float*)(smem + LDS_ENC);
     float* const lds_bias = (float*)(smem + LDS_BIAS);
     uint16_t* const lds_mask = (uint16_t*)(smem + LDS_MASK) + tid;
     float* const lds_q = (float*)(smem + LDS_Q);
     float* const my_q = lds_q + wp * NQ;
     float* const my_f = (float*)(smem + LDS_F) + wp * FSTRIDE;
     float* const my_gn = (float*)(smem + LDS_GN) + wp * NQ;
-    uint16_t* const my_em = (uint16_t*)(smem + LDS_EM) + wp * NJ;
     float* const dbg = (DBG && blockIdx.x == 0) ? args.dbg : nullptr;
 
     Ring ring;
@@ -651,8 +663,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     ring.lane = lane;
     ring_start(ring);   // slots 0 and 1 in flight; the __syncthreads() below makes them visible
 
-    // ---- stage encoder weights, biases and this workgroup's poses in LDS (coalesced)
-    for (int i = tid; i < ENC_FLOATS / 4; i += WG_THREADS) ((f32x4*)ew)[i] = ((const f32x4*)args.enc)[i];
+    // ---- stage biases and this workgroup's poses in LDS (coalesced)
     for (int i = tid; i < BIAS_FLOATS / 4; i += WG_THREADS)
         ((f32x4*)lds_bias)[i] = ((const f32x4*)args.bias)[i];
     {
@@ -680,6 +691,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
         rc.last = __builtin_amdgcn_s_memtime();
     }
     for (int step = 0; step < nsteps; ++step) {
+        uint32_t eb[6];
         uint32_t m2[4], m4[4], m6[1];
         f32x4 x6[4];
         f32x4 x4[32];
@@ -687,7 +699,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
             f32x4 x2[32];
             {
                 // ---------------- normalise + encoder forward (posendf.py:71, net_modules.py:162-169)
-                encoder_forward<SP>(ew, my_q, my_f, my_em, enc_sp, g == 0, PNDF_PARENT, ap);
+                encoder_forward<SP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ap, g);
                 if (DBG && dbg && step == 0) {
                     for (int i = 0; i < NFEAT; ++i) dbg[(size_t)(DBG_FEAT + i) * WG_THREADS + tid] = my_f[i];
                 }
@@ -790,7 +802,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
 
         tick<TIMING>(rc, 9);
         // ---------------- encoder backward + normalise backward + update
-        encoder_backward<SP>(ew, my_f, my_gn, my_em, enc_sp, PNDF_PARENT, ap);
+        encoder_backward<SP>(my_f, my_gn, eb, ring, ap, g);
         if (DBG && dbg && step == 0) {
             for (int i = 0; i < NQ; ++i) dbg[(size_t)(DBG_GN + i) * WG_THREADS + tid] = my_gn[i];
         }

@@ -52,8 +52,19 @@ constexpr Phase PHASES[6] = {
 
 constexpr int phase_chunk_tiles(const Phase& p) { return p.CT * p.KA + p.NB * p.CT; }
 constexpr int phase_tiles(const Phase& p) { return p.NC * phase_chunk_tiles(p); }
-constexpr int FWD_TILES = phase_tiles(PHASES[0]) + phase_tiles(PHASES[1]) + phase_tiles(PHASES[2]);
-constexpr int BWD_TILES = phase_tiles(PHASES[3]) + phase_tiles(PHASES[4]) + phase_tiles(PHASES[5]);
+
+// The encoder (21 BoneMLPs, reference net_modules.py:75-170) also runs on the MFMA pipe, batched over the 16
+// poses of a wave: per joint two 16x16 weight tiles forward (W1: rows = 10 hidden units, k = 4|10 inputs;
+// W2: rows 4..9 = the 6 features, k = hidden) and two transposed tiles backward.  Putting the features on
+// rows 4..9 makes a joint's output tile (D layout) directly the B operand of its children (input vector =
+// [quat(4) | parent feature(6)]: lane group 0 substitutes the child's own normalised quaternion).
+// 42 tiles per direction, padded to 3 slots; forward tiles open the step's stream, backward tiles close it.
+constexpr int ENC_TILES = 2 * 21;
+constexpr int ENC_TILES_PADDED = 48;
+constexpr int TRUNK_FWD_TILES = phase_tiles(PHASES[0]) + phase_tiles(PHASES[1]) + phase_tiles(PHASES[2]);
+constexpr int TRUNK_BWD_TILES = phase_tiles(PHASES[3]) + phase_tiles(PHASES[4]) + phase_tiles(PHASES[5]);
+constexpr int FWD_TILES = ENC_TILES_PADDED + TRUNK_FWD_TILES;
+constexpr int BWD_TILES = TRUNK_BWD_TILES + ENC_TILES_PADDED;
 constexpr int STEP_TILES = FWD_TILES + BWD_TILES;
 constexpr int FWD_SLOTS = FWD_TILES / SLOT_TILES;
 constexpr int STEP_SLOTS = STEP_TILES / SLOT_TILES;
@@ -61,25 +72,19 @@ static_assert(FWD_TILES % SLOT_TILES == 0 && BWD_TILES % SLOT_TILES == 0, "slot 
 static_assert(phase_chunk_tiles(PHASES[0]) % SLOT_TILES == 0, "chunk bodies are whole slots");
 static_assert(phase_chunk_tiles(PHASES[1]) % SLOT_TILES == 0, "chunk bodies are whole slots");
 static_assert(phase_chunk_tiles(PHASES[2]) % SLOT_TILES == 0, "chunk bodies are whole slots");
-static_assert(FWD_TILES == 5312 && STEP_TILES == 10624, "amass.yaml trunk");
+static_assert(TRUNK_FWD_TILES == 5312 && TRUNK_BWD_TILES == 5312 && STEP_TILES == 10720, "amass.yaml trunk");
+static_assert(ENC_TILES_PADDED % SLOT_TILES == 0 && ENC_TILES <= ENC_TILES_PADDED - SLOT_TILES / 2 + 2,
+              "every ring event of the encoder's slots must fall on a tile that is actually read");
 
 // bias block (floats) copied to LDS: b0..b5, then w6 (64), then b6
 constexpr int BIAS_OFF[NLIN] = {0, 256, 768, 1792, 2304, 2560, 2688};
 constexpr int W6_OFF = 2624;
-constexpr int BIAS_FLOATS = 2692;   // padded to a multiple of 4
+constexpr int ENCB_OFF = 2692;      // encoder biases: per joint b1 padded to 16, then b2 on rows 4..9 of 16
+constexpr int BIAS_FLOATS = ENCB_OFF + 21 * 32;
 
-// encoder parameter block (floats), 16-byte aligned sub-blocks so that it can be read from LDS with
-// ds_read_b128: per joint W1[10][in] | b1[10] (+2 pad) | W2[6][10] | b2[6] (+2 pad)
 constexpr int PARENT[NJ] = {-1, -1, -1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19};
 constexpr int enc_in(int j) { return PARENT[j] < 0 ? 4 : 10; }
-constexpr int enc_b1(int j) { return HID * enc_in(j); }
-constexpr int enc_w2(int j) { return enc_b1(j) + 12; }
-constexpr int enc_b2(int j) { return enc_w2(j) + FEAT * HID; }
-constexpr int enc_size(int j) { return enc_b2(j) + 8; }
-constexpr int enc_off(int j) { return j == 0 ? 0 : enc_off(j - 1) + enc_size(j - 1); }
-constexpr int ENC_FLOATS = enc_off(NJ - 1) + enc_size(NJ - 1);
-static_assert(ENC_FLOATS == 3 * 120 + 18 * 180, "padded encoder block");
-static_assert(enc_size(0) % 4 == 0 && enc_size(3) % 4 == 0, "16-byte aligned joints");
+constexpr int ENC_FEAT_ROW = 4;     // features live on rows 4..9 of the joint's output tile
 
 // chunk-mask slots (one u16 per lane per chunk) for the three chunked layers x1, x3, x5
 constexpr int MASK_BASE[3] = {0, 8, 40};

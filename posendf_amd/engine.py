@@ -46,9 +46,9 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.pndf_debug_project_timing.argtypes = [H, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]
     lib.pndf_debug_project_timing.restype = c_int
     lib.pndf_debug_timing_regions.restype = c_int
-    lib.pndf_packed_sizes.argtypes = [POINTER(c_int64)] * 3
+    lib.pndf_packed_sizes.argtypes = [POINTER(c_int64)] * 2
     lib.pndf_packed_sizes.restype = None
-    lib.pndf_pack_host.argtypes = [POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p, c_void_p, c_void_p]
+    lib.pndf_pack_host.argtypes = [POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p, c_void_p]
     lib.pndf_last_error.argtypes = [H]
     lib.pndf_last_error.restype = c_char_p
     lib.pndf_version.restype = c_char_p
@@ -79,18 +79,17 @@ def _tensor_table(sd_np):
 
 
 def pack_host(sd_np, lib=None):
-    """Host-only packing (no device): returns (stream[STEP_TILES*256], enc, bias) float32 arrays."""
+    """Host-only packing (no device): returns (stream[STEP_TILES*256], bias) float32 arrays."""
     lib = lib or load_library()
-    n = [c_int64(), c_int64(), c_int64()]
+    n = [c_int64(), c_int64()]
     lib.pndf_packed_sizes(*[ctypes.byref(x) for x in n])
     stream = np.empty(n[0].value, np.float32)
-    enc = np.empty(n[1].value, np.float32)
-    bias = np.empty(n[2].value, np.float32)
+    bias = np.empty(n[1].value, np.float32)
     arrs, ptrs, numel = _tensor_table(sd_np)
-    rc = lib.pndf_pack_host(ptrs, numel, len(arrs), stream.ctypes.data, enc.ctypes.data, bias.ctypes.data)
+    rc = lib.pndf_pack_host(ptrs, numel, len(arrs), stream.ctypes.data, bias.ctypes.data)
     if rc != 0:
         raise PndfError(f"pndf_pack_host failed ({rc})")
-    return stream, enc, bias
+    return stream, bias
 
 
 class Engine:

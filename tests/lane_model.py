@@ -34,10 +34,15 @@ def mfma_16x16x4(a, b, c):
     return out
 
 
+ENC_PAD = 48          # encoder tiles per direction, padded to 3 slots (pndf_layout.h)
+ENCB_OFF = 2692
+PARENT = (-1, -1, -1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19)
+
+
 class Stream:
-    def __init__(self, stream):
+    def __init__(self, stream, pos=0):
         self.t = stream.reshape(-1, 64, 4)
-        self.pos = 0
+        self.pos = pos
 
     def tile(self):
         t = self.t[self.pos]
@@ -105,6 +110,79 @@ def decode(tiles):
     return out
 
 
+def _tile_bias(bias, off):
+    x = np.zeros((64, 4), np.float32)
+    for r in range(4):
+        x[:, r] = bias[off + 4 * G + r]
+    return x
+
+
+def _mm(tile, x, c):
+    for s in range(4):
+        c = mfma_16x16x4(tile[:, s], x[:, s], c)
+    return c
+
+
+def encoder_fwd_wave(q16, stream, bias, slope):
+    """q16 [16,21,4] -> (features [16,126], per-joint sign masks) using the encoder tiles at the head of the
+    stream (posendf_amd/csrc/pndf_kernel.hip: enc_fwd_joint)."""
+    q16 = q16.astype(np.float32)
+    denom = np.maximum(np.sqrt((q16 * q16).sum(1)), np.float32(1e-12))   # [16,4]
+    st = Stream(stream, 0)
+    F, masks = [None] * 21, [None] * 21
+    feats = np.zeros((16, 126), np.float32)
+    for j in range(21):
+        t1, t2 = st.tile(), st.tile()
+        nq = (q16[:, j, :] / denom)[P]                      # every lane: its pose's normalised quaternion
+        par = F[PARENT[j]] if PARENT[j] >= 0 else np.zeros((64, 4), np.float32)
+        X = np.where((G == 0)[:, None], nq, par)
+        H = _mm(t1, X, _tile_bias(bias, ENCB_OFF + 32 * j))
+        mh = H > 0
+        H = np.where(mh, H, H * np.float32(slope))
+        Fj = _mm(t2, H, _tile_bias(bias, ENCB_OFF + 32 * j + 16))
+        mf = Fj > 0
+        Fj = np.where(mf, Fj, Fj * np.float32(slope))
+        F[j], masks[j] = Fj, (mh, mf)
+        for lane in range(64):
+            g, p = lane >> 4, lane & 15
+            if g == 1:
+                feats[p, 6 * j:6 * j + 4] = Fj[lane]
+            elif g == 2:
+                feats[p, 6 * j + 4:6 * j + 6] = Fj[lane, :2]
+    assert st.pos == 42
+    return feats, masks
+
+
+def encoder_bwd_wave(gx0, masks, stream, slope):
+    """gx0 [16,128] (d d / d feature) -> d d / d n [16,84] using the encoder tiles at the tail of the stream."""
+    ntiles = stream.size // 256
+    st = Stream(stream, ntiles - ENC_PAD)
+    GF = []
+    for j in range(21):
+        x = np.zeros((64, 4), np.float32)
+        for lane in range(64):
+            g, p = lane >> 4, lane & 15
+            if g == 1:
+                x[lane] = gx0[p, 6 * j:6 * j + 4]
+            elif g == 2:
+                x[lane, :2] = gx0[p, 6 * j + 4:6 * j + 6]
+        GF.append(x)
+    gn = np.zeros((16, 84), np.float32)
+    for j in range(20, -1, -1):
+        t1, t2 = st.tile(), st.tile()
+        mh, mf = masks[j]
+        gz2 = np.where(mf, GF[j], GF[j] * np.float32(slope))
+        GH = _mm(t1, gz2, np.zeros((64, 4), np.float32))
+        gz1 = np.where(mh, GH, GH * np.float32(slope))
+        GI = _mm(t2, gz1, np.zeros((64, 4), np.float32))
+        for lane in range(16):                             # lane group 0: rows 0..3 = d d / d n_j
+            gn[lane, 4 * j:4 * j + 4] = GI[lane]
+        if PARENT[j] >= 0:
+            GF[PARENT[j]] = GF[PARENT[j]] + GI
+    assert st.pos == ntiles - ENC_PAD + 42
+    return gn
+
+
 def trunk_wave(feat16, stream, bias, slope):
     """feat16: [16,126] encoder features of the wave's 16 poses.  Returns (d[16], gx0[16,128], stages)."""
     f = np.zeros((16, 128), np.float32)
@@ -115,7 +193,7 @@ def trunk_wave(feat16, stream, bias, slope):
         for s in range(4):
             x[:, s] = f[P, 16 * kt + 4 * G + s]
         x0.append(x)
-    st, masks, stages = Stream(stream), {}, {}
+    st, masks, stages = Stream(stream, ENC_PAD), {}, {}
     x2 = load_bias(bias, BIAS_OFF[1], 32)
     run_phase(0, x0, x2, st, bias[BIAS_OFF[0]:], masks, slope, False)
     x2, m2 = act_tiles(x2, slope)
@@ -150,5 +228,5 @@ def trunk_wave(feat16, stream, bias, slope):
     stages["g2"] = decode(g2)
     g0 = [np.zeros((64, 4), np.float32) for _ in range(8)]
     run_phase(5, g2, g0, st, None, masks, slope, True)
-    assert st.pos == st.t.shape[0], (st.pos, st.t.shape)
+    assert st.pos == st.t.shape[0] - ENC_PAD, (st.pos, st.t.shape)
     return d[:16], decode(g0), stages

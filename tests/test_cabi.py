@@ -66,7 +66,7 @@ def test_no_device_is_a_loud_error(lib):
 def test_pack_host_rejects_bad_tables(lib):
     from posendf_amd import engine, synth
     sd = synth.make_weights(1)
-    stream, enc, bias = engine.pack_host(sd, lib)
+    stream, bias = engine.pack_host(sd, lib)
     assert np.isfinite(stream).all()
     bad = dict(sd)
     bad["dfnet.lin3.weight"] = bad["dfnet.lin3.weight"][:, :-1]

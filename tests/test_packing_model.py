@@ -12,16 +12,23 @@ def test_lane_model_matches_oracle(act, slope):
     from posendf_amd import engine, synth
     import lane_model as lm
     sd = golden_weights("mixed")
-    stream, enc, bias = engine.pack_host(sd)
+    stream, bias = engine.pack_host(sd)
     q = synth.make_poses(16, seed=7, signed=True)
     dbg = {}
     d, dq = onp.forward_grad(q, sd, act, debug=dbg)
-    d_m, gx0_m, stages = lm.trunk_wave(dbg["feat"], stream, bias, slope)
+    # encoder on the MFMA pipe: features from the raw poses, and d d / d n back from d d / d feature
+    feat_m, emasks = lm.encoder_fwd_wave(q, stream, bias, slope)
+    assert rel_err(feat_m, dbg["feat"]) < 1e-5
+    gx0_pad = np.zeros((16, 128), np.float32)
+    gx0_pad[:, :126] = dbg["gx"][0]
+    gn_m = lm.encoder_bwd_wave(gx0_pad, emasks, stream, slope)
+    assert rel_err(gn_m, dbg["gn"].reshape(16, 84)) < 2e-5
+    d_m, gx0_m, stages = lm.trunk_wave(feat_m, stream, bias, slope)
     # forward activations of the accumulator layers, distance, and d d / d feature
     assert rel_err(stages["x2"], onp._act(dbg["zs"][1], act, 100.0)) < 1e-5
     assert rel_err(stages["x4"], onp._act(dbg["zs"][3], act, 100.0)) < 1e-5
     assert rel_err(stages["x6"], onp._act(dbg["zs"][5], act, 100.0)) < 1e-5
-    assert d_err(d_m, d[:, 0]) < 2e-5
+    assert d_err(d_m, d[:, 0]) < 5e-5
     assert rel_err(gx0_m[:, :126], dbg["gx"][0]) < 2e-5
     assert np.all(gx0_m[:, 126:] == 0)
 
@@ -29,25 +36,39 @@ def test_lane_model_matches_oracle(act, slope):
 def test_packed_blocks_layout():
     from posendf_amd import engine, synth
     sd = synth.make_weights(3)
-    stream, enc, bias = engine.pack_host(sd)
-    assert stream.size == 10624 * 256
+    stream, bias = engine.pack_host(sd)
+    assert stream.size == 10720 * 256 and bias.size == 2692 + 21 * 32
     # bias block
     assert np.array_equal(bias[0:256], sd["dfnet.lin0.bias"])
     assert np.array_equal(bias[2560:2624], sd["dfnet.lin5.bias"])
     assert np.array_equal(bias[2624:2688], sd["dfnet.lin6.weight"][0])
     assert bias[2688] == sd["dfnet.lin6.bias"][0]
-    # encoder block: joint 0 (root, 120 floats) then joint 3 (first child) at 360
-    assert np.array_equal(enc[0:40], sd["enc.net.0.net.0.weight"].ravel())
-    assert np.array_equal(enc[40:50], sd["enc.net.0.net.0.bias"])
-    assert np.array_equal(enc[52:112], sd["enc.net.0.net.2.weight"].ravel())
-    assert np.array_equal(enc[112:118], sd["enc.net.0.net.2.bias"])
-    assert np.array_equal(enc[360:460], sd["enc.net.3.net.0.weight"].ravel())
-    assert np.array_equal(enc[360 + 112:360 + 172], sd["enc.net.3.net.2.weight"].ravel())
-    # first tile of the stream = tile(W0 padded, nt=0, kt=0): lane l -> W0[l & 15][4 (l >> 4) + s]
+    # encoder biases: joint 3: b1 at +0..9, b2 on rows 4..9 of the second 16
+    eb = bias[2692 + 32 * 3:2692 + 32 * 4]
+    assert np.array_equal(eb[0:10], sd["enc.net.3.net.0.bias"]) and np.all(eb[10:16] == 0)
+    assert np.array_equal(eb[20:26], sd["enc.net.3.net.2.bias"]) and np.all(eb[16:20] == 0) and np.all(eb[26:] == 0)
+    # encoder forward tiles open the stream: tile 2j = W1 of joint j, tile 2j+1 = W2 on rows 4..9
+    t = stream[: 48 * 256].reshape(48, 64, 4)
+    w1, w2 = sd["enc.net.3.net.0.weight"], sd["enc.net.3.net.2.weight"]
+    for lane in (0, 9, 21, 40):
+        r, g = lane & 15, lane >> 4
+        want = np.zeros(4, np.float32)
+        for s_ in range(4):
+            k = 4 * g + s_
+            want[s_] = w1[r, k] if (r < 10 and k < 10) else 0.0
+        assert np.array_equal(t[6][lane], want)
+        want = np.zeros(4, np.float32)
+        for s_ in range(4):
+            k = 4 * g + s_
+            want[s_] = w2[r - 4, k] if (4 <= r < 10 and k < 10) else 0.0
+        assert np.array_equal(t[7][lane], want)
+    assert np.all(t[42:] == 0)
+    # first trunk tile = tile(W0 padded, nt=0, kt=0): lane l -> W0[l & 15][4 (l >> 4) + s]
     w0 = sd["dfnet.lin0.weight"]
-    t0 = stream[:256].reshape(64, 4)
+    t0 = stream[48 * 256:49 * 256].reshape(64, 4)
     for lane in (0, 5, 17, 63):
         assert np.array_equal(t0[lane], w0[lane & 15, 4 * (lane >> 4):4 * (lane >> 4) + 4])
     # every weight appears in the stream exactly twice (forward tile + transposed tile): checksum of squares
     tot = sum(float((sd[f"dfnet.lin{l}.weight"].astype(np.float64) ** 2).sum()) for l in range(6))
+    tot += sum(float((sd[f"enc.net.{j}.net.{k}.weight"].astype(np.float64) ** 2).sum()) for j in range(21) for k in (0, 2))
     assert abs(float((stream.astype(np.float64) ** 2).sum()) - 2 * tot) < 1e-6 * tot
