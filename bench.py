@@ -125,6 +125,13 @@ def main():
         kern_ms = float(k.item())
 
     if rank == 0:
+        # HBM traffic of the dominant kernel: from the committed PMC passes of the same command
+        # (tools/gpu_profile.sh -> profiles/traffic.json); bench.py itself cannot run rocprofv3
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tpath) and args.act != "softplus" and B == 65536 and args.proj_steps == 100:
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
         total = B * world * args.steps
         achieved = B * args.proj_steps * FLOP_PER_POSE_STEP / (kern_ms * 1e-3) / 1e12
         out = {
@@ -146,8 +153,11 @@ def main():
                        "global_batch": B * world, "proj_steps": args.proj_steps,
                        "parallelism": f"batch-sharded x{world}, final RCCL all_gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "pndf_fused_relu_kernel", "kernel_ms": kern_ms,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)",
+                         "algorithmic_bytes_per_launch": B * 676 + 10720 * 1024,
+                         "kernel": "pndf_fused_softplus_kernel" if args.act == "softplus" else "pndf_fused_relu_kernel",
+                         "kernel_ms": kern_ms,
                          "algorithmic_flop_per_launch": B * args.proj_steps * FLOP_PER_POSE_STEP},
         }
         if world == 1 and not args.no_cpu_baseline:
