@@ -1,0 +1,116 @@
+// Feasibility micro-benchmark for a split-precision (fp16 hi/lo, 3 MFMAs per product block, fp32 accumulate)
+// version of the (lin2,lin3) chunk: v_mfma_f32_16x16x32_f16 fed from LDS (2 x ds_read_b128 per 3 MFMAs).
+// Per chunk: part A 16 k-blocks x 2 tiles x 3 = 96 MFMAs, part B 32 tiles x 3 = 96 MFMAs, 128 KiB of LDS reads.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mf(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// a "group" = 4 tile-pairs (hi, lo) = 8 KiB of LDS = 12 MFMAs
+template <int T0>
+__device__ __forceinline__ void load_group(f16x8 (&h)[4], f16x8 (&l)[4], const char* smem, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = *(const f16x8*)(smem + ((2 * (T0 + i)) % 32) * 1024 + lane * 16);
+        l[i] = *(const f16x8*)(smem + ((2 * (T0 + i) + 1) % 32) * 1024 + lane * 16);
+    }
+}
+
+template <int GI, int MODE>
+__device__ __forceinline__ void groups(const f16x8 (&xh)[16], const f16x8 (&xl)[16], f32x4 (&acc)[32], f32x4 (&ch)[2],
+                                       f16x8 (&chh)[1], f16x8 (&chl)[1], f16x8 (&ch_)[4], f16x8 (&cl_)[4],
+                                       const char* smem, int lane, int c, int nc) {
+    if constexpr (GI < 16) {
+        f16x8 nh[4], nl[4];
+        if (GI + 1 < 16 || c + 1 < nc) load_group<((GI + 1) * 4) % 64>(nh, nl, smem, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (GI < 8) {           // part A: 2 k-blocks x 2 tiles per group
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci) {
+                    ch[ci] = mf(ch_[k2 * 2 + ci], xh[2 * GI + k2], ch[ci]);
+                    ch[ci] = mf(ch_[k2 * 2 + ci], xl[2 * GI + k2], ch[ci]);
+                    ch[ci] = mf(cl_[k2 * 2 + ci], xh[2 * GI + k2], ch[ci]);
+                }
+            if constexpr (GI == 7 && (MODE & 1) == 0) {
+                // epilogue: activation + split into fp16 hi / lo, packed as the next B operand
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float z = ch[ci][r];
+                        z = z * fmaf(fminf(fmaxf(z * 1e30f, 0.f), 1.f), 0.99f, 0.01f);
+                        const _Float16 hi = (_Float16)z;
+                        const _Float16 lo = (_Float16)(z - (float)hi);
+                        chh[0][ci * 4 + r] = hi;
+                        chl[0][ci * 4 + r] = lo;
+                    }
+            }
+        } else {                          // part B: 4 output tiles per group
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                constexpr int dummy = 0; (void)dummy;
+                const int nb = (MODE & 2) ? t : (GI - 8) * 4 + t;
+                acc[nb] = mf(ch_[t], chh[0], acc[nb]);
+                acc[nb] = mf(ch_[t], chl[0], acc[nb]);
+                acc[nb] = mf(cl_[t], chh[0], acc[nb]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ch_[i] = nh[i]; cl_[i] = nl[i]; }
+        groups<GI + 1, MODE>(xh, xl, acc, ch, chh, chl, ch_, cl_, smem, lane, c, nc);
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) k(float* out, unsigned long long* cyc, int nc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 32768 / 2; i += 256) ((_Float16*)smem)[i] = (_Float16)(1e-2f * (1 + (i % 7)));
+    __syncthreads();
+    f16x8 xh[16], xl[16];
+    f32x4 acc[32];
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 8; ++j) { xh[i][j] = (_Float16)(0.01f * (lane % 5 + i + j)); xl[i][j] = (_Float16)(1e-5f * (i + j)); }
+    for (int i = 0; i < 32; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    f16x8 ch_[4], cl_[4], chh[1], chl[1];
+    load_group<0>(ch_, cl_, smem, lane);
+    for (int j = 0; j < 8; ++j) { chh[0][j] = (_Float16)0.1f; chl[0][j] = (_Float16)1e-4f; }
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int c = 0; c < nc; ++c) {
+        f32x4 ch[2] = {f32x4{0.1f, 0.2f, 0.3f, 0.4f}, f32x4{0.1f, 0.2f, 0.3f, 0.4f}};
+        groups<0, MODE>(xh, xl, acc, ch, chh, chl, ch_, cl_, smem, lane, c, nc);
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int i = 0; i < 32; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s + (float)chh[0][0];
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int MODE>
+void run(const char* name, float* out, unsigned long long* cyc) {
+    const int nc = 640, grid = 256;
+    hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipLaunchKernelGGL((k<MODE>), dim3(grid), dim3(256), 65536, 0, out, cyc, nc);
+    hipDeviceSynchronize();
+    unsigned long long h[256];
+    hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    double mean = 0;
+    for (int i = 0; i < grid; ++i) mean += h[i];
+    mean /= grid;
+    printf("%-40s %8.1f cycles / chunk  (192 MFMAs: %.2f cyc/MFMA; fp32 kernel chunk = 18400)\n", name, mean / nc, mean / nc / 192);
+}
+
+int main() {
+    float* out; unsigned long long* cyc;
+    hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 256 * 8);
+    run<0>("split chunk, epilogue, 32 acc tiles", out, cyc);
+    run<1>("split chunk, no epilogue", out, cyc);
+    run<3>("no epilogue, 4 accumulators", out, cyc);
+    return 0;
+}
