@@ -47,7 +47,14 @@ typedef struct {
     int32_t n_dims;         /* 8: in_dim, dims..., 1 */
     int32_t dims[16];       /* 126,256,512,1024,512,256,64,1 (amass.yaml:26,30) */
     int32_t parent[32];     /* net_utils.py:46 */
+    int32_t precision;      /* pndf_precision: arithmetic of the trunk (engine knob, no reference counterpart) */
 } pndf_config;
+
+/* PNDF_PREC_FP32 : exact fp32 MFMA (v_mfma_f32_16x16x4_f32), bit-comparable to an fmaf chain.
+ * PNDF_PREC_F16X3: every fp32 operand split into fp16 hi + lo, three v_mfma_f32_16x16x32_f16 per product block,
+ *                  fp32 accumulate: ~2^-22 relative product error (fp32-class), ~4x the throughput.
+ *                  Operands must stay inside the fp16 range (|x| < 65504); relu / lrelu only. */
+typedef enum { PNDF_PREC_FP32 = 0, PNDF_PREC_F16X3 = 1 } pndf_precision;
 
 /* Fills cfg with the configs/amass.yaml architecture and the SMPL parent table. */
 void pndf_default_config(pndf_config* cfg, int32_t act, float beta);
@@ -94,6 +101,9 @@ int pndf_debug_timing_regions(void);
 void pndf_packed_sizes(int64_t* stream_floats, int64_t* bias_floats);
 int pndf_pack_host(const float* const* tensors, const int64_t* numel, int n_tensors, float* stream,
                    float* bias);
+/* same for the split-precision stream (same size in bytes; trunk tiles hold fp16 pairs) */
+int pndf_pack_host_split(const float* const* tensors, const int64_t* numel, int n_tensors, float* stream,
+                         float* bias);
 
 const char* pndf_last_error(pndf_handle h);   /* h may be NULL: last error of a failed pndf_create */
 const char* pndf_version(void);

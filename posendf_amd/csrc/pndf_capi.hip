@@ -32,6 +32,7 @@ struct PndfKernelArgs {
 };
 extern "C" __global__ void pndf_fused_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_softplus_kernel(PndfKernelArgs args);
+extern "C" __global__ void pndf_fused_split_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_relu_kernel_timing(PndfKernelArgs args);
 extern "C" int pndf_kernel_timing_regions();
 extern "C" long long pndf_kernel_softplus_scratch_floats_per_wg();
@@ -78,6 +79,7 @@ extern "C" void pndf_default_config(pndf_config* cfg, int32_t act, float beta) {
     cfg->n_dims = NLIN + 1;
     for (int i = 0; i <= NLIN; ++i) cfg->dims[i] = DIMS[i];
     for (int i = 0; i < NJ; ++i) cfg->parent[i] = PARENT[i];
+    cfg->precision = PNDF_PREC_FP32;
 }
 
 static int check_config(pndf_engine* h, const pndf_config* cfg) {
@@ -93,6 +95,10 @@ static int check_config(pndf_engine* h, const pndf_config* cfg) {
         return fail(h, PNDF_ERR_UNSUPPORTED, "unknown activation (relu, lrelu and softplus are implemented)");
     if (cfg->act == PNDF_ACT_SOFTPLUS && !(cfg->beta > 0.f))
         return fail(h, PNDF_ERR_BAD_ARG, "softplus beta must be positive");
+    if (cfg->precision != PNDF_PREC_FP32 && cfg->precision != PNDF_PREC_F16X3)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "unknown precision (fp32 and f16x3 are implemented)");
+    if (cfg->precision == PNDF_PREC_F16X3 && cfg->act == PNDF_ACT_SOFTPLUS)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "the split-precision kernel implements relu / lrelu; softplus runs in fp32");
     return PNDF_OK;
 }
 
@@ -116,6 +122,8 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias, BIAS_FLOATS * sizeof(float));
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)pndf_fused_split_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_softplus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
@@ -249,11 +257,61 @@ extern "C" int pndf_pack_host(const float* const* tensors, const int64_t* numel,
     return PNDF_OK;
 }
 
+// ---- split-precision stream
+namespace {
+inline void split_f16(float w, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)w;                       // round to nearest even
+    lo = (_Float16)(w - (float)hi);
+}
+// block(M, nt, kb): hi tile then lo tile, 8 halfs per lane each
+void emit_pair(const Mat& m, int nt, int kb, float* dst) {
+    _Float16* hi = (_Float16*)dst;
+    _Float16* lo = (_Float16*)(dst + TILE_FLOATS);
+    for (int lane = 0; lane < 64; ++lane)
+        for (int jj = 0; jj < 8; ++jj) {
+            const float w = m.at(16 * nt + (lane & 15), 16 * (2 * kb + (jj >> 2)) + 4 * (lane >> 4) + (jj & 3));
+            split_f16(w, hi[lane * 8 + jj], lo[lane * 8 + jj]);
+        }
+}
+}  // namespace
+
+extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* numel, int n_tensors, float* stream,
+                                    float* bias) {
+    // biases and encoder tiles are identical to the fp32 stream (the encoder stays on fp32 MFMA)
+    int rc = pndf_pack_host(tensors, numel, n_tensors, stream, bias);
+    if (rc != PNDF_OK) return rc;
+    const float* const* lin = tensors + 4 * NJ;
+    float* dst = stream + (size_t)ENC_TILES_PADDED * TILE_FLOATS;
+    for (int ph = 0; ph < 6; ++ph) {
+        const Phase& P = PHASES[ph];
+        const Mat A{lin[2 * P.a_lin], DIMS[P.a_lin + 1], DIMS[P.a_lin], P.transposed};
+        const Mat B{lin[2 * P.b_lin], DIMS[P.b_lin + 1], DIMS[P.b_lin], P.transposed};
+        auto partA = [&](int c) {
+            for (int kb = 0; kb < P.KA / 2; ++kb)
+                for (int ci = 0; ci < P.CT; ++ci, dst += 2 * TILE_FLOATS) emit_pair(A, c * P.CT + ci, kb, dst);
+        };
+        auto partB = [&](int c) {
+            for (int nb = 0; nb < P.NB; ++nb)
+                for (int b = 0; b < P.CT / 2; ++b, dst += 2 * TILE_FLOATS) emit_pair(B, nb, (c * P.CT) / 2 + b, dst);
+        };
+        partA(0);
+        for (int c = 0; c < P.NC; ++c) {
+            if (c + 1 < P.NC) partA(c + 1);
+            partB(c);
+        }
+    }
+    if (dst - stream != (ptrdiff_t)(ENC_TILES_PADDED + TRUNK_FWD_TILES + TRUNK_BWD_TILES) * TILE_FLOATS) return PNDF_ERR_BAD_SHAPE;
+    return PNDF_OK;
+}
+
 extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, const int64_t* numel, int n_tensors) {
     if (!h) return PNDF_ERR_BAD_ARG;
     if (const char* why = check_tensors(tensors, numel, n_tensors)) return fail(h, PNDF_ERR_BAD_SHAPE, why);
     std::vector<float> stream((size_t)STEP_TILES * TILE_FLOATS), bias(BIAS_FLOATS);
-    if (pndf_pack_host(tensors, numel, n_tensors, stream.data(), bias.data()) != PNDF_OK)
+    const int prc = (h->cfg.precision == PNDF_PREC_F16X3)
+                        ? pndf_pack_host_split(tensors, numel, n_tensors, stream.data(), bias.data())
+                        : pndf_pack_host(tensors, numel, n_tensors, stream.data(), bias.data());
+    if (prc != PNDF_OK)
         return fail(h, PNDF_ERR_BAD_SHAPE, "internal: packed stream length mismatch");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());   // no launch may still be reading the old weights
@@ -309,7 +367,10 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
         HIP_TRY(h, hipGetLastError());
         return PNDF_OK;
     }
-    if (timing) hipLaunchKernelGGL(pndf_fused_relu_kernel_timing, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+    const bool split = h->cfg.precision == PNDF_PREC_F16X3;
+    if (split && (timing || dbg)) return fail(h, PNDF_ERR_UNSUPPORTED, "debug / timing kernels exist for fp32 precision only");
+    if (split) hipLaunchKernelGGL(pndf_fused_split_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+    else if (timing) hipLaunchKernelGGL(pndf_fused_relu_kernel_timing, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else if (dbg) hipLaunchKernelGGL(pndf_fused_relu_kernel_dbg, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else hipLaunchKernelGGL(pndf_fused_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     HIP_TRY(h, hipGetLastError());

@@ -1,0 +1,443 @@
+// Split-precision variant of the fused Pose-NDF kernel for gfx950: same ownership, register-resident transposed
+// trunk, pair fusion, weight ring and fp32 MFMA encoder as pndf_kernel.hip, but the trunk contractions run on
+// v_mfma_f32_16x16x32_f16 with every fp32 operand carried as fp16 hi + fp16 lo:
+//     W x  ~=  Wh xh + Wh xl + Wl xh        (fp32 accumulate; dropped Wl xl term ~2^-22 relative)
+// i.e. three f16 MFMAs (8192 MACs each, ~8-10 cycles) replace eight fp32 MFMAs (1024 MACs, 32 cycles).
+// One MFMA contracts 32 k = two C/D tiles of the previous layer, whose registers -- converted and packed --
+// are again directly the B operand (pndf_layout.h "split-precision stream").
+// The phase is LDS-read bound (2 KiB of weight pair per 3 MFMAs per wave), so chunk epilogues are taken off
+// the critical path: part A of chunk c+1 is issued BEFORE part B of chunk c and the activation/split of chunk
+// c+1 is scheduled into the shadow of part B's MFMAs.
+#include "pndf_device.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+struct Blk {          // one k-block (32 k) of activations as B operand
+    f16x8 h, l;
+};
+struct Pair {         // one weight block: hi tile + lo tile
+    f16x8 h, l;
+};
+
+__device__ __forceinline__ f32x4 mf16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// (a, b) -> packed fp16 pair hi = rtz(a, b) and lo = rtz(a - hi_a, b - hi_b): the remainders are exact in fp32,
+// so hi + lo carries ~21 significant bits of each value
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]));
+}
+
+// two activated fp32 C/D tiles -> the B operand of the k-block they form (8 halfs = 4 dwords, hi and lo)
+__device__ __forceinline__ void pack_blk(const f32x4& t0, const f32x4& t1, Blk& o) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split2(t0[0], t0[1], h0, l0);
+    split2(t0[2], t0[3], h1, l1);
+    split2(t1[0], t1[1], h2, l2);
+    split2(t1[2], t1[3], h3, l3);
+    o.h = __builtin_bit_cast(f16x8, u32x4{h0, h1, h2, h3});
+    o.l = __builtin_bit_cast(f16x8, u32x4{l0, l1, l2, l3});
+}
+
+// ------------------------------------------------------------------ weight pairs from the ring
+// group = 4 pairs = 8 tiles (hi, lo, hi, lo, ...); ring events exactly as in the fp32 kernel
+template <int T0>
+__device__ __forceinline__ void load_pairs(Pair (&a)[4], Ring& ring) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int t = (T0 + i) % SLOT_TILES;
+        if (t == 0) ring_boundary(ring);
+        if (t == SLOT_TILES / 2) ring_midslot_sync(ring);
+        const f32x4 v = ring_tile(ring, t);
+        if (i & 1) a[i / 2].l = __builtin_bit_cast(f16x8, v);
+        else a[i / 2].h = __builtin_bit_cast(f16x8, v);
+    }
+}
+
+struct DmaPieces {     // the slot fetch that follows a mid-slot barrier, issued piecewise between MFMAs
+    const char* src;
+    uint32_t dst;
+    int n;
+};
+template <int T0>
+__device__ __forceinline__ void dma_begin(DmaPieces& d, Ring& ring, bool loaded) {
+    d.n = 4;
+    if (group_has_mid<8, T0>() && loaded) {
+        ring_dma_begin(ring, (ring.cur == 0) ? 2 : ring.cur - 1, d.src, d.dst);
+        d.n = 0;
+    }
+}
+__device__ __forceinline__ void dma_step(DmaPieces& d) {
+    if (d.n < 4) {
+        __builtin_amdgcn_sched_barrier(0);
+        ring_dma_piece(d.src, d.dst, d.n++);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ------------------------------------------------------------------ one fused layer pair, split precision
+template <int KA2, int CT, int NC, int NB, bool BWD>
+struct SplitPhase {
+    static constexpr int CB = CT / 2;                 // k-blocks of part B per chunk
+    static constexpr int AP = KA2 * CT, BP = NB * CB; // pairs per chunk
+    static constexpr int AG = AP / 4, BG = BP / 4;    // groups of 4 pairs
+    static constexpr int A_TILES = 2 * AP;
+    static_assert(AP % 4 == 0 && BP % 4 == 0 && A_TILES % SLOT_TILES == 0, "group / slot alignment");
+
+    // ---- part A: chunk rows of layer A.  Three partial accumulators per chunk tile (hh, hl, lh terms) keep
+    // dependent MFMAs far apart; they are summed in the epilogue.
+    template <int GA>
+    static __device__ __forceinline__ void part_a(const Blk (&xin)[KA2], f32x4 (&ch)[3][CT], Pair (&cur)[4], Ring& ring) {
+        if constexpr (GA < AG) {
+            Pair nxt[4];
+            constexpr int TN = (8 * (GA + 1)) % SLOT_TILES;
+            load_pairs<TN>(nxt, ring);                 // part B follows, so there is always a next group
+            DmaPieces dp;
+            dma_begin<TN>(dp, ring, true);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int term = 0; term < 3; ++term) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int pi = 4 * GA + i, kb = pi / CT, ci = pi % CT;
+                    const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
+                    const f16x8 x = (term == 1) ? xin[kb].l : xin[kb].h;
+                    ch[term][ci] = mf16(w, x, ch[term][ci]);
+                    if (i & 1) dma_step(dp);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+            part_a<GA + 1>(xin, ch, cur, ring);
+        }
+    }
+
+    // ---- chunk epilogue: sum the three partials, (forward) bias is already in ch[0], activation or mask, split
+    static __device__ __forceinline__ void epilogue(f32x4 (&ch)[3][CT], Blk (&out)[CB], uint16_t* mask, int c, float slope) {
+        f32x4 y[CT];
+        if (!BWD) {
+            float bitsum = 0.f;
+#pragma unroll
+            for (int ci = 0; ci < CT; ++ci) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z = (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r];
+                    const float st = step01(z);
+                    y[ci][r] = z * relu_factor(st, slope);
+                    bitsum = fmaf(st, (float)(1u << (ci * 4 + r)), bitsum);
+                }
+            }
+            mask[c * WG_THREADS] = (uint16_t)(uint32_t)bitsum;
+        } else {
+            const uint32_t bits = mask[c * WG_THREADS];
+#pragma unroll
+            for (int ci = 0; ci < CT; ++ci) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z = (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r];
+                    y[ci][r] = z * relu_factor((float)((bits >> (ci * 4 + r)) & 1u), slope);
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < CB; ++b) pack_blk(y[2 * b], y[2 * b + 1], out[b]);
+    }
+
+    static __device__ __forceinline__ void init_chunk(f32x4 (&ch)[3][CT], const float* biasA, int c, int g) {
+#pragma unroll
+        for (int ci = 0; ci < CT; ++ci) {
+            ch[0][ci] = BWD ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(biasA + 16 * (c * CT + ci) + 4 * g);
+            ch[1][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ch[2][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
+    // ---- part B: every output tile gets the chunk's contribution.  In group 0 the epilogue of the NEXT chunk
+    // (its part A has just been issued) is placed in the same scheduling region, so its VALU work is
+    // interleaved with these MFMAs by the compiler instead of stalling the pipe.
+    template <int GB>
+    static __device__ __forceinline__ void part_b(const Blk (&chb)[CB], f32x4 (&acc)[NB], Pair (&cur)[4], Ring& ring,
+                                                  bool more, f32x4 (&chn)[3][CT], Blk (&nextb)[CB], uint16_t* mask,
+                                                  int c, float slope) {
+        if constexpr (GB < BG) {
+            Pair nxt[4];
+            constexpr int TN = (A_TILES + 8 * (GB + 1)) % SLOT_TILES;
+            const bool loaded = (GB + 1 < BG) || more;
+            if (loaded) load_pairs<TN>(nxt, ring);
+            DmaPieces dp;
+            dma_begin<TN>(dp, ring, loaded);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int term = 0; term < 3; ++term) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int pi = 4 * GB + i, nb = pi / CB, b = pi % CB;
+                    const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
+                    const f16x8 x = (term == 1) ? chb[b].l : chb[b].h;
+                    acc[nb] = mf16(w, x, acc[nb]);
+                    if (i & 1) dma_step(dp);
+                }
+            }
+            if constexpr (GB == 0) {
+                if (more) epilogue(chn, nextb, mask, c + 1, slope);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+            part_b<GB + 1>(chb, acc, cur, ring, more, chn, nextb, mask, c, slope);
+        }
+    }
+
+    static __device__ __forceinline__ void run(const Blk (&xin)[KA2], f32x4 (&acc)[NB], Ring& ring, const float* biasA,
+                                               uint16_t* mask, float slope, int g) {
+        Pair cur[4];
+        load_pairs<0>(cur, ring);
+        f32x4 ch[3][CT];
+        Blk chb[CB];
+        init_chunk(ch, biasA, 0, g);
+        part_a<0>(xin, ch, cur, ring);
+        epilogue(ch, chb, mask, 0, slope);
+        for (int c = 0; c < NC; ++c) {
+            const bool more = c + 1 < NC;
+            Blk nextb[CB];
+            if (more) {
+                init_chunk(ch, biasA, c + 1, g);
+                part_a<0>(xin, ch, cur, ring);
+            }
+            part_b<0>(chb, acc, cur, ring, more, ch, nextb, mask, c, slope);
+#pragma unroll
+            for (int b = 0; b < CB; ++b) chb[b] = nextb[b];
+        }
+    }
+};
+
+// activation of an accumulator layer + split into the next phase's B operands; sign bits in registers
+template <int NT>
+__device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 2], uint32_t (&m)[(NT * 4 + 31) / 32], float slope) {
+    constexpr int NW = (NT * 4 + 31) / 32;
+    float lo[NW], hi[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) lo[w] = hi[w] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float st = step01(x[t][r]);
+            x[t][r] = x[t][r] * relu_factor(st, slope);
+            const int w = (t * 4 + r) / 32, b = (t * 4 + r) % 32;
+            if (b < 16) lo[w] = fmaf(st, (float)(1u << b), lo[w]);
+            else hi[w] = fmaf(st, (float)(1u << (b - 16)), hi[w]);
+        }
+        if (t & 1) pack_blk(x[t - 1], x[t], out[t / 2]);
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        m[w] = (uint32_t)lo[w] | ((uint32_t)hi[w] << 16);
+        asm volatile("" : "+v"(m[w]));      // pin the packing here (see pndf_kernel.hip act_tiles)
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void dact_split_tiles(f32x4 (&gx)[NT], Blk (&out)[NT / 2], const uint32_t (&m)[(NT * 4 + 31) / 32], float slope) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            gx[t][r] = gx[t][r] * relu_factor((float)((m[(t * 4 + r) / 32] >> ((t * 4 + r) % 32)) & 1u), slope);
+        if (t & 1) pack_blk(gx[t - 1], gx[t], out[t / 2]);
+    }
+}
+
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_relu_kernel(PndfKernelArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;
+    const int p = lane & 15;
+    const int wp = wave * 16 + p;
+    ActP ap;
+    ap.slope = args.slope;
+    ap.beta = args.beta;
+    ap.sp = nullptr;
+    const float slope = args.slope;
+    const long long pose0 = (long long)blockIdx.x * WG_POSES;
+    float* const lds_bias = (float*)(smem + LDS_BIAS);
+    uint16_t* const lds_mask = (uint16_t*)(smem + LDS_MASK) + tid;
+    float* const lds_q = (float*)(smem + LDS_Q);
+    float* const my_q = lds_q + wp * NQ;
+    float* const my_f = (float*)(smem + LDS_F) + wp * FSTRIDE;
+    float* const my_gn = (float*)(smem + LDS_GN) + wp * NQ;
+
+    Ring ring;
+    ring.gstream = args.stream;
+    ring.smem = smem;
+    ring.nslots = (args.mode == MODE_FORWARD) ? FWD_SLOTS : STEP_SLOTS;
+    ring.wave = wave;
+    ring.lane = lane;
+    ring_start(ring);
+
+    for (int i = tid; i < BIAS_FLOATS / 4; i += WG_THREADS)
+        ((f32x4*)lds_bias)[i] = ((const f32x4*)args.bias)[i];
+    {
+        long long nvalid = args.B - pose0;
+        if (nvalid > WG_POSES) nvalid = WG_POSES;
+        const f32x4* src = (const f32x4*)(args.q_in + pose0 * NQ);
+        const int nvec = (int)nvalid * (NQ / 4);
+        for (int i = tid; i < WG_POSES * (NQ / 4); i += WG_THREADS) {
+            const int src_i = i < nvec ? i : (nvec - (NQ / 4) + (i % (NQ / 4)));
+            ((f32x4*)lds_q)[i] = src[src_i];
+        }
+    }
+    ring_wait_dma();
+    __syncthreads();
+
+    const int nsteps = (args.mode == MODE_PROJECT) ? args.steps : 1;
+    float dval = 0.f;
+    for (int step = 0; step < nsteps; ++step) {
+        uint32_t eb[6];
+        uint32_t m2[4], m4[4], m6[1];
+        f32x4 x6[4];
+        Blk b4[16];
+        {
+            Blk b2[16];
+            {
+                encoder_forward<false>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ap, g);
+                Blk b0[4];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+                    pack_blk(*(const f32x4*)(my_f + 32 * kb + 4 * g), *(const f32x4*)(my_f + 32 * kb + 16 + 4 * g), b0[kb]);
+                f32x4 x2[32];
+                load_bias<32>(x2, lds_bias + BIAS_OFF[1], g);
+                SplitPhase<4, 2, 8, 32, false>::run(b0, x2, ring, lds_bias + BIAS_OFF[0], lds_mask + MASK_BASE[0] * WG_THREADS, slope, g);
+                act_split_tiles<32>(x2, b2, m2, slope);
+            }
+            f32x4 x4[32];
+            load_bias<32>(x4, lds_bias + BIAS_OFF[3], g);
+            SplitPhase<16, 2, 32, 32, false>::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, slope, g);
+            act_split_tiles<32>(x4, b4, m4, slope);
+        }
+        load_bias<4>(x6, lds_bias + BIAS_OFF[5], g);
+        SplitPhase<16, 4, 4, 4, false>::run(b4, x6, ring, lds_bias + BIAS_OFF[4], lds_mask + MASK_BASE[2] * WG_THREADS, slope, g);
+        Blk b6[2];
+        act_split_tiles<4>(x6, b6, m6, slope);      // b6 unused forward; x6 (fp32) feeds lin6
+
+        // ---------------- lin6 (64 -> 1) + output ReLU, fp32 on the VALU
+        f32x4 w6[4];
+        load_bias<4>(w6, lds_bias + W6_OFF, g);
+        float part = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part = fmaf(w6[t][r], x6[t][r], part);
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        const float z7 = part + lds_bias[BIAS_OFF[6]];
+        dval = fmaxf(z7, 0.f);
+        if (args.mode == MODE_FORWARD) break;
+        float gz7 = (z7 > 0.f) ? 1.f : 0.f;
+        if (args.mode == MODE_FORWARD_GRAD && args.grad_out) {
+            long long pidx = pose0 + wp;
+            if (pidx >= args.B) pidx = args.B - 1;
+            gz7 *= args.grad_out[pidx];
+        }
+
+        // ---------------- trunk backward
+        {
+            f32x4 g0[8];
+            {
+                Blk gb2[16];
+                {
+                    Blk gb4[16];
+                    {
+                        f32x4 g6[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) g6[t] = w6[t] * gz7;
+                        Blk gb6[2];
+                        dact_split_tiles<4>(g6, gb6, m6, slope);
+                        f32x4 g4[32];
+#pragma unroll
+                        for (int t = 0; t < 32; ++t) g4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        SplitPhase<2, 4, 4, 32, true>::run(gb6, g4, ring, nullptr, lds_mask + MASK_BASE[2] * WG_THREADS, slope, g);
+                        dact_split_tiles<32>(g4, gb4, m4, slope);
+                    }
+                    f32x4 g2[32];
+#pragma unroll
+                    for (int t = 0; t < 32; ++t) g2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    SplitPhase<16, 2, 32, 32, true>::run(gb4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, slope, g);
+                    dact_split_tiles<32>(g2, gb2, m2, slope);
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) g0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                SplitPhase<16, 2, 8, 8, true>::run(gb2, g0, ring, nullptr, lds_mask + MASK_BASE[0] * WG_THREADS, slope, g);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) *(f32x4*)(my_f + 16 * t + 4 * g) = g0[t];
+        }
+        __syncthreads();
+
+        // ---------------- encoder backward + normalise backward + update (fp32, as pndf_kernel.hip)
+        encoder_backward<false>(my_f, my_gn, eb, ring, ap, g);
+        {
+            float ss[4], dot[4], denom[4], kk[4];
+            ss[0] = ss[1] = ss[2] = ss[3] = 0.f;
+            dot[0] = dot[1] = dot[2] = dot[3] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const f32x4 qv = *(const f32x4*)(my_q + 4 * j);
+                const f32x4 gv = *(const f32x4*)(my_gn + 4 * j);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ss[c] = fmaf(qv[c], qv[c], ss[c]);
+                    dot[c] = fmaf(gv[c], qv[c], dot[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float norm = sqrtf(ss[c]);
+                denom[c] = fmaxf(norm, 1e-12f);
+                kk[c] = (norm > 1e-12f) ? dot[c] / (denom[c] * denom[c] * norm) : 0.f;
+            }
+            for (int j = g; j < NJ; j += 4) {
+                const f32x4 qv = *(const f32x4*)(my_q + 4 * j);
+                const f32x4 gv = *(const f32x4*)(my_gn + 4 * j);
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float dq = gv[c] / denom[c] - qv[c] * kk[c];
+                    o[c] = (args.mode == MODE_PROJECT) ? __fsub_rn(qv[c], __fmul_rn(dval, dq)) : dq;
+                }
+                *(f32x4*)(my_q + 4 * j) = o;
+            }
+        }
+        __syncthreads();
+    }
+
+    {
+        long long pidx = pose0 + wp;
+        if (g == 0 && pidx < args.B && args.d_out) args.d_out[pidx] = dval;
+    }
+    if (args.mode != MODE_FORWARD) {
+        __syncthreads();
+        long long nvalid = args.B - pose0;
+        if (nvalid > WG_POSES) nvalid = WG_POSES;
+        f32x4* dst = (f32x4*)(args.q_out + pose0 * NQ);
+        const int nvec = (int)nvalid * (NQ / 4);
+        for (int i = tid; i < nvec; i += WG_THREADS) dst[i] = ((const f32x4*)lds_q)[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}

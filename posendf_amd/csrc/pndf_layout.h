@@ -76,6 +76,22 @@ static_assert(TRUNK_FWD_TILES == 5312 && TRUNK_BWD_TILES == 5312 && STEP_TILES =
 static_assert(ENC_TILES_PADDED % SLOT_TILES == 0 && ENC_TILES <= ENC_TILES_PADDED - SLOT_TILES / 2 + 2,
               "every ring event of the encoder's slots must fall on a tile that is actually read");
 
+// ---- split-precision stream (pndf_kernel_split.hip): every fp32 weight is carried as fp16 hi + fp16 lo and
+// every product block is three v_mfma_f32_16x16x32_f16 (hi*hi + hi*lo + lo*hi, fp32 accumulate; the dropped
+// lo*lo term is 2^-22 relative).  One MFMA contracts 32 k = TWO 16-row tiles of the previous layer, so the
+// unit is a "pair": 1 KiB hi tile + 1 KiB lo tile of one (16 rows x 32 k) block,
+//   block(M, nt, kb)[lane*8 + jj] = M[16 nt + (lane & 15)][16 (2 kb + (jj >> 2)) + 4 (lane >> 4) + (jj & 3)]
+// (the k order inside an MFMA is free as long as A and B agree; this one makes the B operand = the packed
+// registers of two consecutive C/D tiles).  Same tile count and slot structure as the fp32 stream; inside a
+// phase the order is software-pipelined:  A(0) | A(1) B(0) | A(2) B(1) | ... | B(NC-1)
+//   A(c): (kb, ci) pairs        B(c): (nb, b) pairs, b = k-block inside the chunk (CT / 2 of them)
+constexpr int phase_a_pairs(const Phase& p) { return (p.KA / 2) * p.CT; }
+constexpr int phase_b_pairs(const Phase& p) { return p.NB * (p.CT / 2); }
+static_assert(2 * (phase_a_pairs(PHASES[1]) + phase_b_pairs(PHASES[1])) == phase_chunk_tiles(PHASES[1]), "same tile count");
+static_assert(2 * (phase_a_pairs(PHASES[2]) + phase_b_pairs(PHASES[2])) == phase_chunk_tiles(PHASES[2]), "same tile count");
+
+enum Precision { PREC_FP32 = 0, PREC_F16X3 = 1 };
+
 // bias block (floats) copied to LDS: b0..b5, then w6 (64), then b6
 constexpr int BIAS_OFF[NLIN] = {0, 256, 768, 1792, 2304, 2560, 2688};
 constexpr int W6_OFF = 2624;

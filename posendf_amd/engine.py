@@ -15,11 +15,12 @@ import numpy as np
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libposendf_amd.so")
 
 ACT_CODES = {"relu": 0, "lrelu": 1, "softplus": 2}
+PRECISION_CODES = {"fp32": 0, "f16x3": 1}
 
 
 class PndfConfig(ctypes.Structure):
     _fields_ = [("act", c_int32), ("beta", c_float), ("num_joints", c_int32), ("n_dims", c_int32),
-                ("dims", c_int32 * 16), ("parent", c_int32 * 32)]
+                ("dims", c_int32 * 16), ("parent", c_int32 * 32), ("precision", c_int32)]
 
 
 class PndfError(RuntimeError):
@@ -49,11 +50,12 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.pndf_packed_sizes.argtypes = [POINTER(c_int64)] * 2
     lib.pndf_packed_sizes.restype = None
     lib.pndf_pack_host.argtypes = [POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p, c_void_p]
+    lib.pndf_pack_host_split.argtypes = [POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p, c_void_p]
     lib.pndf_last_error.argtypes = [H]
     lib.pndf_last_error.restype = c_char_p
     lib.pndf_version.restype = c_char_p
     for name in ("pndf_create", "pndf_destroy", "pndf_load_weights", "pndf_forward", "pndf_forward_grad",
-                 "pndf_project", "pndf_debug_forward_grad", "pndf_pack_host"):
+                 "pndf_project", "pndf_debug_forward_grad", "pndf_pack_host", "pndf_pack_host_split"):
         getattr(lib, name).restype = c_int
     return lib
 
@@ -61,7 +63,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
 EXPORTS = ("pndf_default_config", "pndf_create", "pndf_destroy", "pndf_load_weights", "pndf_forward",
            "pndf_forward_grad", "pndf_project", "pndf_debug_forward_grad", "pndf_debug_floats",
            "pndf_debug_project_timing", "pndf_debug_timing_regions",
-           "pndf_packed_sizes", "pndf_pack_host", "pndf_last_error", "pndf_version")
+           "pndf_packed_sizes", "pndf_pack_host", "pndf_pack_host_split", "pndf_last_error", "pndf_version")
 
 
 def state_dict_order():
@@ -78,15 +80,17 @@ def _tensor_table(sd_np):
     return arrs, ptrs, numel
 
 
-def pack_host(sd_np, lib=None):
-    """Host-only packing (no device): returns (stream[STEP_TILES*256], bias) float32 arrays."""
+def pack_host(sd_np, lib=None, split=False):
+    """Host-only packing (no device): returns (stream[STEP_TILES*256], bias) float32 arrays; split=True gives
+    the split-precision stream (trunk tiles = fp16 hi/lo pairs, view them with .view(np.float16))."""
     lib = lib or load_library()
     n = [c_int64(), c_int64()]
     lib.pndf_packed_sizes(*[ctypes.byref(x) for x in n])
     stream = np.empty(n[0].value, np.float32)
     bias = np.empty(n[1].value, np.float32)
     arrs, ptrs, numel = _tensor_table(sd_np)
-    rc = lib.pndf_pack_host(ptrs, numel, len(arrs), stream.ctypes.data, bias.ctypes.data)
+    fn = lib.pndf_pack_host_split if split else lib.pndf_pack_host
+    rc = fn(ptrs, numel, len(arrs), stream.ctypes.data, bias.ctypes.data)
     if rc != 0:
         raise PndfError(f"pndf_pack_host failed ({rc})")
     return stream, bias
@@ -95,12 +99,16 @@ def pack_host(sd_np, lib=None):
 class Engine:
     """One engine per device.  All compute methods take raw device pointers and a stream handle."""
 
-    def __init__(self, act: str = "lrelu", beta: float = 100.0, device: int = 0, lib=None):
+    def __init__(self, act: str = "lrelu", beta: float = 100.0, device: int = 0, lib=None, precision: str = "fp32"):
         self.lib = lib or load_library()
         if act not in ACT_CODES:
             raise PndfError(f"unknown activation {act!r}")
+        if precision not in PRECISION_CODES:
+            raise PndfError(f"unknown precision {precision!r} (fp32, f16x3)")
         cfg = PndfConfig()
         self.lib.pndf_default_config(ctypes.byref(cfg), ACT_CODES[act], float(beta))
+        cfg.precision = PRECISION_CODES[precision]
+        self.precision = precision
         self.handle = c_void_p()
         rc = self.lib.pndf_create(ctypes.byref(self.handle), ctypes.byref(cfg), int(device))
         if rc != 0:

@@ -11,6 +11,8 @@ gfx950 device, train=False raises.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 from torch.autograd.function import once_differentiable
@@ -69,6 +71,9 @@ class PoseNDF(nn.Module):
             self.loss_l1 = nn.L1Loss()
         elif self.loss == "l2":
             self.loss_l1 = nn.MSELoss()
+        # engine knob (no reference counterpart): arithmetic of the trunk, "fp32" (exact) or "f16x3" (fp16 hi/lo
+        # split, fp32 accumulate, fp32-class accuracy); opt["engine"]["precision"] or $PNDF_PRECISION
+        self._precision = (opt.get("engine") or {}).get("precision") or os.environ.get("PNDF_PRECISION", "fp32")
         self._act = opt["model"]["DFNet"]["act"]
         self._beta = float(opt["model"]["DFNet"].get("beta", 100.0))
         if self.enc is not None and opt["model"]["StrEnc"]["act"] != self._act:
@@ -93,7 +98,8 @@ class PoseNDF(nn.Module):
         fp = self._fingerprint()
         entry = self._engines.get(idx)
         if entry is None:
-            entry = [Engine(self._act, self._beta, idx), None]
+            prec = "fp32" if self._act == "softplus" else self._precision     # softplus runs in fp32 only
+            entry = [Engine(self._act, self._beta, idx, precision=prec), None]
             self._engines[idx] = entry
         if entry[1] != fp:          # first use, load_state_dict, optimiser step, .to(): re-pack the weights
             sd = self.state_dict()

@@ -230,3 +230,129 @@ def trunk_wave(feat16, stream, bias, slope):
     run_phase(5, g2, g0, st, None, masks, slope, True)
     assert st.pos == st.t.shape[0] - ENC_PAD, (st.pos, st.t.shape)
     return d[:16], decode(g0), stages
+
+
+# ====================================================================== split-precision trunk (f16 x 3)
+def mfma_f16_16x16x32(a, b, c):
+    """a, b: [64, 8] fp16 (A[i = lane & 15][k = 8 (lane >> 4) + jj], B[k][j = lane & 15]); c: [64,4] fp32.
+    Products of fp16 values are exact in fp32; the sum is modelled in fp64 and rounded once per MFMA."""
+    A = np.zeros((16, 32), np.float64)
+    B = np.zeros((32, 16), np.float64)
+    for jj in range(8):
+        A[P, 8 * G + jj] = a[:, jj].astype(np.float64)
+        B[8 * G + jj, P] = b[:, jj].astype(np.float64)
+    D = A @ B
+    out = c.astype(np.float64)
+    for r in range(4):
+        out[:, r] += D[4 * G + r, P]
+    return out.astype(np.float32)
+
+
+def split16(x):
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    return hi, lo
+
+
+def pack_blocks(tiles):
+    """fp32 C/D-layout tiles -> list of (hi, lo) [64,8] fp16 B operands, one per pair of tiles."""
+    out = []
+    for b in range(len(tiles) // 2):
+        x = np.concatenate([tiles[2 * b], tiles[2 * b + 1]], axis=1)      # [64, 8]
+        out.append(split16(x))
+    return out
+
+
+class PairStream:
+    def __init__(self, stream_f32, tile_pos):
+        self.t = stream_f32.reshape(-1, 256)
+        self.pos = tile_pos
+
+    def pair(self):
+        hi = self.t[self.pos].view(np.float16).reshape(64, 8)
+        lo = self.t[self.pos + 1].view(np.float16).reshape(64, 8)
+        self.pos += 2
+        return hi, lo
+
+
+def _mm3(w, x, c):
+    (wh, wl), (xh, xl) = w, x
+    c = mfma_f16_16x16x32(wh, xh, c)
+    c = mfma_f16_16x16x32(wh, xl, c)
+    c = mfma_f16_16x16x32(wl, xh, c)
+    return c
+
+
+def run_phase_split(ph, xin, acc, st, bias_a, masks, slope, bwd):
+    """xin: list of (hi, lo) blocks; acc: list of fp32 tiles.  Stream order A(0) | A(c+1) B(c) ... (pndf_layout.h)."""
+    KA, CT, NC, NB = PHASES[ph]
+
+    def part_a(c):
+        ch = [np.zeros((64, 4), np.float32) for _ in range(CT)]
+        if not bwd:
+            for ci in range(CT):
+                ch[ci] = _tile_bias(bias_a, 16 * (c * CT + ci))
+        for kb in range(KA // 2):
+            for ci in range(CT):
+                ch[ci] = _mm3(st.pair(), xin[kb], ch[ci])
+        if not bwd:
+            m = [t > 0 for t in ch]
+            masks[(ph, c)] = m
+        else:
+            m = masks[({3: 2, 4: 1, 5: 0}[ph], c)]
+        ch = [np.where(mm, t, t * np.float32(slope)) for t, mm in zip(ch, m)]
+        return pack_blocks(ch)
+
+    chb = part_a(0)
+    for c in range(NC):
+        nxt = part_a(c + 1) if c + 1 < NC else None
+        for nb in range(NB):
+            for b in range(CT // 2):
+                acc[nb] = _mm3(st.pair(), chb[b], acc[nb])
+        chb = nxt
+
+
+def trunk_wave_split(feat16, stream, bias, slope):
+    f = np.zeros((16, 128), np.float32)
+    f[:, :126] = feat16
+    x0 = []
+    for kt in range(8):
+        x = np.zeros((64, 4), np.float32)
+        for s in range(4):
+            x[:, s] = f[P, 16 * kt + 4 * G + s]
+        x0.append(x)
+    st, masks, stages = PairStream(stream, ENC_PAD), {}, {}
+    x2 = load_bias(bias, BIAS_OFF[1], 32)
+    run_phase_split(0, pack_blocks(x0), x2, st, bias[BIAS_OFF[0]:], masks, slope, False)
+    x2, m2 = act_tiles(x2, slope)
+    stages["x2"] = decode(x2)
+    x4 = load_bias(bias, BIAS_OFF[3], 32)
+    run_phase_split(1, pack_blocks(x2), x4, st, bias[BIAS_OFF[2]:], masks, slope, False)
+    x4, m4 = act_tiles(x4, slope)
+    stages["x4"] = decode(x4)
+    x6 = load_bias(bias, BIAS_OFF[5], 4)
+    run_phase_split(2, pack_blocks(x4), x6, st, bias[BIAS_OFF[4]:], masks, slope, False)
+    x6, m6 = act_tiles(x6, slope)
+    stages["x6"] = decode(x6)
+    w6 = load_bias(bias, W6_OFF, 4)
+    part = np.zeros(64, np.float32)
+    for t in range(4):
+        for r in range(4):
+            part += w6[t][:, r] * x6[t][:, r]
+    tot = np.zeros(64, np.float32)
+    for l in range(64):
+        tot[l] = part[[(l & 15) + 16 * g for g in range(4)]].sum()
+    z7 = tot + bias[BIAS_OFF[6]]
+    d = np.maximum(z7, 0)
+    gz7 = (z7 > 0).astype(np.float32)
+    g6 = dact_tiles([w6[t] * gz7[:, None] for t in range(4)], m6, slope)
+    g4 = [np.zeros((64, 4), np.float32) for _ in range(32)]
+    run_phase_split(3, pack_blocks(g6), g4, st, None, masks, slope, True)
+    g4 = dact_tiles(g4, m4, slope)
+    g2 = [np.zeros((64, 4), np.float32) for _ in range(32)]
+    run_phase_split(4, pack_blocks(g4), g2, st, None, masks, slope, True)
+    g2 = dact_tiles(g2, m2, slope)
+    g0 = [np.zeros((64, 4), np.float32) for _ in range(8)]
+    run_phase_split(5, pack_blocks(g2), g0, st, None, masks, slope, True)
+    assert st.pos == st.t.shape[0] - ENC_PAD, (st.pos, st.t.shape)
+    return d[:16], decode(g0), stages

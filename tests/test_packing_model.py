@@ -72,3 +72,26 @@ def test_packed_blocks_layout():
     tot = sum(float((sd[f"dfnet.lin{l}.weight"].astype(np.float64) ** 2).sum()) for l in range(6))
     tot += sum(float((sd[f"enc.net.{j}.net.{k}.weight"].astype(np.float64) ** 2).sum()) for j in range(21) for k in (0, 2))
     assert abs(float((stream.astype(np.float64) ** 2).sum()) - 2 * tot) < 1e-6 * tot
+
+
+def test_split_precision_lane_model():
+    """f16 x 3 trunk (pndf_kernel_split.hip) modelled at lane level with the real split packer: checks the block
+    permutation, the software-pipelined stream order and -- the point of the scheme -- that three fp16 MFMAs
+    per product block keep fp32-class accuracy (vs the fp64 oracle, next to the fp32 oracle's own error)."""
+    from posendf_amd import engine, synth
+    import lane_model as lm
+    sd = golden_weights("mixed")
+    stream, bias = engine.pack_host(sd, split=True)
+    q = synth.make_poses(16, seed=7, signed=True)
+    dbg, dbg64 = {}, {}
+    d32, _ = onp.forward_grad(q, sd, "lrelu", debug=dbg)
+    d64, _ = onp.forward_grad(q, sd, "lrelu", dtype=np.float64, debug=dbg64)
+    d_m, gx0_m, stages = lm.trunk_wave_split(dbg["feat"], stream, bias, 0.01)
+    assert rel_err(stages["x4"], onp._act(dbg64["zs"][3], "lrelu", 100.0)) < 2e-5
+    e_split = d_err(d_m, d64[:, 0])
+    e_fp32 = d_err(d32[:, 0], d64[:, 0])
+    assert e_split < 5e-5, (e_split, e_fp32)
+    g_split = rel_err(gx0_m[:, :126], dbg64["gx"][0])
+    g_fp32 = rel_err(dbg["gx"][0], dbg64["gx"][0])
+    assert g_split < 5e-5, (g_split, g_fp32)
+    print("split vs fp64: d", e_split, "gx0", g_split, "| fp32 oracle vs fp64: d", e_fp32, "gx0", g_fp32)
