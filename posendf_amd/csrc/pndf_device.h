@@ -20,16 +20,17 @@ constexpr int SLOT_BYTES = SLOT_TILES * TILE_BYTES;          // 16 KiB
 // constant LDS addresses above 64 KiB would each be materialised in an SGPR, hoisted out of the step loop
 // and spilled.  The DMA ring sits at the bottom so that its M0 base stays below 64 KiB.
 constexpr int FSTRIDE = 132;                                 // floats per pose in the feature buffer (bank skew)
-constexpr int RING_SLOTS = 3;
-constexpr int LDS_RING = 0;                                  // 3 slots of 16 KiB (DMA target, lowest addresses)
+constexpr int RING_SLOTS = 5;
+constexpr int MASK_ROWS = 48;                                // u8 [48][256]: x1 8 chunks, x3 32 chunks, x5 4 chunks x 2 bytes
+constexpr int LDS_RING = 0;                                  // 5 slots of 16 KiB (DMA target, lowest addresses)
 constexpr int LDS_BIAS = LDS_RING + RING_SLOTS * SLOT_BYTES; // BIAS_FLOATS floats (trunk + encoder biases)
-constexpr int LDS_MASK = LDS_BIAS + BIAS_FLOATS * 4;         // u16 [MASK_CHUNKS][256]; aliased by GN after the trunk
-constexpr int LDS_GN = LDS_MASK;                             // float [64][84]  d d / d n per pose
-constexpr int LDS_Q = LDS_MASK + MASK_CHUNKS * WG_THREADS * 2;   // float [64][84]  the pose tile
-constexpr int LDS_F = LDS_Q + WG_POSES * NQ * 4;             // float [64][FSTRIDE]  features, then d d / d feature
+constexpr int LDS_MASK = LDS_BIAS + BIAS_FLOATS * 4;         // chunk-layer sign bits
+constexpr int LDS_Q = LDS_MASK + MASK_ROWS * WG_THREADS;     // float [64][84]  the pose tile
+constexpr int LDS_F = LDS_Q + WG_POSES * NQ * 4;             // float [64][FSTRIDE]  features, then d d / d feature,
+constexpr int LDS_GN = LDS_F;                                //   then (same rows) d d / d n of the pose
 constexpr int LDS_TOTAL = LDS_F + WG_POSES * FSTRIDE * 4;
 static_assert(LDS_BIAS % 16 == 0 && LDS_MASK % 16 == 0 && LDS_Q % 16 == 0 && LDS_F % 16 == 0, "16-byte LDS carve");
-static_assert(WG_POSES * NQ * 4 <= MASK_CHUNKS * WG_THREADS * 2, "GN aliases the chunk-mask region");
+static_assert(NQ <= FSTRIDE, "GN aliases the feature rows");
 static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
 
 enum { MODE_FORWARD = 0, MODE_FORWARD_GRAD = 1, MODE_PROJECT = 2 };
@@ -41,10 +42,13 @@ enum {
     DBG_DQ = DBG_GN + 84, DBG_TOTAL = DBG_DQ + 84
 };
 
-// Weight ring: 3 slots of 16 tiles.  Slot i lives in buffer i % 3.  The one barrier per slot sits in the
-// MIDDLE of the slot being consumed (tile 8): at that point every wave has left slot i-1, so its buffer
-// can take the DMA of slot i+2, and the DMA of slot i+1 (issued one slot earlier) has landed for everybody.
-// Crossing a slot boundary therefore needs no synchronisation and tile prefetch runs straight through.
+// Weight ring: RING_SLOTS (5) slots of 16 tiles; slot i lives in buffer i % 5 and is fetched FOUR slots ahead.
+// The one barrier per slot sits in the MIDDLE of the slot being consumed (tile 8): every wave has then left
+// slot i-1, so its buffer can take the DMA of slot i+4; before the barrier each wave waits with a COUNTED
+// vmcnt until its share of slot i+1 has landed (the DMAs of slots i+2, i+3 stay in flight).  Crossing a slot
+// boundary needs no synchronisation and tile prefetch runs straight through.  Depth matters for the
+// split-precision kernel, which consumes a slot in ~300 cycles: with 3 slots the latency budget of a DMA was
+// one slot time and every L2 miss of the weight stream (3 %, i.e. almost every slot) stalled all four waves.
 struct Ring {
     const char* gstream;   // packed weight stream (global)
     char* smem;
@@ -95,16 +99,21 @@ __device__ __forceinline__ void ring_dma(Ring& r, int buf) {
 }
 
 __device__ __forceinline__ void ring_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// at most two slot fetches (4 pieces each) of this wave may still be in flight
+__device__ __forceinline__ void ring_wait_next_slot() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 
 __device__ __forceinline__ void ring_start(Ring& r) {
     r.next = 0;
-    ring_dma(r, 0);
-    ring_dma(r, 1);
-    r.cur = 2;             // the first slot boundary makes it 0
+#pragma unroll
+    for (int b = 0; b < RING_SLOTS - 1; ++b) ring_dma(r, b);     // slots 0..3; the caller waits vmcnt(0) + barrier
+    r.cur = RING_SLOTS - 1;                                      // the first slot boundary makes it 0
 }
 
+// buffer that takes the slot fetched at the mid-slot point of the current slot (= buffer of the previous slot)
+__device__ __forceinline__ int ring_fill_buffer(const Ring& r) { return (r.cur == 0) ? RING_SLOTS - 1 : r.cur - 1; }
+
 // tile 0 of a slot: switch buffers (no barrier needed, see above)
-__device__ __forceinline__ void ring_boundary(Ring& r) { r.cur = (r.cur == 2) ? 0 : r.cur + 1; }
+__device__ __forceinline__ void ring_boundary(Ring& r) { r.cur = (r.cur == RING_SLOTS - 1) ? 0 : r.cur + 1; }
 
 // tile 8 of a slot: one barrier, then prefetch two slots ahead into the buffer of the previous slot
 // A raw s_barrier, not __syncthreads(): the latter's fence adds `s_waitcnt lgkmcnt(0)`, i.e. it waits for the
@@ -112,7 +121,7 @@ __device__ __forceinline__ void ring_boundary(Ring& r) { r.cur = (r.cur == 2) ? 
 // wave's DMA share of the next slot has landed (its own vmcnt(0) above), and every read of the previous slot
 // returned long ago (its data has been consumed by MFMAs issued before this point).
 __device__ __forceinline__ void ring_midslot_sync(Ring& r) {
-    ring_wait_dma();
+    ring_wait_next_slot();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
@@ -129,6 +138,22 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// chunk-layer sign bits: one byte per lane per 8 bits; a CT = 4 chunk (16 bits) uses two consecutive rows
+template <int CT>
+__device__ __forceinline__ void store_chunk_bits(uint8_t* mask, int c, uint32_t bits) {
+    if constexpr (CT == 2) {
+        mask[c * WG_THREADS] = (uint8_t)bits;
+    } else {
+        mask[(2 * c) * WG_THREADS] = (uint8_t)bits;
+        mask[(2 * c + 1) * WG_THREADS] = (uint8_t)(bits >> 8);
+    }
+}
+template <int CT>
+__device__ __forceinline__ uint32_t load_chunk_bits(const uint8_t* mask, int c) {
+    if constexpr (CT == 2) return mask[c * WG_THREADS];
+    else return (uint32_t)mask[(2 * c) * WG_THREADS] | ((uint32_t)mask[(2 * c + 1) * WG_THREADS] << 8);
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -227,7 +252,7 @@ __device__ __forceinline__ f32x4 enc_tile(Ring& ring) {
     if (t == 0) ring_boundary(ring);
     if (t == SLOT_TILES / 2) {
         ring_midslot_sync(ring);
-        ring_dma(ring, (ring.cur == 0) ? 2 : ring.cur - 1);
+        ring_dma(ring, ring_fill_buffer(ring));
     }
     return ring_tile(ring, t);
 }

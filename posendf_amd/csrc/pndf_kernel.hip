@@ -31,7 +31,7 @@ struct PhaseBody {
     // (or garbage after the very last group) on exit.
     template <int GI>
     static __device__ __forceinline__ void groups(const f32x4 (&xin)[KA], f32x4 (&acc)[NB], f32x4 (&ch)[CT],
-                                                  f32x4 (&cur)[GT], Ring& ring, uint16_t* mask, const ActP& ap,
+                                                  f32x4 (&cur)[GT], Ring& ring, uint8_t* mask, const ActP& ap,
                                                   int spslot, int c, RegionClock* rc) {
         if constexpr (GI < NG) {
             f32x4 nxt[GT];
@@ -44,7 +44,7 @@ struct PhaseBody {
             // MFMA pipe, behind an MFMA they are free)
             const char* dsrc = nullptr;
             uint32_t ddst = 0;
-            if (MID && loaded) ring_dma_begin(ring, (ring.cur == 0) ? 2 : ring.cur - 1, dsrc, ddst);
+            if (MID && loaded) ring_dma_begin(ring, ring_fill_buffer(ring), dsrc, ddst);
             int piece = 0;
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE this group's MFMAs
             if constexpr (GI < NGA) {
@@ -95,9 +95,9 @@ struct PhaseBody {
                                 bitsum = fmaf(st, (float)(1u << (ci * 4 + r)), bitsum);
                             }
                         }
-                        mask[c * WG_THREADS] = (uint16_t)(uint32_t)bitsum;
+                        store_chunk_bits<CT>(mask, c, (uint32_t)bitsum);
                     } else {
-                        const uint32_t bits = mask[c * WG_THREADS];
+                        const uint32_t bits = load_chunk_bits<CT>(mask, c);
 #pragma unroll
                         for (int ci = 0; ci < CT; ++ci) {
 #pragma unroll
@@ -139,7 +139,7 @@ struct PhaseBody {
 
 template <int KA, int CT, int NC, int NB, bool BWD, bool SP, bool GTIME = false>
 __device__ __forceinline__ void run_phase(const f32x4 (&xin)[KA], f32x4 (&acc)[NB], Ring& ring,
-                                          const float* biasA, uint16_t* mask, const ActP& ap, int spslot, int g,
+                                          const float* biasA, uint8_t* mask, const ActP& ap, int spslot, int g,
                                           RegionClock* rc = nullptr) {
     using Body = PhaseBody<KA, CT, NC, NB, BWD, SP, GTIME>;
     f32x4 cur[Body::GT];
@@ -228,11 +228,11 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     ap.sp = SP ? (f32x4*)wg_scratch + tid : nullptr;
     const long long pose0 = (long long)blockIdx.x * WG_POSES;
     float* const lds_bias = (float*)(smem + LDS_BIAS);
-    uint16_t* const lds_mask = (uint16_t*)(smem + LDS_MASK) + tid;
+    uint8_t* const lds_mask = (uint8_t*)(smem + LDS_MASK) + tid;
     float* const lds_q = (float*)(smem + LDS_Q);
     float* const my_q = lds_q + wp * NQ;
     float* const my_f = (float*)(smem + LDS_F) + wp * FSTRIDE;
-    float* const my_gn = (float*)(smem + LDS_GN) + wp * NQ;
+    float* const my_gn = (float*)(smem + LDS_GN) + wp * FSTRIDE;   // aliases the feature row of the pose
     float* const dbg = (DBG && blockIdx.x == 0) ? args.dbg : nullptr;
 
     Ring ring;

@@ -71,7 +71,7 @@ template <int T0>
 __device__ __forceinline__ void dma_begin(DmaPieces& d, Ring& ring, bool loaded) {
     d.n = 4;
     if (group_has_mid<8, T0>() && loaded) {
-        ring_dma_begin(ring, (ring.cur == 0) ? 2 : ring.cur - 1, d.src, d.dst);
+        ring_dma_begin(ring, ring_fill_buffer(ring), d.src, d.dst);
         d.n = 0;
     }
 }
@@ -123,7 +123,7 @@ struct SplitPhase {
     }
 
     // ---- chunk epilogue: sum the three partials, (forward) bias is already in ch[0], activation or mask, split
-    static __device__ __forceinline__ void epilogue(f32x4 (&ch)[3][CT], Blk (&out)[CB], uint16_t* mask, int c, float slope) {
+    static __device__ __forceinline__ void epilogue(f32x4 (&ch)[3][CT], Blk (&out)[CB], uint8_t* mask, int c, float slope) {
         f32x4 y[CT];
         if (!BWD) {
             float bitsum = 0.f;
@@ -137,9 +137,9 @@ struct SplitPhase {
                     bitsum = fmaf(st, (float)(1u << (ci * 4 + r)), bitsum);
                 }
             }
-            mask[c * WG_THREADS] = (uint16_t)(uint32_t)bitsum;
+            store_chunk_bits<CT>(mask, c, (uint32_t)bitsum);
         } else {
-            const uint32_t bits = mask[c * WG_THREADS];
+            const uint32_t bits = load_chunk_bits<CT>(mask, c);
 #pragma unroll
             for (int ci = 0; ci < CT; ++ci) {
 #pragma unroll
@@ -167,7 +167,7 @@ struct SplitPhase {
     // interleaved with these MFMAs by the compiler instead of stalling the pipe.
     template <int GB>
     static __device__ __forceinline__ void part_b(const Blk (&chb)[CB], f32x4 (&acc)[NB], Pair (&cur)[4], Ring& ring,
-                                                  bool more, f32x4 (&chn)[3][CT], Blk (&nextb)[CB], uint16_t* mask,
+                                                  bool more, f32x4 (&chn)[3][CT], Blk (&nextb)[CB], uint8_t* mask,
                                                   int c, float slope) {
         if constexpr (GB < BG) {
             Pair nxt[4];
@@ -199,7 +199,7 @@ struct SplitPhase {
     }
 
     static __device__ __forceinline__ void run(const Blk (&xin)[KA2], f32x4 (&acc)[NB], Ring& ring, const float* biasA,
-                                               uint16_t* mask, float slope, int g) {
+                                               uint8_t* mask, float slope, int g) {
         Pair cur[4];
         load_pairs<0>(cur, ring);
         f32x4 ch[3][CT];
@@ -275,16 +275,17 @@ extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_rel
     const float slope = args.slope;
     const long long pose0 = (long long)blockIdx.x * WG_POSES;
     float* const lds_bias = (float*)(smem + LDS_BIAS);
-    uint16_t* const lds_mask = (uint16_t*)(smem + LDS_MASK) + tid;
+    uint8_t* const lds_mask = (uint8_t*)(smem + LDS_MASK) + tid;
     float* const lds_q = (float*)(smem + LDS_Q);
     float* const my_q = lds_q + wp * NQ;
     float* const my_f = (float*)(smem + LDS_F) + wp * FSTRIDE;
-    float* const my_gn = (float*)(smem + LDS_GN) + wp * NQ;
+    float* const my_gn = (float*)(smem + LDS_GN) + wp * FSTRIDE;   // aliases the feature row of the pose
 
     Ring ring;
     ring.gstream = args.stream;
     ring.smem = smem;
     ring.nslots = (args.mode == MODE_FORWARD) ? FWD_SLOTS : STEP_SLOTS;
+    if (args.dbg_nslots > 0) ring.nslots = args.dbg_nslots;
     ring.wave = wave;
     ring.lane = lane;
     ring_start(ring);

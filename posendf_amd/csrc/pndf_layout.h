@@ -102,9 +102,8 @@ constexpr int PARENT[NJ] = {-1, -1, -1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13,
 constexpr int enc_in(int j) { return PARENT[j] < 0 ? 4 : 10; }
 constexpr int ENC_FEAT_ROW = 4;     // features live on rows 4..9 of the joint's output tile
 
-// chunk-mask slots (one u16 per lane per chunk) for the three chunked layers x1, x3, x5
+// chunk-mask rows (one byte per lane per row) for the three chunked layers x1 (8 chunks), x3 (32), x5 (4 x 2 rows)
 constexpr int MASK_BASE[3] = {0, 8, 40};
-constexpr int MASK_CHUNKS = 44;
 
 enum Act { ACT_RELU = 0, ACT_LRELU = 1, ACT_SOFTPLUS = 2 };
 
