@@ -33,6 +33,7 @@ struct PndfKernelArgs {
 extern "C" __global__ void pndf_fused_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_softplus_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_split_relu_kernel(PndfKernelArgs args);
+extern "C" __global__ void pndf_fused_split_relu_kernel_timing(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_relu_kernel_timing(PndfKernelArgs args);
 extern "C" int pndf_kernel_timing_regions();
 extern "C" long long pndf_kernel_softplus_scratch_floats_per_wg();
@@ -124,6 +125,8 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
         e = hipFuncSetAttribute((const void*)pndf_fused_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_split_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)pndf_fused_split_relu_kernel_timing, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_softplus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
@@ -368,8 +371,9 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
         return PNDF_OK;
     }
     const bool split = h->cfg.precision == PNDF_PREC_F16X3;
-    if (split && (timing || dbg)) return fail(h, PNDF_ERR_UNSUPPORTED, "debug / timing kernels exist for fp32 precision only");
-    if (split) hipLaunchKernelGGL(pndf_fused_split_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+    if (split && dbg && !timing) return fail(h, PNDF_ERR_UNSUPPORTED, "the stage-dump kernel exists for fp32 precision only");
+    if (split && timing) hipLaunchKernelGGL(pndf_fused_split_relu_kernel_timing, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+    else if (split) hipLaunchKernelGGL(pndf_fused_split_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else if (timing) hipLaunchKernelGGL(pndf_fused_relu_kernel_timing, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else if (dbg) hipLaunchKernelGGL(pndf_fused_relu_kernel_dbg, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else hipLaunchKernelGGL(pndf_fused_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);

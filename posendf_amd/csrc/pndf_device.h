@@ -64,22 +64,20 @@ struct Ring {
 // degrades every `s_waitcnt lgkmcnt(N)` of the tile prefetch to lgkmcnt(0), which serialises ds_read and
 // MFMA.  Consequence (cdna_hip_programming.md 5.7): the compiler does not count these loads, so every
 // consumer-side barrier is preceded by an explicit `s_waitcnt vmcnt(0)`.
-// One 1-KiB piece (tile 4*wave + j of the slot).  M0 is written in the same statement that uses it
-// (cdna_hip_programming.md 5.7: M0 is compiler-owned outside the statement).
-__device__ __forceinline__ void ring_dma_piece(const char* src, uint32_t dst, int j) {
-    uint32_t keep;
+// One 1-KiB piece (tile 4*wave + j of the slot).  Piece 0 saves M0 and points it at the wave's LDS window,
+// piece 3 restores it; pieces 1..3 reuse it (the instruction offset moves both the global and the LDS address).
+// Between the pieces only MFMAs, ds_reads and waits are issued -- none of them touches M0 on gfx950 -- and
+// with one wave per SIMD every SALU instruction saved here is ~4 issue cycles of the critical path.
+__device__ __forceinline__ void ring_dma_piece(const char* src, uint32_t dst, int j, uint32_t& keep) {
     if (j == 0)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                      : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     else if (j == 1)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        asm volatile("global_load_lds_dwordx4 %0, off offset:1024" : : "v"(src) : "memory");
     else if (j == 2)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        asm volatile("global_load_lds_dwordx4 %0, off offset:2048" : : "v"(src) : "memory");
     else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        asm volatile("global_load_lds_dwordx4 %0, off offset:3072\n\ts_mov_b32 m0, %1" : : "v"(src), "s"(keep) : "memory");
 }
 
 // source / destination of this wave's share of the next slot to fetch; advances r.next
@@ -94,8 +92,9 @@ __device__ __forceinline__ void ring_dma(Ring& r, int buf) {
     const char* src;
     uint32_t dst;
     ring_dma_begin(r, buf, src, dst);
+    uint32_t keep = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ring_dma_piece(src, dst, j);
+    for (int j = 0; j < 4; ++j) ring_dma_piece(src, dst, j, keep);
 }
 
 __device__ __forceinline__ void ring_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -65,6 +65,7 @@ __device__ __forceinline__ void load_pairs(Pair (&a)[4], Ring& ring) {
 struct DmaPieces {     // the slot fetch that follows a mid-slot barrier, issued piecewise between MFMAs
     const char* src;
     uint32_t dst;
+    uint32_t keep;
     int n;
 };
 template <int T0>
@@ -78,7 +79,8 @@ __device__ __forceinline__ void dma_begin(DmaPieces& d, Ring& ring, bool loaded)
 __device__ __forceinline__ void dma_step(DmaPieces& d) {
     if (d.n < 4) {
         __builtin_amdgcn_sched_barrier(0);
-        ring_dma_piece(d.src, d.dst, d.n++);
+        ring_dma_piece(d.src, d.dst, d.n, d.keep);
+        d.n++;
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -102,6 +104,9 @@ struct SplitPhase {
             load_pairs<TN>(nxt, ring);                 // part B follows, so there is always a next group
             DmaPieces dp;
             dma_begin<TN>(dp, ring, true);
+            // one wait for the whole current group (the 8 reads just issued may stay in flight) instead of the
+            // compiler's per-MFMA lgkmcnt ladder: with one wave per SIMD every instruction is ~4 issue cycles
+            __builtin_amdgcn_s_waitcnt(0xC87F);        // lgkmcnt(8)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int term = 0; term < 3; ++term) {
@@ -176,6 +181,8 @@ struct SplitPhase {
             if (loaded) load_pairs<TN>(nxt, ring);
             DmaPieces dp;
             dma_begin<TN>(dp, ring, loaded);
+            if (loaded) __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8)
+            else __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int term = 0; term < 3; ++term) {
@@ -260,7 +267,8 @@ __device__ __forceinline__ void dact_split_tiles(f32x4 (&gx)[NT], Blk (&out)[NT 
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_relu_kernel(PndfKernelArgs args) {
+template <bool TIMING>
+__device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -307,6 +315,14 @@ extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_rel
 
     const int nsteps = (args.mode == MODE_PROJECT) ? args.steps : 1;
     float dval = 0.f;
+    RegionClock rc;
+    if constexpr (TIMING) {
+#pragma unroll
+        for (int i = 0; i < TIMING_REGIONS; ++i) rc.acc[i] = 0;
+#pragma unroll
+        for (int i = 0; i < TIMING_GROUPS; ++i) rc.grp[i] = 0;
+        rc.last = __builtin_amdgcn_s_memtime();
+    }
     for (int step = 0; step < nsteps; ++step) {
         uint32_t eb[6];
         uint32_t m2[4], m4[4], m6[1];
@@ -320,18 +336,24 @@ extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_rel
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
                     pack_blk(*(const f32x4*)(my_f + 32 * kb + 4 * g), *(const f32x4*)(my_f + 32 * kb + 16 + 4 * g), b0[kb]);
+                tick<TIMING>(rc, 0);
                 f32x4 x2[32];
                 load_bias<32>(x2, lds_bias + BIAS_OFF[1], g);
                 SplitPhase<4, 2, 8, 32, false>::run(b0, x2, ring, lds_bias + BIAS_OFF[0], lds_mask + MASK_BASE[0] * WG_THREADS, slope, g);
+                tick<TIMING>(rc, 1);
                 act_split_tiles<32>(x2, b2, m2, slope);
+                tick<TIMING>(rc, 2);
             }
             f32x4 x4[32];
             load_bias<32>(x4, lds_bias + BIAS_OFF[3], g);
             SplitPhase<16, 2, 32, 32, false>::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, slope, g);
+            tick<TIMING>(rc, 3);
             act_split_tiles<32>(x4, b4, m4, slope);
+            tick<TIMING>(rc, 4);
         }
         load_bias<4>(x6, lds_bias + BIAS_OFF[5], g);
         SplitPhase<16, 4, 4, 4, false>::run(b4, x6, ring, lds_bias + BIAS_OFF[4], lds_mask + MASK_BASE[2] * WG_THREADS, slope, g);
+        tick<TIMING>(rc, 5);
         Blk b6[2];
         act_split_tiles<4>(x6, b6, m6, slope);      // b6 unused forward; x6 (fp32) feeds lin6
 
@@ -369,17 +391,20 @@ extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_rel
                         for (int t = 0; t < 4; ++t) g6[t] = w6[t] * gz7;
                         Blk gb6[2];
                         dact_split_tiles<4>(g6, gb6, m6, slope);
+                        tick<TIMING>(rc, 6);
                         f32x4 g4[32];
 #pragma unroll
                         for (int t = 0; t < 32; ++t) g4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                         SplitPhase<2, 4, 4, 32, true>::run(gb6, g4, ring, nullptr, lds_mask + MASK_BASE[2] * WG_THREADS, slope, g);
                         dact_split_tiles<32>(g4, gb4, m4, slope);
+                        tick<TIMING>(rc, 7);
                     }
                     f32x4 g2[32];
 #pragma unroll
                     for (int t = 0; t < 32; ++t) g2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                     SplitPhase<16, 2, 32, 32, true>::run(gb4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, slope, g);
                     dact_split_tiles<32>(g2, gb2, m2, slope);
+                    tick<TIMING>(rc, 8);
                 }
 #pragma unroll
                 for (int t = 0; t < 8; ++t) g0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -390,8 +415,10 @@ extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_rel
         }
         __syncthreads();
 
+        tick<TIMING>(rc, 9);
         // ---------------- encoder backward + normalise backward + update (fp32, as pndf_kernel.hip)
         encoder_backward<false>(my_f, my_gn, eb, ring, ap, g);
+        tick<TIMING>(rc, 10);
         {
             float ss[4], dot[4], denom[4], kk[4];
             ss[0] = ss[1] = ss[2] = ss[3] = 0.f;
@@ -425,6 +452,16 @@ extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_rel
             }
         }
         __syncthreads();
+        tick<TIMING>(rc, 11);
+    }
+    if constexpr (TIMING) {
+        if (lane == 0 && args.dbg) {
+            unsigned long long* out = (unsigned long long*)args.dbg + ((size_t)blockIdx.x * 4 + wave) * (TIMING_REGIONS + TIMING_GROUPS);
+#pragma unroll
+            for (int i = 0; i < TIMING_REGIONS; ++i) out[i] = rc.acc[i];
+#pragma unroll
+            for (int i = 0; i < TIMING_GROUPS; ++i) out[TIMING_REGIONS + i] = 0;
+        }
     }
 
     {
@@ -441,4 +478,13 @@ extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_rel
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+}
+
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_relu_kernel(PndfKernelArgs args) {
+    pndf_fused_split_body<false>(args);
+}
+
+// split-precision kernel with s_memtime region stamps (performance analysis only)
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_relu_kernel_timing(PndfKernelArgs args) {
+    pndf_fused_split_body<true>(args);
 }

@@ -18,7 +18,11 @@ TILES = [0, 640, 0, 4096, 0, 576, 0, 576, 4096, 640, 0, 0]
 
 def main():
     B, steps = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 20
-    net = PoseNDF(amass_config("lrelu", "cuda:0"))
+    prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
+    cfg = amass_config("lrelu", "cuda:0")
+    cfg["engine"] = {"precision": prec}
+    net = PoseNDF(cfg)
+    cyc_per_tile = 128 if prec == "fp32" else 15        # fp32: 4 MFMAs x 32 cycles; f16x3: 1.5 MFMAs x ~10
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(0, 2.0, 0.1).items()})
     q = torch.from_numpy(synth.make_poses(B, seed=1)).cuda()
     eng = net._engine_for(q.device)
@@ -32,9 +36,9 @@ def main():
     c = call[:, :12]
     mean = c.mean(0)
     tot = mean.sum()
-    print(f"per wave-step: total {tot:,.0f} shader cycles; ideal MFMA {sum(TILES) * 4 * 32:,} ({sum(TILES) * 128 / tot * 100:.1f} %)")
+    print(f"[{prec}] per wave-step: total {tot:,.0f} shader cycles; ideal MFMA {sum(TILES) * cyc_per_tile:,} ({sum(TILES) * cyc_per_tile / tot * 100:.1f} %)")
     for n, m, t in zip(NAMES, mean, TILES):
-        ideal = t * 4 * 32
+        ideal = t * cyc_per_tile
         extra = f"  ideal {ideal:9,d}  eff {ideal / m * 100:5.1f} %  over {m - ideal:9,.0f}" if t else f"  {'':40s}"
         print(f"{n:24s} {m:11,.0f} cyc {m / tot * 100:5.1f} %{extra}")
     grp = call[:, 12:].mean(0) / 32          # per chunk of the (lin2,lin3) phase; ideal = 16 MFMAs = 512 cycles

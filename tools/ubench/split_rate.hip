@@ -9,22 +9,49 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 mf(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // a "group" = 4 tile-pairs (hi, lo) = 8 KiB of LDS = 12 MFMAs
-template <int T0>
-__device__ __forceinline__ void load_group(f16x8 (&h)[4], f16x8 (&l)[4], const char* smem, int lane) {
+struct R { const char* g; char* smem; int cur; int next; int wave; int lane; const char* src; unsigned dst; int n; };
+
+__device__ __forceinline__ void piece(R& r) {
+    if (r.n < 4) {
+        unsigned keep;
+        const char* src = r.src + r.n * 1024;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(r.dst + r.n * 1024) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        r.n++;
+    }
+}
+
+// T0 = pair index (8 pairs = 16 tiles per slot)
+template <int T0, int MODE>
+__device__ __forceinline__ void load_group(f16x8 (&h)[4], f16x8 (&l)[4], R& r) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        h[i] = *(const f16x8*)(smem + ((2 * (T0 + i)) % 32) * 1024 + lane * 16);
-        l[i] = *(const f16x8*)(smem + ((2 * (T0 + i) + 1) % 32) * 1024 + lane * 16);
+        const int t = (2 * (T0 + i)) % 16;
+        if ((MODE & 16) && t == 0) r.cur = (r.cur == 4) ? 0 : r.cur + 1;
+        if (t == 8) {
+            if (MODE & 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (MODE & 4) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+            if (MODE & 8) {
+                r.src = r.g + (size_t)r.next * 16384 + r.wave * 4096 + r.lane * 16;
+                r.dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(r.smem) + ((r.cur == 0) ? 4 : r.cur - 1) * 16384 + r.wave * 4096;
+                r.n = 0;
+                r.next = (r.next + 1 == 664) ? 0 : r.next + 1;
+            }
+        }
+        h[i] = *(const f16x8*)(r.smem + r.cur * 16384 + t * 1024 + r.lane * 16);
+        l[i] = *(const f16x8*)(r.smem + r.cur * 16384 + (t + 1) * 1024 + r.lane * 16);
     }
 }
 
 template <int GI, int MODE>
 __device__ __forceinline__ void groups(const f16x8 (&xh)[16], const f16x8 (&xl)[16], f32x4 (&acc)[32], f32x4 (&ch)[2],
                                        f16x8 (&chh)[1], f16x8 (&chl)[1], f16x8 (&ch_)[4], f16x8 (&cl_)[4],
-                                       const char* smem, int lane, int c, int nc) {
+                                       R& smem, int lane, int c, int nc) {
     if constexpr (GI < 16) {
         f16x8 nh[4], nl[4];
-        if (GI + 1 < 16 || c + 1 < nc) load_group<((GI + 1) * 4) % 64>(nh, nl, smem, lane);
+        if (GI + 1 < 16 || c + 1 < nc) load_group<((GI + 1) * 4) % 64, MODE>(nh, nl, smem);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (GI < 8) {           // part A: 2 k-blocks x 2 tiles per group
 #pragma unroll
@@ -34,6 +61,7 @@ __device__ __forceinline__ void groups(const f16x8 (&xh)[16], const f16x8 (&xl)[
                     ch[ci] = mf(ch_[k2 * 2 + ci], xh[2 * GI + k2], ch[ci]);
                     ch[ci] = mf(ch_[k2 * 2 + ci], xl[2 * GI + k2], ch[ci]);
                     ch[ci] = mf(cl_[k2 * 2 + ci], xh[2 * GI + k2], ch[ci]);
+                    if (MODE & 8) piece(smem);
                 }
             if constexpr (GI == 7 && (MODE & 1) == 0) {
                 // epilogue: activation + split into fp16 hi / lo, packed as the next B operand
@@ -57,6 +85,7 @@ __device__ __forceinline__ void groups(const f16x8 (&xh)[16], const f16x8 (&xl)[
                 acc[nb] = mf(ch_[t], chh[0], acc[nb]);
                 acc[nb] = mf(ch_[t], chl[0], acc[nb]);
                 acc[nb] = mf(cl_[t], chh[0], acc[nb]);
+                if (MODE & 8) piece(smem);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -67,23 +96,24 @@ __device__ __forceinline__ void groups(const f16x8 (&xh)[16], const f16x8 (&xl)[
 }
 
 template <int MODE>
-__global__ void __launch_bounds__(256, 1) k(float* out, unsigned long long* cyc, int nc) {
+__global__ void __launch_bounds__(256, 1) k(float* out, unsigned long long* cyc, int nc, const char* gbuf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 32768 / 2; i += 256) ((_Float16*)smem)[i] = (_Float16)(1e-2f * (1 + (i % 7)));
+    for (int i = threadIdx.x; i < 81920 / 2; i += 256) ((_Float16*)smem)[i] = (_Float16)(1e-2f * (1 + (i % 7)));
     __syncthreads();
+    R r; r.g = gbuf; r.smem = smem; r.cur = 0; r.next = 0; r.lane = lane; r.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); r.n = 4; r.src = gbuf; r.dst = 0;
     f16x8 xh[16], xl[16];
     f32x4 acc[32];
     for (int i = 0; i < 16; ++i)
         for (int j = 0; j < 8; ++j) { xh[i][j] = (_Float16)(0.01f * (lane % 5 + i + j)); xl[i][j] = (_Float16)(1e-5f * (i + j)); }
     for (int i = 0; i < 32; ++i) acc[i] = f32x4{0, 0, 0, 0};
     f16x8 ch_[4], cl_[4], chh[1], chl[1];
-    load_group<0>(ch_, cl_, smem, lane);
+    load_group<0, 0>(ch_, cl_, r);
     for (int j = 0; j < 8; ++j) { chh[0][j] = (_Float16)0.1f; chl[0][j] = (_Float16)1e-4f; }
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int c = 0; c < nc; ++c) {
         f32x4 ch[2] = {f32x4{0.1f, 0.2f, 0.3f, 0.4f}, f32x4{0.1f, 0.2f, 0.3f, 0.4f}};
-        groups<0, MODE>(xh, xl, acc, ch, chh, chl, ch_, cl_, smem, lane, c, nc);
+        groups<0, MODE>(xh, xl, acc, ch, chh, chl, ch_, cl_, r, lane, c, nc);
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0;
@@ -95,8 +125,10 @@ __global__ void __launch_bounds__(256, 1) k(float* out, unsigned long long* cyc,
 template <int MODE>
 void run(const char* name, float* out, unsigned long long* cyc) {
     const int nc = 640, grid = 256;
-    hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    hipLaunchKernelGGL((k<MODE>), dim3(grid), dim3(256), 65536, 0, out, cyc, nc);
+    static char* gbuf = nullptr;
+    if (!gbuf) { hipMalloc(&gbuf, 664 * 16384); hipMemset(gbuf, 0, 664 * 16384); }
+    hipFuncSetAttribute((const void*)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160000);
+    hipLaunchKernelGGL((k<MODE>), dim3(grid), dim3(256), 160000, 0, out, cyc, nc, gbuf);
     hipDeviceSynchronize();
     unsigned long long h[256];
     hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
@@ -112,5 +144,10 @@ int main() {
     run<0>("split chunk, epilogue, 32 acc tiles", out, cyc);
     run<1>("split chunk, no epilogue", out, cyc);
     run<3>("no epilogue, 4 accumulators", out, cyc);
+    run<1 + 16>("no epi + rotating buffers", out, cyc);
+    run<1 + 16 + 4>("no epi + rot + barrier/slot", out, cyc);
+    run<1 + 16 + 8>("no epi + rot + DMA/slot", out, cyc);
+    run<1 + 16 + 4 + 8>("no epi + rot + barrier + DMA", out, cyc);
+    run<16 + 4 + 8>("epilogue + rot + barrier + DMA", out, cyc);
     return 0;
 }
