@@ -28,12 +28,16 @@ __device__ __forceinline__ f32x4 mf16(f16x8 a, f16x8 b, f32x4 c) {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// (a, b) -> packed fp16 pair hi = rtz(a, b) and lo = rtz(a - hi_a, b - hi_b): the remainders are exact in fp32,
-// so hi + lo carries ~21 significant bits of each value
+// (a, b) -> packed fp16 pairs: hi = rtz(a, b) (one v_cvt_pkrtz), lo = rne(a - hi_a, b - hi_b).  The remainders
+// are exact in fp32; rounding lo to NEAREST keeps the residual error unbiased (+-2^-23 relative) -- with a
+// truncated lo the error of a 1024-term contraction accumulates linearly instead of as a random walk.
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
     const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
     hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]));
+    f16x2 l;
+    l[0] = (_Float16)(a - (float)h[0]);
+    l[1] = (_Float16)(b - (float)h[1]);
+    lo = __builtin_bit_cast(unsigned, l);
 }
 
 // two activated fp32 C/D tiles -> the B operand of the k-block they form (8 halfs = 4 dwords, hi and lo)
