@@ -46,7 +46,14 @@ def test_create_rejects_unsupported(lib):
     assert b"activation" in lib.pndf_last_error(None)
     lib.pndf_default_config(ctypes.byref(cfg), 2, -1.0)             # softplus needs beta > 0
     assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -1
+    lib.pndf_default_config(ctypes.byref(cfg), 2, 100.0)
+    cfg.precision = 1                                               # softplus has no split-precision kernel
+    assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -4
     lib.pndf_default_config(ctypes.byref(cfg), 1, 100.0)
+    cfg.precision = 9                                               # unknown precision code
+    assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -4
+    lib.pndf_default_config(ctypes.byref(cfg), 1, 100.0)
+    assert cfg.precision == 0
     cfg.dims[2] = 384                                               # other architecture
     assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -4
     cfg.dims[2] = 512

@@ -19,9 +19,18 @@ def torch_cuda():
     return torch
 
 
-def make_net(torch, act, regime=None, sd=None):
+PRECISIONS = ["fp32", "f16x3"]      # f16x3: fp16 hi/lo split operands, fp32 accumulate (relu / lrelu only)
+
+
+def cases(acts):
+    return [(a, p) for a in acts for p in PRECISIONS if not (a == "softplus" and p == "f16x3")]
+
+
+def make_net(torch, act, regime=None, sd=None, precision="fp32"):
     from posendf_amd import PoseNDF, amass_config
-    net = PoseNDF(amass_config(act, "cuda:0"))
+    cfg = amass_config(act, "cuda:0")
+    cfg["engine"] = {"precision": precision}
+    net = PoseNDF(cfg)
     sd = sd if sd is not None else golden_weights(regime)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     net.eval()
@@ -31,12 +40,12 @@ def make_net(torch, act, regime=None, sd=None):
 ALL_ACTS = ["lrelu", "relu", "softplus"]
 
 
-@pytest.mark.parametrize("act", ALL_ACTS)
+@pytest.mark.parametrize("act,precision", cases(ALL_ACTS))
 @pytest.mark.parametrize("regime", list(REGIMES))
-def test_golden_single_step(torch_cuda, act, regime):
+def test_golden_single_step(torch_cuda, act, regime, precision):
     torch = torch_cuda
     g = load_golden(act, regime)
-    net = make_net(torch, act, regime)
+    net = make_net(torch, act, regime, precision=precision)
     q = torch.from_numpy(g["q"]).cuda().requires_grad_(True)
     d = net(q, train=False)["dist_pred"]
     assert d.shape == (len(g["q"]), 1)
@@ -54,13 +63,13 @@ def test_golden_single_step(torch_cuda, act, regime):
         assert np.all(dq.cpu().numpy()[z] == 0)
 
 
-@pytest.mark.parametrize("act", ALL_ACTS)
-def test_golden_autograd_contract(torch_cuda, act):
+@pytest.mark.parametrize("act,precision", cases(ALL_ACTS))
+def test_golden_autograd_contract(torch_cuda, act, precision):
     """backward with an arbitrary upstream gradient (motion_denoise.py:82-83,97-98) and the pose-prior
     objective 1e7 c^2 / (1 + it) of motion_denoise.py:33."""
     torch = torch_cuda
     g = load_golden(act, "mixed")
-    net = make_net(torch, act, "mixed")
+    net = make_net(torch, act, "mixed", precision=precision)
     q = torch.from_numpy(g["q"]).cuda().requires_grad_(True)
     (net(q, train=False)["dist_pred"] * torch.from_numpy(g["grad_out"]).cuda()).sum().backward()
     truth = g["dq_f64"] * g["grad_out"].reshape(-1, 1, 1)
@@ -77,15 +86,15 @@ def test_golden_autograd_contract(torch_cuda, act):
                      2 * TOL, "prior")
 
 
-@pytest.mark.parametrize("act", ALL_ACTS)
+@pytest.mark.parametrize("act,precision", cases(ALL_ACTS))
 @pytest.mark.parametrize("regime", list(REGIMES))
-def test_golden_projection(torch_cuda, act, regime):
+def test_golden_projection(torch_cuda, act, regime, precision):
     """1/10/100-step projection vs the reference.  Single step: 1e-4.  Free-running: measured against the
     reference's fp64 trajectory with the reference's own fp32 run as the envelope (LeakyReLU/ReLU kinks make
     a per-pose 1e-4 gate fail for the reference against itself)."""
     torch = torch_cuda
     g = load_golden(act, regime)
-    net = make_net(torch, act, regime)
+    net = make_net(torch, act, regime, precision=precision)
     q0 = torch.from_numpy(g["q"]).cuda()
     for steps in (1, 10, 100):
         qp, dl = net.project(q0, steps=steps)
@@ -95,19 +104,25 @@ def test_golden_projection(torch_cuda, act, regime):
         ref = rel_err_rows(g[f"q{steps}_f32"], truth)
         outlier_gate(mine, ref, TOL, f"project{steps}")
         assert np.percentile(mine, 90) < TOL
-        # d_last is dist_pred of the last iteration (before its update)
-        assert d_err(dl.cpu().numpy()[:, 0], g["dtrace_f64"][steps - 1], floor_frac=0.05) < 20 * TOL if steps > 1 \
-            else d_err(dl.cpu().numpy()[:, 0], g["dtrace_f32"][0]) < TOL
+        # d_last is dist_pred of the last iteration (before its update); along a free-running trajectory it
+        # is subject to the same kink divergence as q, so it gets the same outlier gate
+        dref64 = g["dtrace_f64"][steps - 1]
+        floor = 0.05 * np.abs(dref64).max()
+        derr = lambda a: np.abs(np.asarray(a, np.float64) - dref64) / np.maximum(np.abs(dref64), floor)
+        if steps == 1:
+            assert d_err(dl.cpu().numpy()[:, 0], g["dtrace_f32"][0]) < TOL
+        else:
+            outlier_gate(derr(dl.cpu().numpy()[:, 0]), derr(g["dtrace_f32"][steps - 1]), 20 * TOL, f"d_last{steps}")
 
 
-@pytest.mark.parametrize("act", ["lrelu", "softplus"])
+@pytest.mark.parametrize("act,precision", cases(["lrelu", "softplus"]))
 @pytest.mark.parametrize("B", [1, 15, 63, 64, 65, 257, 1000])
-def test_ragged_batches_match_oracle(torch_cuda, B, act):
+def test_ragged_batches_match_oracle(torch_cuda, B, act, precision):
     torch = torch_cuda
     from oracle import posendf_np as onp
     from posendf_amd import synth
     sd = golden_weights("mixed")
-    net = make_net(torch, act, sd=sd)
+    net = make_net(torch, act, sd=sd, precision=precision)
     qn = synth.make_poses(B, seed=100 + B, signed=True)
     q = torch.from_numpy(qn).cuda().requires_grad_(True)
     d = net(q, train=False)["dist_pred"]
@@ -122,14 +137,15 @@ def test_ragged_batches_match_oracle(torch_cuda, B, act):
     outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project4")
 
 
-def test_teacher_forced_steps(torch_cuda):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_teacher_forced_steps(torch_cuda, precision):
     """Per-step parity along the reference's own fp32 trajectory (BASELINE.md gate 2): feed q_k of the
     oracle trajectory, compare one engine step with the oracle's next iterate."""
     torch = torch_cuda
     from oracle import posendf_np as onp
     from posendf_amd import synth
     sd = golden_weights("live")
-    net = make_net(torch, "lrelu", sd=sd)
+    net = make_net(torch, "lrelu", sd=sd, precision=precision)
     q = synth.make_poses(128, seed=9)
     for k in range(12):
         d, dq = onp.forward_grad(q, sd, "lrelu")
@@ -142,13 +158,14 @@ def test_teacher_forced_steps(torch_cuda):
         q = nxt.astype(np.float32)
 
 
-def test_full_size_properties(torch_cuda):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_full_size_properties(torch_cuda, precision):
     """BASELINE.json configs 2-3 size (B = 65,536): size-independent properties instead of an oracle run."""
     torch = torch_cuda
     from oracle import posendf_np as onp
     from posendf_amd import synth
     sd = golden_weights("live")
-    net = make_net(torch, "lrelu", sd=sd)
+    net = make_net(torch, "lrelu", sd=sd, precision=precision)
     B = 65536
     qn = synth.make_poses(B, seed=1234)
     q = torch.from_numpy(qn).cuda()
