@@ -5,10 +5,11 @@
 # Counters are collected with --kernel-trace only, as the pool requires.
 set -u
 OUT=${1:-gpurun_out/prof}
+PREC=${2:-f16x3}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-ref --precision $PREC"
 rocprofv3 -L > "$ROOT/$OUT/counters_available.txt" 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace" -o trace -- $BENCH > "$ROOT/$OUT/trace.log" 2>&1
 echo "trace rc=$?"
@@ -23,4 +24,4 @@ echo "pmc_write rc=$?"
 timeout 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d "$ROOT/$OUT/pmc_l2" -o pmc -- $BENCH > "$ROOT/$OUT/pmc_l2.log" 2>&1
 echo "pmc_l2 rc=$?"
 find "$ROOT/$OUT" -name "*.csv" | head -40
-for f in $(find "$ROOT/$OUT" -name "*counter_collection.csv"); do echo "== $f"; grep pndf_fused "$f" | head -12; done
+for f in $(find "$ROOT/$OUT" -name "*counter_collection.csv"); do echo "== $f"; grep "pndf_fused" "$f" | head -12; done

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""profiles/<round>/<tag>_pmc_{fetch,write}_counters.csv -> entry of profiles/traffic.json (HBM bytes per launch).
+usage: make_traffic.py <kernel_name> <fetch_csv> <write_csv> <workload text>"""
+import csv
+import json
+import os
+import statistics
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def vals(path, counter, kernel):
+    return [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+            if r["Counter_Name"] == counter and r["Kernel_Name"] == kernel]
+
+
+def main():
+    kernel, fetch_csv, write_csv, workload = sys.argv[1:5]
+    f, w = statistics.mean(vals(fetch_csv, "FETCH_SIZE", kernel)), statistics.mean(vals(write_csv, "WRITE_SIZE", kernel))
+    path = os.path.join(REPO, "profiles", "traffic.json")
+    db = json.load(open(path)) if os.path.exists(path) else {}
+    if "kernel" in db:      # old single-entry format
+        db = {}
+    db[kernel] = {"workload": workload, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "gfx950_fetch_correction": 2.0,
+                  "hbm_bytes_per_launch": (2 * f + w) * 1024,
+                  "note": "separate --pmc passes (tools/gpu_profile.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md; counts "
+                          "Infinity-Cache hits; the traffic above the algorithmic ~55 MB is the ~3% of weight-stream "
+                          "requests that miss the per-XCD L2",
+                  "source": [os.path.relpath(fetch_csv, REPO), os.path.relpath(write_csv, REPO)]}
+    json.dump(db, open(path, "w"), indent=1)
+    print(kernel, db[kernel]["hbm_bytes_per_launch"])
+
+
+if __name__ == "__main__":
+    main()
