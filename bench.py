@@ -84,9 +84,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PNDF_BENCH_FORCE_DIST") == "1"   # the flag exercises RCCL with 1 rank
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     sd = synth.make_weights(0, 2.0, 0.1)                        # BASELINE.md section 3 "live regime"
@@ -108,14 +110,14 @@ def main():
 
     def one_pass():
         qp, d = net.project(q0, steps=args.proj_steps)
-        if world > 1:
+        if use_dist:
             all_gather_blocks(qp, B * world)                    # the only collective: final gather over xGMI
         return qp, d
 
     for _ in range(args.warmup):
         one_pass()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -123,14 +125,14 @@ def main():
         ev[k][0].record()
         qp, d = net.project(q0, steps=args.proj_steps)          # the dominant kernel, bracketed by HIP events
         ev[k][1].record()
-        if world > 1:
+        if use_dist:
             all_gather_blocks(qp, B * world)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -205,7 +207,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.act, sd, args.proj_steps, args.cpu_budget)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

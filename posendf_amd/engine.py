@@ -29,6 +29,14 @@ class PndfError(RuntimeError):
 
 def load_library(path: str | None = None) -> ctypes.CDLL:
     path = path or _LIB_PATH
+    # PyTorch is the plumbing for device memory and streams, so the library must share PyTorch's HIP runtime:
+    # import torch FIRST so that its bundled libamdhip64 is the one already mapped when the loader resolves
+    # this library's dependency (the other order puts two HIP runtimes in the process and pndf_create then
+    # sees no device).  Without torch installed the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise PndfError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). The engine has no fallback path.")

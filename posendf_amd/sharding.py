@@ -17,9 +17,9 @@ def shard_bounds(total: int, rank: int, world: int):
 def all_gather_blocks(x: torch.Tensor, total: int, group=None):
     """Gather per-rank blocks (possibly ragged by one row) into the [total, ...] tensor, in rank order."""
     import torch.distributed as dist
-    world = dist.get_world_size(group)
-    if world == 1:
+    if not dist.is_initialized():
         return x
+    world = dist.get_world_size(group)
     rows = max(shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world))
     pad = x
     if x.shape[0] < rows:   # ragged tail: pad to the common block size, trimmed below
