@@ -1,0 +1,103 @@
+"""Motion denoising around the engine -- the second caller of the hot path.
+
+Mirrors the optimiser structure of the reference's `MotionDenoise.optimize`
+(experiments/motion_denoise.py:58-121): Adam(lr=0.02, betas=(0.9, 0.999)) over SMPL axis-angle body poses,
+10 x 50 steps, loss = sum_k w_k(loss_k, it) with the reference's iteration-dependent weights (:29-35):
+    temp   : 10    * c * (1 + it)
+    data   : 100   * c / (1 + it)          (only for it > 0, :92)
+    pose_pr: 1e7   * c * c / (1 + it)      with c = mean_t PoseNDF(q_t)  (:81-83)
+The pose-prior term -- the part on the hot path -- runs on the HIP engine through `PoseNDF.forward(train=False)`
+and its first-order autograd contract.  The reference's temporal / data terms need the SMPL body model
+(vertices, joints: third-party code + licensed model files, parity unpinned); here they are
+pluggable: pass `body_model(pose_body[T,69]) -> (vertices[T,V,3], joints[T,J,3])`, or leave it None to use
+pose-space surrogates (per-joint axis-angle differences), which keep the objective's structure.
+
+Sequences are independent problems (one `main()` per sequence in the reference, :171-188): a batch [S, T, 69] is
+optimised with per-sequence means, one engine launch per Adam step for all S x T frames.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def axis_angle_to_quaternion(axis_angle: torch.Tensor) -> torch.Tensor:
+    """pytorch3d.transforms.axis_angle_to_quaternion restated from its documented convention (real part first;
+    q = [cos(|a|/2), a * sin(|a|/2) / |a|], Taylor series 1/2 - |a|^2/48 below 1e-6).  Third-party arithmetic that
+    is not under /root/reference: parity unpinned; self-tested in tests/test_motion_denoise.py."""
+    angles = torch.norm(axis_angle, p=2, dim=-1, keepdim=True)
+    half = 0.5 * angles
+    small = angles.abs() < 1e-6
+    safe = torch.where(small, torch.ones_like(angles), angles)
+    k = torch.where(small, 0.5 - angles * angles / 48.0, torch.sin(half) / safe)
+    return torch.cat([torch.cos(half), axis_angle * k], dim=-1)
+
+
+def loss_weights():
+    """experiments/motion_denoise.py:29-35."""
+    return {"temp": lambda cst, it: 10.0 ** 1 * cst * (1 + it),
+            "data": lambda cst, it: 10.0 ** 2 * cst / (1 + it),
+            "pose_pr": lambda cst, it: 10.0 ** 7 * cst * cst / (1 + it)}
+
+
+class MotionDenoise:
+    def __init__(self, posendf, body_model=None, device="cuda:0"):
+        self.pose_prior = posendf
+        self.body_model = body_model
+        self.device = device
+
+    # ---- loss terms -----------------------------------------------------------------------------
+    def pose_prior_term(self, body_pose):
+        """[S,T,69] -> per-sequence mean distance [S]  (motion_denoise.py:81-83)."""
+        S, T = body_pose.shape[:2]
+        quat = axis_angle_to_quaternion(body_pose.reshape(S * T, 23, 3)[:, :21])
+        dist = self.pose_prior(quat, train=False)["dist_pred"]
+        return dist.reshape(S, T).mean(dim=1)
+
+    def _geometry(self, body_pose):
+        S, T = body_pose.shape[:2]
+        if self.body_model is None:
+            pts = body_pose.reshape(S, T, 23, 3)[:, :, :21]          # pose-space surrogate "vertices" = "joints"
+            return pts, pts
+        v, j = self.body_model(body_pose.reshape(S * T, 69))
+        return v.reshape(S, T, *v.shape[1:]), j.reshape(S, T, *j.shape[1:])
+
+    @staticmethod
+    def _mean_norm(x):
+        """mean over (t, point) of the Euclidean norm, per sequence (motion_denoise.py:89,94)."""
+        return torch.sqrt((x * x).sum(dim=-1) + 1e-20).mean(dim=(1, 2))
+
+    def losses(self, body_pose, init_joints, it):
+        loss = {"pose_pr": self.pose_prior_term(body_pose)}
+        verts, joints = self._geometry(body_pose)
+        loss["temp"] = self._mean_norm(verts[:, :-1] - verts[:, 1:])                 # :88-89
+        if it > 0:                                                                    # :92 ("for nans")
+            loss["data"] = self._mean_norm(joints - init_joints)                      # :93-94
+        return loss
+
+    @staticmethod
+    def total(loss, it):
+        w = loss_weights()
+        return torch.stack([w[k](v, it) for k, v in loss.items()]).sum(dim=0)         # backward_step, :37-45
+
+    # ---- optimiser ------------------------------------------------------------------------------
+    def optimize(self, noisy_poses, iterations=10, steps_per_iter=50, lr=0.02):
+        """noisy_poses: [T,69] or [S,T,69] axis-angle.  Returns (denoised poses, history of per-step mean losses)."""
+        single = noisy_poses.dim() == 2
+        pose = noisy_poses.to(self.device, torch.float32)
+        if single:
+            pose = pose[None]
+        body_pose = pose.clone().requires_grad_(True)
+        with torch.no_grad():
+            _, init_joints = self._geometry(pose)
+        opt = torch.optim.Adam([body_pose], lr, betas=(0.9, 0.999))                   # :70
+        history = []
+        for it in range(iterations):                                                  # :74
+            for _ in range(steps_per_iter):                                           # :77
+                opt.zero_grad()
+                loss = self.losses(body_pose, init_joints, it)
+                tot = self.total(loss, it).sum()          # sequences are independent: sum of per-sequence objectives
+                tot.backward()                            # :98
+                opt.step()                                # :99
+                history.append({k: float(v.mean()) for k, v in loss.items()})
+        out = body_pose.detach()
+        return (out[0] if single else out), history

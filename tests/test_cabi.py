@@ -103,3 +103,29 @@ def test_facade_surface_cpu():
     assert net.dfnet.lin0.weight.grad is not None
     with pytest.raises(PndfError):
         net(torch.from_numpy(g["q"]), train=False)
+
+
+def test_reference_checkpoint_interchange(tmp_path):
+    """the reference's on-disk checkpoint (model/train_posendf.py:147-156: a dict with
+    'epoch' / 'model_state_dict' / 'optimizer_state_dict', legacy non-zip serialisation) loads unchanged, the way
+    experiments/sample_poses.py:90-91 does it, and round-trips."""
+    import torch
+    from conftest import golden_weights
+    from posendf_amd import PoseNDF, amass_config
+    src = PoseNDF(amass_config("lrelu", "cpu"))
+    src.load_state_dict({k: torch.from_numpy(v) for k, v in golden_weights("mixed").items()})
+    opt = torch.optim.Adam(src.parameters(), lr=1e-5, weight_decay=1e-4)          # train_posendf.py:30
+    path = tmp_path / "checkpoint_epoch_best.tar"
+    torch.save({"epoch": 7, "model_state_dict": src.state_dict(), "optimizer_state_dict": opt.state_dict()}, path,
+               _use_new_zipfile_serialization=False)
+    ckpt = torch.load(path, map_location="cpu")["model_state_dict"]                # sample_poses.py:90
+    dst = PoseNDF(amass_config("lrelu", "cpu"))
+    dst.load_state_dict(ckpt)                                                      # sample_poses.py:91
+    dst.eval()
+    for (ka, a), (kb, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert ka == kb and torch.equal(a, b)
+    # the packed engine weights are a pure function of the state dict
+    from posendf_amd import engine
+    s1, b1 = engine.pack_host({k: v.numpy() for k, v in src.state_dict().items()})
+    s2, b2 = engine.pack_host({k: v.numpy() for k, v in dst.state_dict().items()})
+    assert np.array_equal(s1, s2) and np.array_equal(b1, b2)
