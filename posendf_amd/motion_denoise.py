@@ -80,7 +80,7 @@ class MotionDenoise:
         return torch.stack([w[k](v, it) for k, v in loss.items()]).sum(dim=0)         # backward_step, :37-45
 
     # ---- optimiser ------------------------------------------------------------------------------
-    def optimize(self, noisy_poses, iterations=10, steps_per_iter=50, lr=0.02):
+    def optimize(self, noisy_poses, iterations=10, steps_per_iter=50, lr=0.02, record=True):
         """noisy_poses: [T,69] or [S,T,69] axis-angle.  Returns (denoised poses, history of per-step mean losses)."""
         single = noisy_poses.dim() == 2
         pose = noisy_poses.to(self.device, torch.float32)
@@ -98,6 +98,7 @@ class MotionDenoise:
                 tot = self.total(loss, it).sum()          # sequences are independent: sum of per-sequence objectives
                 tot.backward()                            # :98
                 opt.step()                                # :99
-                history.append({k: float(v.mean()) for k, v in loss.items()})
+                if record:                                # one host sync per step; off for throughput
+                    history.append({k: float(v.detach().mean()) for k, v in loss.items()})
         out = body_pose.detach()
         return (out[0] if single else out), history

@@ -237,3 +237,51 @@ def test_debug_stages(torch_cuda):
                        capture_output=True, text=True, timeout=900)
     print(r.stdout[-4000:])
     assert "MISMATCH" not in r.stdout and r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_side_stream_and_graph_capture(torch_cuda, precision):
+    """The C ABI enqueues on the caller's stream and allocates nothing per call (include/posendf_amd.h conventions):
+    a launch on a side stream and a hipGraph capture + replay give the same bits as the default-stream call."""
+    torch = torch_cuda
+    from posendf_amd import synth
+    net = make_net(torch, "lrelu", "live", precision=precision)
+    q = torch.from_numpy(synth.make_poses(300, seed=9)).cuda()
+    ref_q, ref_d = net.project(q, steps=7)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        s_q, s_d = net.project(q, steps=7)
+    side.synchronize()
+    assert torch.equal(s_q, ref_q) and torch.equal(s_d, ref_d)
+    # graph capture: static input/output buffers, replay after changing the input in place
+    q_static = q.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        g_q, g_d = net.project(q_static, steps=7)
+    q2 = torch.from_numpy(synth.make_poses(300, seed=10)).cuda()
+    q_static.copy_(q2)
+    g.replay()
+    torch.cuda.synchronize()
+    want_q, want_d = net.project(q2, steps=7)
+    assert torch.equal(g_q, want_q) and torch.equal(g_d, want_d)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_nonfinite_pose_stays_in_its_row(torch_cuda, precision):
+    """Poses are independent rows (model/posendf.py:64 reshapes to [B,21,4]): a NaN pose poisons only its own
+    distance and gradient, as in the reference, and its 63 workgroup neighbours are bit-identical."""
+    torch = torch_cuda
+    from posendf_amd import synth
+    net = make_net(torch, "lrelu", "live", precision=precision)
+    q = torch.from_numpy(synth.make_poses(128, seed=11)).cuda()
+    clean_q, clean_d = net.project(q, steps=3)
+    bad = q.clone()
+    bad[37, 5, 2] = float("nan")
+    got_q, got_d = net.project(bad, steps=3)
+    torch.cuda.synchronize()
+    keep = torch.ones(128, dtype=torch.bool, device="cuda")
+    keep[37] = False
+    assert torch.equal(got_q[keep], clean_q[keep]) and torch.equal(got_d[keep], clean_d[keep])
+    assert not torch.isfinite(got_q[37]).all()
