@@ -68,28 +68,35 @@ struct Ring {
 // piece 3 restores it; pieces 1..3 reuse it (the instruction offset moves both the global and the LDS address).
 // Between the pieces only MFMAs, ds_reads and waits are issued -- none of them touches M0 on gfx950 -- and
 // with one wave per SIMD every SALU instruction saved here is ~4 issue cycles of the critical path.
-__device__ __forceinline__ void ring_dma_piece(const char* src, uint32_t dst, int j, uint32_t& keep) {
+// Addressing: SGPR base (the stream pointer) + one 32-bit VGPR byte offset -- measured 21 issue cycles per piece
+// between MFMAs against 30 for the 64-bit-VGPR-address form (tools/ubench/dma_cost.hip).
+struct DmaSrc {
+    const char* base;      // uniform
+    uint32_t off;          // per lane: slot * SLOT_BYTES + wave * 4 KiB + lane * 16
+};
+__device__ __forceinline__ void ring_dma_piece(const DmaSrc& src, uint32_t dst, int j, uint32_t& keep) {
     if (j == 0)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     : "=&s"(keep) : "v"(src.off), "s"(src.base), "s"(dst) : "memory");
     else if (j == 1)
-        asm volatile("global_load_lds_dwordx4 %0, off offset:1024" : : "v"(src) : "memory");
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(src.off), "s"(src.base) : "memory");
     else if (j == 2)
-        asm volatile("global_load_lds_dwordx4 %0, off offset:2048" : : "v"(src) : "memory");
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(src.off), "s"(src.base) : "memory");
     else
-        asm volatile("global_load_lds_dwordx4 %0, off offset:3072\n\ts_mov_b32 m0, %1" : : "v"(src), "s"(keep) : "memory");
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072\n\ts_mov_b32 m0, %2" : : "v"(src.off), "s"(src.base), "s"(keep) : "memory");
 }
 
 // source / destination of this wave's share of the next slot to fetch; advances r.next
-__device__ __forceinline__ void ring_dma_begin(Ring& r, int buf, const char*& src, uint32_t& dst) {
-    src = r.gstream + (size_t)r.next * SLOT_BYTES + r.wave * (4 * TILE_BYTES) + r.lane * 16;
+__device__ __forceinline__ void ring_dma_begin(Ring& r, int buf, DmaSrc& src, uint32_t& dst) {
+    src.base = r.gstream;
+    src.off = (uint32_t)r.next * SLOT_BYTES + r.wave * (4 * TILE_BYTES) + r.lane * 16;
     const uint32_t lds_base = (uint32_t)(size_t)(PNDF_LDS char*)(r.smem + LDS_RING);
     dst = lds_base + buf * SLOT_BYTES + r.wave * (4 * TILE_BYTES);
     r.next = (r.next + 1 == r.nslots) ? 0 : r.next + 1;
 }
 
 __device__ __forceinline__ void ring_dma(Ring& r, int buf) {
-    const char* src;
+    DmaSrc src;
     uint32_t dst;
     ring_dma_begin(r, buf, src, dst);
     uint32_t keep = 0;

@@ -42,7 +42,7 @@ struct PhaseBody {
             // the slot fetch that follows a mid-slot barrier: four 1-KiB DMA instructions, each issued behind
             // an MFMA of this group (a VMEM issue blocks the wave ~16+ cycles; back to back they starve the
             // MFMA pipe, behind an MFMA they are free)
-            const char* dsrc = nullptr;
+            DmaSrc dsrc{nullptr, 0u};
             uint32_t ddst = 0;
             if (MID && loaded) ring_dma_begin(ring, ring_fill_buffer(ring), dsrc, ddst);
             int piece = 0;

@@ -67,25 +67,55 @@ __device__ __forceinline__ void load_pairs(Pair (&a)[4], Ring& ring) {
 }
 
 struct DmaPieces {     // the slot fetch that follows a mid-slot barrier, issued piecewise between MFMAs
-    const char* src;
+    DmaSrc src;
     uint32_t dst;
-    uint32_t keep;
-    int n;
 };
 template <int T0>
 __device__ __forceinline__ void dma_begin(DmaPieces& d, Ring& ring, bool loaded) {
-    d.n = 4;
-    if (group_has_mid<8, T0>() && loaded) {
-        ring_dma_begin(ring, ring_fill_buffer(ring), d.src, d.dst);
-        d.n = 0;
-    }
+    if (group_has_mid<8, T0>() && loaded) ring_dma_begin(ring, ring_fill_buffer(ring), d.src, d.dst);
 }
-__device__ __forceinline__ void dma_step(DmaPieces& d) {
-    if (d.n < 4) {
-        __builtin_amdgcn_sched_barrier(0);
-        ring_dma_piece(d.src, d.dst, d.n, d.keep);
-        d.n++;
-        __builtin_amdgcn_sched_barrier(0);
+// The four pieces of a slot fetch are spread over the two tile groups that follow the barrier: pieces 0, 1 in the
+// group that ran the mid-slot events (TN == 8), pieces 2, 3 in the next one (TN == 0, same phase by construction:
+// a phase starts on a slot boundary and fetches are only begun when a next group exists).  Each group saves M0,
+// issues its two pieces two MFMAs apart and restores M0 -- nothing in between touches M0.
+template <int TN, bool SECOND>
+__device__ __forceinline__ void dma_step(const DmaPieces& d, uint32_t& keep) {
+    if constexpr (TN == SLOT_TILES / 2 && !SECOND)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     : "=&s"(keep) : "v"(d.src.off), "s"(d.src.base), "s"(d.dst) : "memory");
+    else if constexpr (TN == SLOT_TILES / 2 && SECOND)
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024\n\ts_mov_b32 m0, %2"
+                     : : "v"(d.src.off), "s"(d.src.base), "s"(keep) : "memory");
+    else if constexpr (TN == 0 && !SECOND)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048"
+                     : "=&s"(keep) : "v"(d.src.off), "s"(d.src.base), "s"(d.dst) : "memory");
+    else
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072\n\ts_mov_b32 m0, %2"
+                     : : "v"(d.src.off), "s"(d.src.base), "s"(keep) : "memory");
+}
+
+// What follows MFMA J (0..11) of a group, for the group after it (first tile TN of its slot):
+//   J = 0      ring events of the next group (slot boundary / mid-slot wait + barrier + fetch set-up)
+//   J = 0..3   its four hi tiles, J = 4..7 its four lo tiles (needed only by that group's MFMAs 8..11)
+//   J = 9, 11  one DMA piece each: the four pieces of a slot fetch are spread over the two groups after the barrier
+// One LDS read per MFMA instead of a burst of eight: right after the workgroup barrier all four waves used to issue
+// their bursts at once and sat in the LDS queue with an empty MFMA pipe (tools/ubench/split_rate.hip: barrier cost
+// 150 -> 33 cycles per slot).
+template <int TN, int J>
+__device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, uint32_t& keep, bool loaded) {
+    if constexpr (J == 0) {
+        if (loaded) {
+            if constexpr (TN == 0) ring_boundary(ring);
+            if constexpr (TN == SLOT_TILES / 2) ring_midslot_sync(ring);
+            dma_begin<TN>(dp, ring, true);
+        }
+    }
+    if constexpr (J < 4) {
+        if (loaded) nxt[J].h = __builtin_bit_cast(f16x8, ring_tile(ring, TN + 2 * J));
+    } else if constexpr (J < 8) {
+        if (loaded) nxt[J - 4].l = __builtin_bit_cast(f16x8, ring_tile(ring, TN + 2 * (J - 4) + 1));
+    } else if constexpr (J == 9 || J == 11) {
+        if (TN == 0 || loaded) dma_step<TN, J == 11>(dp, keep);
     }
 }
 
@@ -100,34 +130,34 @@ struct SplitPhase {
 
     // ---- part A: chunk rows of layer A.  Three partial accumulators per chunk tile (hh, hl, lh terms) keep
     // dependent MFMAs far apart; they are summed in the epilogue.
+    template <int GA, int M>
+    static __device__ __forceinline__ void a_steps(const Blk (&xin)[KA2], f32x4 (&ch)[3][CT], const Pair (&cur)[4],
+                                                   Pair (&nxt)[4], Ring& ring, DmaPieces& dp, uint32_t& keep) {
+        if constexpr (M < 12) {
+            constexpr int term = M / 4, i = M % 4, pi = 4 * GA + i, kb = pi / CT, ci = pi % CT;
+            constexpr int TN = (8 * (GA + 1)) % SLOT_TILES;
+            if constexpr (M == 8) __builtin_amdgcn_s_waitcnt(0xC87F);     // lgkmcnt(8): this group's lo tiles
+            const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
+            const f16x8 x = (term == 1) ? xin[kb].l : xin[kb].h;
+            ch[term][ci] = mf16(w, x, ch[term][ci]);
+            __builtin_amdgcn_sched_barrier(0);
+            feed<TN, M>(nxt, ring, dp, keep, true);     // part B follows, so there is always a next group
+            __builtin_amdgcn_sched_barrier(0);
+            a_steps<GA, M + 1>(xin, ch, cur, nxt, ring, dp, keep);
+        }
+    }
     template <int GA>
-    static __device__ __forceinline__ void part_a(const Blk (&xin)[KA2], f32x4 (&ch)[3][CT], Pair (&cur)[4], Ring& ring) {
+    static __device__ __forceinline__ void part_a(const Blk (&xin)[KA2], f32x4 (&ch)[3][CT], Pair (&cur)[4], Ring& ring,
+                                                  DmaPieces& dp) {
         if constexpr (GA < AG) {
             Pair nxt[4];
-            constexpr int TN = (8 * (GA + 1)) % SLOT_TILES;
-            load_pairs<TN>(nxt, ring);                 // part B follows, so there is always a next group
-            DmaPieces dp;
-            dma_begin<TN>(dp, ring, true);
-            // one wait for the whole current group (the 8 reads just issued may stay in flight) instead of the
-            // compiler's per-MFMA lgkmcnt ladder: with one wave per SIMD every instruction is ~4 issue cycles
-            __builtin_amdgcn_s_waitcnt(0xC87F);        // lgkmcnt(8)
+            __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt(4): this group's hi tiles
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int term = 0; term < 3; ++term) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int pi = 4 * GA + i, kb = pi / CT, ci = pi % CT;
-                    const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
-                    const f16x8 x = (term == 1) ? xin[kb].l : xin[kb].h;
-                    ch[term][ci] = mf16(w, x, ch[term][ci]);
-                    if (i & 1) dma_step(dp);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            uint32_t keep = 0;
+            a_steps<GA, 0>(xin, ch, cur, nxt, ring, dp, keep);
 #pragma unroll
             for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
-            part_a<GA + 1>(xin, ch, cur, ring);
+            part_a<GA + 1>(xin, ch, cur, ring, dp);
         }
     }
 
@@ -173,39 +203,68 @@ struct SplitPhase {
 
     // ---- part B: every output tile gets the chunk's contribution.  In group 0 the epilogue of the NEXT chunk
     // (its part A has just been issued) is placed in the same scheduling region, so its VALU work is
-    // interleaved with these MFMAs by the compiler instead of stalling the pipe.
+    // interleaved with these MFMAs by the compiler instead of stalling the pipe (that group keeps the burst prefetch).
+    template <int GB, int M>
+    static __device__ __forceinline__ void b_steps(const Blk (&chb)[CB], f32x4 (&acc)[NB], const Pair (&cur)[4],
+                                                   Pair (&nxt)[4], Ring& ring, DmaPieces& dp, uint32_t& keep, bool loaded) {
+        if constexpr (M < 12) {
+            constexpr int term = M / 4, i = M % 4, pi = 4 * GB + i, nb = pi / CB, b = pi % CB;
+            constexpr int TN = (A_TILES + 8 * (GB + 1)) % SLOT_TILES;
+            if constexpr (M == 8) {
+                if (loaded) __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8)
+                else __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+            }
+            const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
+            const f16x8 x = (term == 1) ? chb[b].l : chb[b].h;
+            acc[nb] = mf16(w, x, acc[nb]);
+            __builtin_amdgcn_sched_barrier(0);
+            feed<TN, M>(nxt, ring, dp, keep, loaded);
+            __builtin_amdgcn_sched_barrier(0);
+            b_steps<GB, M + 1>(chb, acc, cur, nxt, ring, dp, keep, loaded);
+        }
+    }
     template <int GB>
     static __device__ __forceinline__ void part_b(const Blk (&chb)[CB], f32x4 (&acc)[NB], Pair (&cur)[4], Ring& ring,
-                                                  bool more, f32x4 (&chn)[3][CT], Blk (&nextb)[CB], uint8_t* mask,
-                                                  int c, float slope) {
+                                                  DmaPieces& dp, bool more, f32x4 (&chn)[3][CT], Blk (&nextb)[CB],
+                                                  uint8_t* mask, int c, float slope) {
         if constexpr (GB < BG) {
             Pair nxt[4];
             constexpr int TN = (A_TILES + 8 * (GB + 1)) % SLOT_TILES;
             const bool loaded = (GB + 1 < BG) || more;
-            if (loaded) load_pairs<TN>(nxt, ring);
-            DmaPieces dp;
-            dma_begin<TN>(dp, ring, loaded);
-            if (loaded) __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8)
-            else __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int term = 0; term < 3; ++term) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int pi = 4 * GB + i, nb = pi / CB, b = pi % CB;
-                    const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
-                    const f16x8 x = (term == 1) ? chb[b].l : chb[b].h;
-                    acc[nb] = mf16(w, x, acc[nb]);
-                    if (i & 1) dma_step(dp);
-                }
-            }
             if constexpr (GB == 0) {
+                uint32_t keep0 = 0;
+                if (loaded) load_pairs<TN>(nxt, ring);
+                dma_begin<TN>(dp, ring, loaded);
+                if (loaded) __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8)
+                else __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int term = 0; term < 3; ++term) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int pi = i, nb = pi / CB, b = pi % CB;
+                        const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
+                        const f16x8 x = (term == 1) ? chb[b].l : chb[b].h;
+                        acc[nb] = mf16(w, x, acc[nb]);
+                        if (term == 2 && (i & 1) && (TN == 0 || loaded)) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (i == 1) dma_step<TN, false>(dp, keep0);
+                            else dma_step<TN, true>(dp, keep0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
                 if (more) epilogue(chn, nextb, mask, c + 1, slope);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                if (loaded) __builtin_amdgcn_s_waitcnt(0xC47F);   // lgkmcnt(4): hi tiles of this group
+                __builtin_amdgcn_sched_barrier(0);
+                uint32_t keep = 0;
+                b_steps<GB, 0>(chb, acc, cur, nxt, ring, dp, keep, loaded);
             }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
-            part_b<GB + 1>(chb, acc, cur, ring, more, chn, nextb, mask, c, slope);
+            part_b<GB + 1>(chb, acc, cur, ring, dp, more, chn, nextb, mask, c, slope);
         }
     }
 
@@ -213,19 +272,22 @@ struct SplitPhase {
                                                uint8_t* mask, float slope, int g) {
         Pair cur[4];
         load_pairs<0>(cur, ring);
+        DmaPieces dp;
+        dp.src = DmaSrc{nullptr, 0u};
+        dp.dst = 0;
         f32x4 ch[3][CT];
         Blk chb[CB];
         init_chunk(ch, biasA, 0, g);
-        part_a<0>(xin, ch, cur, ring);
+        part_a<0>(xin, ch, cur, ring, dp);
         epilogue(ch, chb, mask, 0, slope);
         for (int c = 0; c < NC; ++c) {
             const bool more = c + 1 < NC;
             Blk nextb[CB];
             if (more) {
                 init_chunk(ch, biasA, c + 1, g);
-                part_a<0>(xin, ch, cur, ring);
+                part_a<0>(xin, ch, cur, ring, dp);
             }
-            part_b<0>(chb, acc, cur, ring, more, ch, nextb, mask, c, slope);
+            part_b<0>(chb, acc, cur, ring, dp, more, ch, nextb, mask, c, slope);
 #pragma unroll
             for (int b = 0; b < CB; ++b) chb[b] = nextb[b];
         }

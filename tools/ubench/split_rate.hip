@@ -24,15 +24,27 @@ __device__ __forceinline__ void piece(R& r) {
 }
 
 // T0 = pair index (8 pairs = 16 tiles per slot)
+template <int TP, int MODE>
+__device__ __forceinline__ void load_pair(f16x8& h, f16x8& l, R& r);
+
 template <int T0, int MODE>
 __device__ __forceinline__ void load_group(f16x8 (&h)[4], f16x8 (&l)[4], R& r) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int t = (2 * (T0 + i)) % 16;
+    load_pair<T0, MODE>(h[0], l[0], r);
+    load_pair<T0 + 1, MODE>(h[1], l[1], r);
+    load_pair<T0 + 2, MODE>(h[2], l[2], r);
+    load_pair<T0 + 3, MODE>(h[3], l[3], r);
+}
+
+template <int TP, int MODE>
+__device__ __forceinline__ void load_pair(f16x8& hh, f16x8& ll, R& r) {
+    f16x8 h[1], l[1];
+    {
+        constexpr int i = 0;
+        const int t = (2 * TP) % 16;
         if ((MODE & 16) && t == 0) r.cur = (r.cur == 4) ? 0 : r.cur + 1;
         if (t == 8) {
-            if (MODE & 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            if (MODE & 4) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+            if ((MODE & 8) && !(MODE & 128)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if ((MODE & 4) && (!(MODE & 64) || (r.next & 1))) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
             if (MODE & 8) {
                 r.src = r.g + (size_t)r.next * 16384 + r.wave * 4096 + r.lane * 16;
                 r.dst = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(r.smem) + ((r.cur == 0) ? 4 : r.cur - 1) * 16384 + r.wave * 4096;
@@ -43,6 +55,7 @@ __device__ __forceinline__ void load_group(f16x8 (&h)[4], f16x8 (&l)[4], R& r) {
         h[i] = *(const f16x8*)(r.smem + r.cur * 16384 + t * 1024 + r.lane * 16);
         l[i] = *(const f16x8*)(r.smem + r.cur * 16384 + (t + 1) * 1024 + r.lane * 16);
     }
+    hh = h[0]; ll = l[0];
 }
 
 template <int GI, int MODE>
@@ -51,7 +64,7 @@ __device__ __forceinline__ void groups(const f16x8 (&xh)[16], const f16x8 (&xl)[
                                        R& smem, int lane, int c, int nc) {
     if constexpr (GI < 16) {
         f16x8 nh[4], nl[4];
-        if (GI + 1 < 16 || c + 1 < nc) load_group<((GI + 1) * 4) % 64, MODE>(nh, nl, smem);
+        if (!(MODE & 256)) { if (GI + 1 < 16 || c + 1 < nc) load_group<((GI + 1) * 4) % 64, MODE>(nh, nl, smem); }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (GI < 8) {           // part A: 2 k-blocks x 2 tiles per group
 #pragma unroll
@@ -61,7 +74,8 @@ __device__ __forceinline__ void groups(const f16x8 (&xh)[16], const f16x8 (&xl)[
                     ch[ci] = mf(ch_[k2 * 2 + ci], xh[2 * GI + k2], ch[ci]);
                     ch[ci] = mf(ch_[k2 * 2 + ci], xl[2 * GI + k2], ch[ci]);
                     ch[ci] = mf(cl_[k2 * 2 + ci], xh[2 * GI + k2], ch[ci]);
-                    if (MODE & 8) piece(smem);
+                    if (MODE & 256) { __builtin_amdgcn_sched_barrier(0); if (k2 * 2 + ci == 0) load_pair<((GI + 1) * 4) % 64, MODE>(nh[0], nl[0], smem); if (k2 * 2 + ci == 1) load_pair<((GI + 1) * 4) % 64 + 1, MODE>(nh[1], nl[1], smem); if (k2 * 2 + ci == 2) load_pair<((GI + 1) * 4) % 64 + 2, MODE>(nh[2], nl[2], smem); if (k2 * 2 + ci == 3) load_pair<((GI + 1) * 4) % 64 + 3, MODE>(nh[3], nl[3], smem); __builtin_amdgcn_sched_barrier(0); }
+                    if ((MODE & 8) && (!(MODE & 32) || ci == 0)) piece(smem);
                 }
             if constexpr (GI == 7 && (MODE & 1) == 0) {
                 // epilogue: activation + split into fp16 hi / lo, packed as the next B operand
@@ -85,7 +99,8 @@ __device__ __forceinline__ void groups(const f16x8 (&xh)[16], const f16x8 (&xl)[
                 acc[nb] = mf(ch_[t], chh[0], acc[nb]);
                 acc[nb] = mf(ch_[t], chl[0], acc[nb]);
                 acc[nb] = mf(cl_[t], chh[0], acc[nb]);
-                if (MODE & 8) piece(smem);
+                if (MODE & 256) { __builtin_amdgcn_sched_barrier(0); if (t == 0) load_pair<((GI + 1) * 4) % 64, MODE>(nh[0], nl[0], smem); if (t == 1) load_pair<((GI + 1) * 4) % 64 + 1, MODE>(nh[1], nl[1], smem); if (t == 2) load_pair<((GI + 1) * 4) % 64 + 2, MODE>(nh[2], nl[2], smem); if (t == 3) load_pair<((GI + 1) * 4) % 64 + 3, MODE>(nh[3], nl[3], smem); __builtin_amdgcn_sched_barrier(0); }
+                if ((MODE & 8) && (!(MODE & 32) || (t & 1) == 0)) piece(smem);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -149,5 +164,18 @@ int main() {
     run<1 + 16 + 8>("no epi + rot + DMA/slot", out, cyc);
     run<1 + 16 + 4 + 8>("no epi + rot + barrier + DMA", out, cyc);
     run<16 + 4 + 8>("epilogue + rot + barrier + DMA", out, cyc);
+    run<16 + 4 + 8 + 32>("  + spread pieces", out, cyc);
+    run<16 + 4 + 8 + 64>("  + barrier every 2nd slot", out, cyc);
+    run<16 + 4 + 8 + 128>("  + no vmcnt wait", out, cyc);
+    run<16 + 4 + 8 + 32 + 64>("  + spread + barrier/2", out, cyc);
+    run<16 + 4 + 8 + 32 + 64 + 128>("  + spread + barrier/2 + no vmcnt", out, cyc);
+    run<16 + 4 + 8 + 256>("  + interleaved reads", out, cyc);
+    run<16 + 4 + 8 + 256 + 32>("  + interleaved reads + spread", out, cyc);
+    run<16 + 4 + 256>("epilogue + rot + barrier, interleaved", out, cyc);
+    run<16 + 256>("epilogue + rot, interleaved", out, cyc);
+    run<16>("epilogue + rot only", out, cyc);
+    run<16 + 8>("epilogue + rot + DMA", out, cyc);
+    run<16 + 8 + 32>("epilogue + rot + DMA spread", out, cyc);
+    run<16 + 4>("epilogue + rot + barrier", out, cyc);
     return 0;
 }
