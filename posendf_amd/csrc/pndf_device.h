@@ -64,26 +64,28 @@ struct Ring {
 // degrades every `s_waitcnt lgkmcnt(N)` of the tile prefetch to lgkmcnt(0), which serialises ds_read and
 // MFMA.  Consequence (cdna_hip_programming.md 5.7): the compiler does not count these loads, so every
 // consumer-side barrier is preceded by an explicit `s_waitcnt vmcnt(0)`.
-// One 1-KiB piece (tile 4*wave + j of the slot).  Piece 0 saves M0 and points it at the wave's LDS window,
-// piece 3 restores it; pieces 1..3 reuse it (the instruction offset moves both the global and the LDS address).
-// Between the pieces only MFMAs, ds_reads and waits are issued -- none of them touches M0 on gfx950 -- and
-// with one wave per SIMD every SALU instruction saved here is ~4 issue cycles of the critical path.
+// One 1-KiB piece (tile 4*wave + j of the slot).  Piece 0 points M0 at the wave's LDS window, pieces 1..3 reuse
+// it (the instruction offset moves both the global and the LDS address).
 // Addressing: SGPR base (the stream pointer) + one 32-bit VGPR byte offset -- measured 21 issue cycles per piece
 // between MFMAs against 30 for the 64-bit-VGPR-address form (tools/ubench/dma_cost.hip).
 struct DmaSrc {
     const char* base;      // uniform
     uint32_t off;          // per lane: slot * SLOT_BYTES + wave * 4 KiB + lane * 16
 };
-__device__ __forceinline__ void ring_dma_piece(const DmaSrc& src, uint32_t dst, int j, uint32_t& keep) {
+// M0 is declared clobbered and never restored: hipcc treats M0 as a reserved scratch register that it sets right
+// before each of its own uses (there is none in these kernels), so saving / restoring it only costs issue slots --
+// and with one wave per SIMD every SALU instruction is ~4 cycles of the critical path.  Pieces 1..3 rely on M0 still
+// holding piece 0's value: between them only MFMAs, ds_reads, VALU and waits are issued.
+__device__ __forceinline__ void ring_dma_piece(const DmaSrc& src, uint32_t dst, int j) {
     if (j == 0)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     : "=&s"(keep) : "v"(src.off), "s"(src.base), "s"(dst) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     : : "v"(src.off), "s"(src.base), "s"(dst) : "memory", "m0");
     else if (j == 1)
         asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(src.off), "s"(src.base) : "memory");
     else if (j == 2)
         asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(src.off), "s"(src.base) : "memory");
     else
-        asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072\n\ts_mov_b32 m0, %2" : : "v"(src.off), "s"(src.base), "s"(keep) : "memory");
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(src.off), "s"(src.base) : "memory");
 }
 
 // source / destination of this wave's share of the next slot to fetch; advances r.next
@@ -99,9 +101,8 @@ __device__ __forceinline__ void ring_dma(Ring& r, int buf) {
     DmaSrc src;
     uint32_t dst;
     ring_dma_begin(r, buf, src, dst);
-    uint32_t keep = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ring_dma_piece(src, dst, j, keep);
+    for (int j = 0; j < 4; ++j) ring_dma_piece(src, dst, j);
 }
 
 __device__ __forceinline__ void ring_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -46,7 +46,6 @@ struct PhaseBody {
             uint32_t ddst = 0;
             if (MID && loaded) ring_dma_begin(ring, ring_fill_buffer(ring), dsrc, ddst);
             int piece = 0;
-            uint32_t m0keep = 0;
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE this group's MFMAs
             if constexpr (GI < NGA) {
                 // ---- part A: two k-tiles of the chunk rows; tile order (kt, ci)
@@ -59,7 +58,7 @@ struct PhaseBody {
                             ch[ci] = mfma4(cur[k2 * CT + ci][s], xin[2 * GI + k2][s], ch[ci]);
                         if (MID && s < 2 && loaded) {      // 2 k-tiles x 2 = 4 pieces
                             __builtin_amdgcn_sched_barrier(0);
-                            ring_dma_piece(dsrc, ddst, piece++, m0keep);
+                            ring_dma_piece(dsrc, ddst, piece++);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -119,7 +118,7 @@ struct PhaseBody {
                             acc[2 * nbp + h] = mfma4(cur[ci * 2 + h][s], ch[ci][s], acc[2 * nbp + h]);
                         if (MID && ci < 2 && s < 2 && loaded) {   // 4 pieces
                             __builtin_amdgcn_sched_barrier(0);
-                            ring_dma_piece(dsrc, ddst, piece++, m0keep);
+                            ring_dma_piece(dsrc, ddst, piece++);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }

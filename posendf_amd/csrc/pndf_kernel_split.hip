@@ -76,22 +76,20 @@ __device__ __forceinline__ void dma_begin(DmaPieces& d, Ring& ring, bool loaded)
 }
 // The four pieces of a slot fetch are spread over the two tile groups that follow the barrier: pieces 0, 1 in the
 // group that ran the mid-slot events (TN == 8), pieces 2, 3 in the next one (TN == 0, same phase by construction:
-// a phase starts on a slot boundary and fetches are only begun when a next group exists).  Each group saves M0,
-// issues its two pieces two MFMAs apart and restores M0 -- nothing in between touches M0.
+// a phase starts on a slot boundary and fetches are only begun when a next group exists).  Each group sets M0 for
+// its first piece; the second one, two MFMAs later, reuses it (M0: see ring_dma_piece).
 template <int TN, bool SECOND>
-__device__ __forceinline__ void dma_step(const DmaPieces& d, uint32_t& keep) {
+__device__ __forceinline__ void dma_step(const DmaPieces& d) {
     if constexpr (TN == SLOT_TILES / 2 && !SECOND)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     : "=&s"(keep) : "v"(d.src.off), "s"(d.src.base), "s"(d.dst) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     : : "v"(d.src.off), "s"(d.src.base), "s"(d.dst) : "memory", "m0");
     else if constexpr (TN == SLOT_TILES / 2 && SECOND)
-        asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024\n\ts_mov_b32 m0, %2"
-                     : : "v"(d.src.off), "s"(d.src.base), "s"(keep) : "memory");
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(d.src.off), "s"(d.src.base) : "memory");
     else if constexpr (TN == 0 && !SECOND)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048"
-                     : "=&s"(keep) : "v"(d.src.off), "s"(d.src.base), "s"(d.dst) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048"
+                     : : "v"(d.src.off), "s"(d.src.base), "s"(d.dst) : "memory", "m0");
     else
-        asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072\n\ts_mov_b32 m0, %2"
-                     : : "v"(d.src.off), "s"(d.src.base), "s"(keep) : "memory");
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(d.src.off), "s"(d.src.base) : "memory");
 }
 
 // What follows MFMA J (0..11) of a group, for the group after it (first tile TN of its slot):
@@ -102,7 +100,7 @@ __device__ __forceinline__ void dma_step(const DmaPieces& d, uint32_t& keep) {
 // their bursts at once and sat in the LDS queue with an empty MFMA pipe (tools/ubench/split_rate.hip: barrier cost
 // 150 -> 33 cycles per slot).
 template <int TN, int J>
-__device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, uint32_t& keep, bool loaded) {
+__device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, bool loaded) {
     if constexpr (J == 0) {
         if (loaded) {
             if constexpr (TN == 0) ring_boundary(ring);
@@ -115,7 +113,7 @@ __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, 
     } else if constexpr (J < 8) {
         if (loaded) nxt[J - 4].l = __builtin_bit_cast(f16x8, ring_tile(ring, TN + 2 * (J - 4) + 1));
     } else if constexpr (J == 9 || J == 11) {
-        if (TN == 0 || loaded) dma_step<TN, J == 11>(dp, keep);
+        if (TN == 0 || loaded) dma_step<TN, J == 11>(dp);
     }
 }
 
@@ -132,7 +130,7 @@ struct SplitPhase {
     // dependent MFMAs far apart; they are summed in the epilogue.
     template <int GA, int M>
     static __device__ __forceinline__ void a_steps(const Blk (&xin)[KA2], f32x4 (&ch)[3][CT], const Pair (&cur)[4],
-                                                   Pair (&nxt)[4], Ring& ring, DmaPieces& dp, uint32_t& keep) {
+                                                   Pair (&nxt)[4], Ring& ring, DmaPieces& dp) {
         if constexpr (M < 12) {
             constexpr int term = M / 4, i = M % 4, pi = 4 * GA + i, kb = pi / CT, ci = pi % CT;
             constexpr int TN = (8 * (GA + 1)) % SLOT_TILES;
@@ -141,9 +139,9 @@ struct SplitPhase {
             const f16x8 x = (term == 1) ? xin[kb].l : xin[kb].h;
             ch[term][ci] = mf16(w, x, ch[term][ci]);
             __builtin_amdgcn_sched_barrier(0);
-            feed<TN, M>(nxt, ring, dp, keep, true);     // part B follows, so there is always a next group
+            feed<TN, M>(nxt, ring, dp, true);     // part B follows, so there is always a next group
             __builtin_amdgcn_sched_barrier(0);
-            a_steps<GA, M + 1>(xin, ch, cur, nxt, ring, dp, keep);
+            a_steps<GA, M + 1>(xin, ch, cur, nxt, ring, dp);
         }
     }
     template <int GA>
@@ -153,8 +151,7 @@ struct SplitPhase {
             Pair nxt[4];
             __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt(4): this group's hi tiles
             __builtin_amdgcn_sched_barrier(0);
-            uint32_t keep = 0;
-            a_steps<GA, 0>(xin, ch, cur, nxt, ring, dp, keep);
+            a_steps<GA, 0>(xin, ch, cur, nxt, ring, dp);
 #pragma unroll
             for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
             part_a<GA + 1>(xin, ch, cur, ring, dp);
@@ -206,7 +203,7 @@ struct SplitPhase {
     // interleaved with these MFMAs by the compiler instead of stalling the pipe (that group keeps the burst prefetch).
     template <int GB, int M>
     static __device__ __forceinline__ void b_steps(const Blk (&chb)[CB], f32x4 (&acc)[NB], const Pair (&cur)[4],
-                                                   Pair (&nxt)[4], Ring& ring, DmaPieces& dp, uint32_t& keep, bool loaded) {
+                                                   Pair (&nxt)[4], Ring& ring, DmaPieces& dp, bool loaded) {
         if constexpr (M < 12) {
             constexpr int term = M / 4, i = M % 4, pi = 4 * GB + i, nb = pi / CB, b = pi % CB;
             constexpr int TN = (A_TILES + 8 * (GB + 1)) % SLOT_TILES;
@@ -218,9 +215,9 @@ struct SplitPhase {
             const f16x8 x = (term == 1) ? chb[b].l : chb[b].h;
             acc[nb] = mf16(w, x, acc[nb]);
             __builtin_amdgcn_sched_barrier(0);
-            feed<TN, M>(nxt, ring, dp, keep, loaded);
+            feed<TN, M>(nxt, ring, dp, loaded);
             __builtin_amdgcn_sched_barrier(0);
-            b_steps<GB, M + 1>(chb, acc, cur, nxt, ring, dp, keep, loaded);
+            b_steps<GB, M + 1>(chb, acc, cur, nxt, ring, dp, loaded);
         }
     }
     template <int GB>
@@ -232,7 +229,6 @@ struct SplitPhase {
             constexpr int TN = (A_TILES + 8 * (GB + 1)) % SLOT_TILES;
             const bool loaded = (GB + 1 < BG) || more;
             if constexpr (GB == 0) {
-                uint32_t keep0 = 0;
                 if (loaded) load_pairs<TN>(nxt, ring);
                 dma_begin<TN>(dp, ring, loaded);
                 if (loaded) __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8)
@@ -248,8 +244,8 @@ struct SplitPhase {
                         acc[nb] = mf16(w, x, acc[nb]);
                         if (term == 2 && (i & 1) && (TN == 0 || loaded)) {
                             __builtin_amdgcn_sched_barrier(0);
-                            if (i == 1) dma_step<TN, false>(dp, keep0);
-                            else dma_step<TN, true>(dp, keep0);
+                            if (i == 1) dma_step<TN, false>(dp);
+                            else dma_step<TN, true>(dp);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -259,8 +255,7 @@ struct SplitPhase {
             } else {
                 if (loaded) __builtin_amdgcn_s_waitcnt(0xC47F);   // lgkmcnt(4): hi tiles of this group
                 __builtin_amdgcn_sched_barrier(0);
-                uint32_t keep = 0;
-                b_steps<GB, 0>(chb, acc, cur, nxt, ring, dp, keep, loaded);
+                b_steps<GB, 0>(chb, acc, cur, nxt, ring, dp, loaded);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) cur[i] = nxt[i];

@@ -22,16 +22,23 @@ def main():
     cfg = amass_config("lrelu", "cuda:0")
     cfg["engine"] = {"precision": prec}
     net = PoseNDF(cfg)
-    cyc_per_tile = 128 if prec == "fp32" else 15        # fp32: 4 MFMAs x 32 cycles; f16x3: 1.5 MFMAs x ~10
+    cyc_per_tile = 128 if prec == "fp32" else 24        # fp32: 4 MFMAs x 32 cycles; f16x3: 1.5 MFMAs x 16
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(0, 2.0, 0.1).items()})
     q = torch.from_numpy(synth.make_poses(B, seed=1)).cuda()
     eng = net._engine_for(q.device)
     R = eng.lib.pndf_debug_timing_regions()
     cyc = torch.zeros((B // 64) * 4 * R, dtype=torch.int64, device="cuda")
     out = torch.empty_like(q)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     rc = eng.lib.pndf_debug_project_timing(eng.handle, q.data_ptr(), out.data_ptr(), B, steps, cyc.data_ptr(), 0)
+    e1.record()
     assert rc == 0
     torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    rounds = -(-(B // 64) // 256)
+    print(f"instrumented launch {ms:.2f} ms for {steps} steps, {rounds} workgroup rounds per CU -> effective shader clock "
+          f"{cyc.cpu().numpy().reshape(-1, R)[:, :12].sum(1).mean() * rounds / (ms * 1e-3) / 1e9:.2f} GHz")
     call = cyc.cpu().numpy().reshape(-1, R).astype(np.float64) / steps
     c = call[:, :12]
     mean = c.mean(0)
