@@ -432,11 +432,14 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
         const float z7 = part + lds_bias[BIAS_OFF[6]];
         dval = fmaxf(z7, 0.f);
         if (args.mode == MODE_FORWARD) break;
-        float gz7 = (z7 > 0.f) ? 1.f : 0.f;
+        const float gz7 = (z7 > 0.f) ? 1.f : 0.f;
+        // grad_outputs scale the RESULT, not the seed of the backward pass: the pass is linear in the seed, and a
+        // seed of 1e-7 (or 1e+6: motion_denoise.py's 1e7 * c^2 weight) would leave the fp16 range of the operands
+        float gscale = 1.f;
         if (args.mode == MODE_FORWARD_GRAD && args.grad_out) {
             long long pidx = pose0 + wp;
             if (pidx >= args.B) pidx = args.B - 1;
-            gz7 *= args.grad_out[pidx];
+            gscale = args.grad_out[pidx];
         }
 
         // ---------------- trunk backward
@@ -507,7 +510,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float dq = gv[c] / denom[c] - qv[c] * kk[c];
-                    o[c] = (args.mode == MODE_PROJECT) ? __fsub_rn(qv[c], __fmul_rn(dval, dq)) : dq;
+                    o[c] = (args.mode == MODE_PROJECT) ? __fsub_rn(qv[c], __fmul_rn(dval, dq)) : dq * gscale;
                 }
                 *(f32x4*)(my_q + 4 * j) = o;
             }

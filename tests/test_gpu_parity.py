@@ -285,3 +285,20 @@ def test_nonfinite_pose_stays_in_its_row(torch_cuda, precision):
     keep[37] = False
     assert torch.equal(got_q[keep], clean_q[keep]) and torch.equal(got_d[keep], clean_d[keep])
     assert not torch.isfinite(got_q[37]).all()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("scale", [1e-9, 3e5])
+def test_grad_outputs_scale_is_harmless(torch_cuda, precision, scale):
+    """dist.backward(gradient=s): the input gradient is s times the unit one for any s -- also for scales that
+    would leave the fp16 operand range of the split kernel if they seeded the backward pass
+    (motion_denoise.py:31 weights the prior by 1e7 * c^2)."""
+    torch = torch_cuda
+    from posendf_amd import synth
+    net = make_net(torch, "lrelu", "live", precision=precision)
+    q = torch.from_numpy(synth.make_poses(200, seed=12)).cuda().requires_grad_(True)
+    d = net(q, train=False)["dist_pred"]
+    (unit,) = torch.autograd.grad(d, q, grad_outputs=torch.ones_like(d), retain_graph=True)
+    (scaled,) = torch.autograd.grad(d, q, grad_outputs=torch.full_like(d, scale))
+    assert torch.isfinite(scaled).all()
+    assert rel_err((scaled / scale).cpu().numpy(), unit.cpu().numpy()) < 1e-6
