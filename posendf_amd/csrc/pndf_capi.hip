@@ -34,6 +34,8 @@ extern "C" __global__ void pndf_fused_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_softplus_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_split_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_split_relu_kernel_timing(PndfKernelArgs args);
+extern "C" __global__ void pndf_fused_half_relu_kernel(PndfKernelArgs args);
+extern "C" __global__ void pndf_fused_half_relu_kernel_timing(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_relu_kernel_timing(PndfKernelArgs args);
 extern "C" int pndf_kernel_timing_regions();
 extern "C" long long pndf_kernel_softplus_scratch_floats_per_wg();
@@ -96,9 +98,9 @@ static int check_config(pndf_engine* h, const pndf_config* cfg) {
         return fail(h, PNDF_ERR_UNSUPPORTED, "unknown activation (relu, lrelu and softplus are implemented)");
     if (cfg->act == PNDF_ACT_SOFTPLUS && !(cfg->beta > 0.f))
         return fail(h, PNDF_ERR_BAD_ARG, "softplus beta must be positive");
-    if (cfg->precision != PNDF_PREC_FP32 && cfg->precision != PNDF_PREC_F16X3)
-        return fail(h, PNDF_ERR_UNSUPPORTED, "unknown precision (fp32 and f16x3 are implemented)");
-    if (cfg->precision == PNDF_PREC_F16X3 && cfg->act == PNDF_ACT_SOFTPLUS)
+    if (cfg->precision != PNDF_PREC_FP32 && cfg->precision != PNDF_PREC_F16X3 && cfg->precision != PNDF_PREC_F16)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "unknown precision (fp32, f16x3 and f16 are implemented)");
+    if (cfg->precision != PNDF_PREC_FP32 && cfg->act == PNDF_ACT_SOFTPLUS)
         return fail(h, PNDF_ERR_UNSUPPORTED, "the split-precision kernel implements relu / lrelu; softplus runs in fp32");
     return PNDF_OK;
 }
@@ -127,6 +129,10 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
         e = hipFuncSetAttribute((const void*)pndf_fused_split_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_split_relu_kernel_timing, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)pndf_fused_half_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)pndf_fused_half_relu_kernel_timing, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_softplus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
@@ -311,7 +317,7 @@ extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, con
     if (!h) return PNDF_ERR_BAD_ARG;
     if (const char* why = check_tensors(tensors, numel, n_tensors)) return fail(h, PNDF_ERR_BAD_SHAPE, why);
     std::vector<float> stream((size_t)STEP_TILES * TILE_FLOATS), bias(BIAS_FLOATS);
-    const int prc = (h->cfg.precision == PNDF_PREC_F16X3)
+    const int prc = (h->cfg.precision != PNDF_PREC_FP32)
                         ? pndf_pack_host_split(tensors, numel, n_tensors, stream.data(), bias.data())
                         : pndf_pack_host(tensors, numel, n_tensors, stream.data(), bias.data());
     if (prc != PNDF_OK)
@@ -370,9 +376,11 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
         HIP_TRY(h, hipGetLastError());
         return PNDF_OK;
     }
-    const bool split = h->cfg.precision == PNDF_PREC_F16X3;
-    if (split && dbg && !timing) return fail(h, PNDF_ERR_UNSUPPORTED, "the stage-dump kernel exists for fp32 precision only");
-    if (split && timing) hipLaunchKernelGGL(pndf_fused_split_relu_kernel_timing, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+    const bool split = h->cfg.precision == PNDF_PREC_F16X3, half = h->cfg.precision == PNDF_PREC_F16;
+    if ((split || half) && dbg && !timing) return fail(h, PNDF_ERR_UNSUPPORTED, "the stage-dump kernel exists for fp32 precision only");
+    if (half && timing) hipLaunchKernelGGL(pndf_fused_half_relu_kernel_timing, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+    else if (half) hipLaunchKernelGGL(pndf_fused_half_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+    else if (split && timing) hipLaunchKernelGGL(pndf_fused_split_relu_kernel_timing, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else if (split) hipLaunchKernelGGL(pndf_fused_split_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else if (timing) hipLaunchKernelGGL(pndf_fused_relu_kernel_timing, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else if (dbg) hipLaunchKernelGGL(pndf_fused_relu_kernel_dbg, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);

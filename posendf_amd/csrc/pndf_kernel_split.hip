@@ -31,7 +31,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // (a, b) -> packed fp16 pairs: hi = rtz(a, b) (one v_cvt_pkrtz), lo = rne(a - hi_a, b - hi_b).  The remainders
 // are exact in fp32; rounding lo to NEAREST keeps the residual error unbiased (+-2^-23 relative) -- with a
 // truncated lo the error of a 1024-term contraction accumulates linearly instead of as a random walk.
+template <bool SINGLE>
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    if constexpr (SINGLE) {        // plain fp16 operands: round to nearest, no lo part
+        f16x2 r;
+        r[0] = (_Float16)a;
+        r[1] = (_Float16)b;
+        hi = __builtin_bit_cast(unsigned, r);
+        lo = 0u;
+        return;
+    }
     const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
     hi = __builtin_bit_cast(unsigned, h);
     f16x2 l;
@@ -41,12 +50,13 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 }
 
 // two activated fp32 C/D tiles -> the B operand of the k-block they form (8 halfs = 4 dwords, hi and lo)
+template <bool SINGLE = false>
 __device__ __forceinline__ void pack_blk(const f32x4& t0, const f32x4& t1, Blk& o) {
     unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-    split2(t0[0], t0[1], h0, l0);
-    split2(t0[2], t0[3], h1, l1);
-    split2(t1[0], t1[1], h2, l2);
-    split2(t1[2], t1[3], h3, l3);
+    split2<SINGLE>(t0[0], t0[1], h0, l0);
+    split2<SINGLE>(t0[2], t0[3], h1, l1);
+    split2<SINGLE>(t1[0], t1[1], h2, l2);
+    split2<SINGLE>(t1[2], t1[3], h3, l3);
     o.h = __builtin_bit_cast(f16x8, u32x4{h0, h1, h2, h3});
     o.l = __builtin_bit_cast(f16x8, u32x4{l0, l1, l2, l3});
 }
@@ -118,7 +128,7 @@ __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, 
 }
 
 // ------------------------------------------------------------------ one fused layer pair, split precision
-template <int KA2, int CT, int NC, int NB, bool BWD>
+template <int KA2, int CT, int NC, int NB, bool BWD, bool SINGLE = false>
 struct SplitPhase {
     static constexpr int CB = CT / 2;                 // k-blocks of part B per chunk
     static constexpr int AP = KA2 * CT, BP = NB * CB; // pairs per chunk
@@ -186,7 +196,7 @@ struct SplitPhase {
             }
         }
 #pragma unroll
-        for (int b = 0; b < CB; ++b) pack_blk(y[2 * b], y[2 * b + 1], out[b]);
+        for (int b = 0; b < CB; ++b) pack_blk<SINGLE>(y[2 * b], y[2 * b + 1], out[b]);
     }
 
     static __device__ __forceinline__ void init_chunk(f32x4 (&ch)[3][CT], const float* biasA, int c, int g) {
@@ -289,8 +299,139 @@ struct SplitPhase {
     }
 };
 
+
+// ------------------------------------------------------------------ one fused layer pair, plain fp16 operands
+// Single-term variant (precision "f16", NOT parity grade: operands rounded to 11 bits): the same stream, chunking and
+// ring as SplitPhase, but only the hi tile of every weight pair is read and one MFMA is issued per product block.
+// A group is one whole slot (16 stream tiles = 8 hi tiles = 8 MFMAs), so the ring events sit at fixed positions:
+// slot boundary behind MFMA 0, mid-slot wait + barrier behind MFMA 4, the slot fetch's four pieces behind MFMAs 4..7.
+__device__ __forceinline__ void load_half(f16x8 (&a)[8], Ring& ring) {     // burst form (phase start, part B group 0)
+    ring_boundary(ring);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i == 4) {
+            ring_midslot_sync(ring);
+            ring_dma(ring, ring_fill_buffer(ring));
+        }
+        a[i] = __builtin_bit_cast(f16x8, ring_tile(ring, 2 * i));
+    }
+}
+template <int J>
+__device__ __forceinline__ void feed_half(f16x8 (&nxt)[8], Ring& ring, DmaPieces& dp, bool loaded) {
+    if (!loaded) return;
+    if constexpr (J == 0) ring_boundary(ring);
+    if constexpr (J == 4) {
+        ring_midslot_sync(ring);
+        ring_dma_begin(ring, ring_fill_buffer(ring), dp.src, dp.dst);
+    }
+    nxt[J] = __builtin_bit_cast(f16x8, ring_tile(ring, 2 * J));
+    if constexpr (J >= 4) ring_dma_piece(dp.src, dp.dst, J - 4);
+}
+
+template <int KA2, int CT, int NC, int NB, bool BWD>
+struct HalfPhase {
+    using Base = SplitPhase<KA2, CT, NC, NB, BWD, true>;
+    static constexpr int CB = CT / 2;
+    static constexpr int AP = KA2 * CT, BP = NB * CB;
+    static constexpr int AG = AP / 8, BG = BP / 8;
+    static_assert(AP % 8 == 0 && BP % 8 == 0, "a group is one slot = 8 weight pairs");
+
+    template <int GA, int M>
+    static __device__ __forceinline__ void a_steps(const Blk (&xin)[KA2], f32x4 (&ch)[3][CT], const f16x8 (&cur)[8],
+                                                   f16x8 (&nxt)[8], Ring& ring, DmaPieces& dp) {
+        if constexpr (M < 8) {
+            constexpr int pi = 8 * GA + M, kb = pi / CT, ci = pi % CT;
+            ch[0][ci] = mf16(cur[M], xin[kb].h, ch[0][ci]);
+            __builtin_amdgcn_sched_barrier(0);
+            feed_half<M>(nxt, ring, dp, true);
+            __builtin_amdgcn_sched_barrier(0);
+            a_steps<GA, M + 1>(xin, ch, cur, nxt, ring, dp);
+        }
+    }
+    template <int GA>
+    static __device__ __forceinline__ void part_a(const Blk (&xin)[KA2], f32x4 (&ch)[3][CT], f16x8 (&cur)[8], Ring& ring,
+                                                  DmaPieces& dp) {
+        if constexpr (GA < AG) {
+            f16x8 nxt[8];
+            a_steps<GA, 0>(xin, ch, cur, nxt, ring, dp);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+            part_a<GA + 1>(xin, ch, cur, ring, dp);
+        }
+    }
+
+    template <int GB, int M>
+    static __device__ __forceinline__ void b_steps(const Blk (&chb)[CB], f32x4 (&acc)[NB], const f16x8 (&cur)[8],
+                                                   f16x8 (&nxt)[8], Ring& ring, DmaPieces& dp, bool loaded) {
+        if constexpr (M < 8) {
+            constexpr int pi = 8 * GB + M, nb = pi / CB, b = pi % CB;
+            acc[nb] = mf16(cur[M], chb[b].h, acc[nb]);
+            __builtin_amdgcn_sched_barrier(0);
+            feed_half<M>(nxt, ring, dp, loaded);
+            __builtin_amdgcn_sched_barrier(0);
+            b_steps<GB, M + 1>(chb, acc, cur, nxt, ring, dp, loaded);
+        }
+    }
+    template <int GB>
+    static __device__ __forceinline__ void part_b(const Blk (&chb)[CB], f32x4 (&acc)[NB], f16x8 (&cur)[8], Ring& ring,
+                                                  DmaPieces& dp, bool more, f32x4 (&chn)[3][CT], Blk (&nextb)[CB],
+                                                  uint8_t* mask, int c, float slope) {
+        if constexpr (GB < BG) {
+            f16x8 nxt[8];
+            const bool loaded = (GB + 1 < BG) || more;
+            if constexpr (GB == 0) {
+                // burst prefetch + the NEXT chunk's epilogue in one scheduling region (see SplitPhase::part_b)
+                if (loaded) load_half(nxt, ring);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int nb = i / CB, b = i % CB;
+                    acc[nb] = mf16(cur[i], chb[b].h, acc[nb]);
+                }
+                if (more) Base::epilogue(chn, nextb, mask, c + 1, slope);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                b_steps<GB, 0>(chb, acc, cur, nxt, ring, dp, loaded);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+            part_b<GB + 1>(chb, acc, cur, ring, dp, more, chn, nextb, mask, c, slope);
+        }
+    }
+
+    static __device__ __forceinline__ void run(const Blk (&xin)[KA2], f32x4 (&acc)[NB], Ring& ring, const float* biasA,
+                                               uint8_t* mask, float slope, int g) {
+        f16x8 cur[8];
+        load_half(cur, ring);
+        DmaPieces dp;
+        dp.src = DmaSrc{nullptr, 0u};
+        dp.dst = 0;
+        f32x4 ch[3][CT];
+        Blk chb[CB];
+        Base::init_chunk(ch, biasA, 0, g);
+        part_a<0>(xin, ch, cur, ring, dp);
+        Base::epilogue(ch, chb, mask, 0, slope);
+        for (int c = 0; c < NC; ++c) {
+            const bool more = c + 1 < NC;
+            Blk nextb[CB];
+            if (more) {
+                Base::init_chunk(ch, biasA, c + 1, g);
+                part_a<0>(xin, ch, cur, ring, dp);
+            }
+            part_b<0>(chb, acc, cur, ring, dp, more, ch, nextb, mask, c, slope);
+#pragma unroll
+            for (int b = 0; b < CB; ++b) chb[b] = nextb[b];
+        }
+    }
+};
+
+template <int TERMS, int KA2, int CT, int NC, int NB, bool BWD>
+struct PhaseSel { using type = SplitPhase<KA2, CT, NC, NB, BWD, false>; };
+template <int KA2, int CT, int NC, int NB, bool BWD>
+struct PhaseSel<1, KA2, CT, NC, NB, BWD> { using type = HalfPhase<KA2, CT, NC, NB, BWD>; };
+
 // activation of an accumulator layer + split into the next phase's B operands; sign bits in registers
-template <int NT>
+template <int NT, bool SINGLE = false>
 __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 2], uint32_t (&m)[(NT * 4 + 31) / 32], float slope) {
     constexpr int NW = (NT * 4 + 31) / 32;
     float lo[NW], hi[NW];
@@ -306,7 +447,7 @@ __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 
             if (b < 16) lo[w] = fmaf(st, (float)(1u << b), lo[w]);
             else hi[w] = fmaf(st, (float)(1u << (b - 16)), hi[w]);
         }
-        if (t & 1) pack_blk(x[t - 1], x[t], out[t / 2]);
+        if (t & 1) pack_blk<SINGLE>(x[t - 1], x[t], out[t / 2]);
     }
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -315,21 +456,22 @@ __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 
     }
 }
 
-template <int NT>
+template <int NT, bool SINGLE = false>
 __device__ __forceinline__ void dact_split_tiles(f32x4 (&gx)[NT], Blk (&out)[NT / 2], const uint32_t (&m)[(NT * 4 + 31) / 32], float slope) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             gx[t][r] = gx[t][r] * relu_factor((float)((m[(t * 4 + r) / 32] >> ((t * 4 + r) % 32)) & 1u), slope);
-        if (t & 1) pack_blk(gx[t - 1], gx[t], out[t / 2]);
+        if (t & 1) pack_blk<SINGLE>(gx[t - 1], gx[t], out[t / 2]);
     }
 }
 
 }  // namespace
 
-template <bool TIMING>
+template <bool TIMING, int TERMS>
 __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args) {
+    constexpr bool SG = (TERMS == 1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -396,27 +538,27 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
                 Blk b0[4];
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
-                    pack_blk(*(const f32x4*)(my_f + 32 * kb + 4 * g), *(const f32x4*)(my_f + 32 * kb + 16 + 4 * g), b0[kb]);
+                    pack_blk<SG>(*(const f32x4*)(my_f + 32 * kb + 4 * g), *(const f32x4*)(my_f + 32 * kb + 16 + 4 * g), b0[kb]);
                 tick<TIMING>(rc, 0);
                 f32x4 x2[32];
                 load_bias<32>(x2, lds_bias + BIAS_OFF[1], g);
-                SplitPhase<4, 2, 8, 32, false>::run(b0, x2, ring, lds_bias + BIAS_OFF[0], lds_mask + MASK_BASE[0] * WG_THREADS, slope, g);
+                PhaseSel<TERMS, 4, 2, 8, 32, false>::type::run(b0, x2, ring, lds_bias + BIAS_OFF[0], lds_mask + MASK_BASE[0] * WG_THREADS, slope, g);
                 tick<TIMING>(rc, 1);
-                act_split_tiles<32>(x2, b2, m2, slope);
+                act_split_tiles<32, SG>(x2, b2, m2, slope);
                 tick<TIMING>(rc, 2);
             }
             f32x4 x4[32];
             load_bias<32>(x4, lds_bias + BIAS_OFF[3], g);
-            SplitPhase<16, 2, 32, 32, false>::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, slope, g);
+            PhaseSel<TERMS, 16, 2, 32, 32, false>::type::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, slope, g);
             tick<TIMING>(rc, 3);
-            act_split_tiles<32>(x4, b4, m4, slope);
+            act_split_tiles<32, SG>(x4, b4, m4, slope);
             tick<TIMING>(rc, 4);
         }
         load_bias<4>(x6, lds_bias + BIAS_OFF[5], g);
-        SplitPhase<16, 4, 4, 4, false>::run(b4, x6, ring, lds_bias + BIAS_OFF[4], lds_mask + MASK_BASE[2] * WG_THREADS, slope, g);
+        PhaseSel<TERMS, 16, 4, 4, 4, false>::type::run(b4, x6, ring, lds_bias + BIAS_OFF[4], lds_mask + MASK_BASE[2] * WG_THREADS, slope, g);
         tick<TIMING>(rc, 5);
         Blk b6[2];
-        act_split_tiles<4>(x6, b6, m6, slope);      // b6 unused forward; x6 (fp32) feeds lin6
+        act_split_tiles<4, SG>(x6, b6, m6, slope);      // b6 unused forward; x6 (fp32) feeds lin6
 
         // ---------------- lin6 (64 -> 1) + output ReLU, fp32 on the VALU
         f32x4 w6[4];
@@ -454,25 +596,25 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
 #pragma unroll
                         for (int t = 0; t < 4; ++t) g6[t] = w6[t] * gz7;
                         Blk gb6[2];
-                        dact_split_tiles<4>(g6, gb6, m6, slope);
+                        dact_split_tiles<4, SG>(g6, gb6, m6, slope);
                         tick<TIMING>(rc, 6);
                         f32x4 g4[32];
 #pragma unroll
                         for (int t = 0; t < 32; ++t) g4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        SplitPhase<2, 4, 4, 32, true>::run(gb6, g4, ring, nullptr, lds_mask + MASK_BASE[2] * WG_THREADS, slope, g);
-                        dact_split_tiles<32>(g4, gb4, m4, slope);
+                        PhaseSel<TERMS, 2, 4, 4, 32, true>::type::run(gb6, g4, ring, nullptr, lds_mask + MASK_BASE[2] * WG_THREADS, slope, g);
+                        dact_split_tiles<32, SG>(g4, gb4, m4, slope);
                         tick<TIMING>(rc, 7);
                     }
                     f32x4 g2[32];
 #pragma unroll
                     for (int t = 0; t < 32; ++t) g2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    SplitPhase<16, 2, 32, 32, true>::run(gb4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, slope, g);
-                    dact_split_tiles<32>(g2, gb2, m2, slope);
+                    PhaseSel<TERMS, 16, 2, 32, 32, true>::type::run(gb4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, slope, g);
+                    dact_split_tiles<32, SG>(g2, gb2, m2, slope);
                     tick<TIMING>(rc, 8);
                 }
 #pragma unroll
                 for (int t = 0; t < 8; ++t) g0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                SplitPhase<16, 2, 8, 8, true>::run(gb2, g0, ring, nullptr, lds_mask + MASK_BASE[0] * WG_THREADS, slope, g);
+                PhaseSel<TERMS, 16, 2, 8, 8, true>::type::run(gb2, g0, ring, nullptr, lds_mask + MASK_BASE[0] * WG_THREADS, slope, g);
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) *(f32x4*)(my_f + 16 * t + 4 * g) = g0[t];
@@ -545,10 +687,19 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
 }
 
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_relu_kernel(PndfKernelArgs args) {
-    pndf_fused_split_body<false>(args);
+    pndf_fused_split_body<false, 3>(args);
 }
 
 // split-precision kernel with s_memtime region stamps (performance analysis only)
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_relu_kernel_timing(PndfKernelArgs args) {
-    pndf_fused_split_body<true>(args);
+    pndf_fused_split_body<true, 3>(args);
+}
+
+// plain-fp16 kernel (precision "f16"): one MFMA per product block, operands rounded to fp16 -- a measured comparison
+// point (BASELINE.json configs[2] "fp32 vs bf16"), NOT within the 1e-4 parity bar
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_half_relu_kernel(PndfKernelArgs args) {
+    pndf_fused_split_body<false, 1>(args);
+}
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_half_relu_kernel_timing(PndfKernelArgs args) {
+    pndf_fused_split_body<true, 3 - 2>(args);
 }

@@ -90,7 +90,7 @@ constexpr int phase_b_pairs(const Phase& p) { return p.NB * (p.CT / 2); }
 static_assert(2 * (phase_a_pairs(PHASES[1]) + phase_b_pairs(PHASES[1])) == phase_chunk_tiles(PHASES[1]), "same tile count");
 static_assert(2 * (phase_a_pairs(PHASES[2]) + phase_b_pairs(PHASES[2])) == phase_chunk_tiles(PHASES[2]), "same tile count");
 
-enum Precision { PREC_FP32 = 0, PREC_F16X3 = 1 };
+enum Precision { PREC_FP32 = 0, PREC_F16X3 = 1, PREC_F16 = 2 };
 
 // bias block (floats) copied to LDS: b0..b5, then w6 (64), then b6
 constexpr int BIAS_OFF[NLIN] = {0, 256, 768, 1792, 2304, 2560, 2688};

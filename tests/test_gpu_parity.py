@@ -302,3 +302,24 @@ def test_grad_outputs_scale_is_harmless(torch_cuda, precision, scale):
     (scaled,) = torch.autograd.grad(d, q, grad_outputs=torch.full_like(d, scale))
     assert torch.isfinite(scaled).all()
     assert rel_err((scaled / scale).cpu().numpy(), unit.cpu().numpy()) < 1e-6
+
+
+def test_f16_single_is_a_bounded_approximation(torch_cuda):
+    """precision="f16" (operands rounded to fp16, one MFMA per block) is a speed/accuracy comparison point, NOT a
+    parity-grade mode: it must stay a sane approximation of the oracle (1e-2 relative here; the parity modes are
+    held to 1e-4) and it must actually differ from f16x3 (i.e. the single-term kernel is the one that ran)."""
+    torch = torch_cuda
+    g = load_golden("lrelu", "live")
+    net = make_net(torch, "lrelu", "live", precision="f16")
+    q = torch.from_numpy(g["q"]).cuda().requires_grad_(True)
+    d = net(q, train=False)["dist_pred"]
+    (dq,) = torch.autograd.grad(d, q, grad_outputs=torch.ones_like(d))
+    e_d = d_err(d.detach().cpu().numpy().ravel(), g["d_f64"].ravel())
+    e_g = np.median(rel_err_rows(dq.cpu().numpy(), g["dq_f64"]))
+    print(f"f16 single: d err {e_d:.2e}, median grad err {e_g:.2e}")
+    assert e_d < 1e-2 and e_g < 1e-2
+    ref = make_net(torch, "lrelu", "live", precision="f16x3")
+    d3 = ref(q.detach(), train=False)["dist_pred"]
+    assert not torch.equal(d3, d.detach())
+    qp, dl = net.project(q.detach(), steps=100)
+    assert torch.isfinite(qp).all() and (dl >= 0).all()
