@@ -22,7 +22,7 @@ def main():
     cfg = amass_config("lrelu", "cuda:0")
     cfg["engine"] = {"precision": prec}
     net = PoseNDF(cfg)
-    cyc_per_tile = 128 if prec == "fp32" else 24        # fp32: 4 MFMAs x 32 cycles; f16x3: 1.5 MFMAs x 16
+    cyc_per_tile = {"fp32": 128, "f16x3": 24, "f16": 8}[prec]   # per stream tile: 4 MFMAs x 32 cycles; 1.5 x 16; 0.5 x 16
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(0, 2.0, 0.1).items()})
     q = torch.from_numpy(synth.make_poses(B, seed=1)).cuda()
     eng = net._engine_for(q.device)
