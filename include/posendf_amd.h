@@ -108,6 +108,20 @@ int pndf_pack_host(const float* const* tensors, const int64_t* numel, int n_tens
 int pndf_pack_host_split(const float* const* tensors, const int64_t* numel, int n_tensors, float* stream,
                          float* bias);
 
+/* ---- motion-denoise optimiser step around the engine (experiments/motion_denoise.py:29-45,70-99).
+ * Stateless helpers (no handle; status codes as above, no error text).  One Adam step =
+ *   pndf_forward_grad(h, q, NULL, d, dq, S*T, stream);  pndf_denoise_update(...)   -- q for the first step from
+ * pndf_aa2quat.  Terms: pose prior 1e7 c_s^2 / (1+it), c_s = mean_t d (:81-83,33) and the pose-space surrogates of the
+ * SMPL temporal / data terms (:31-32,88-94; the body model itself is out of scope).  Adam(lr, 0.9, 0.999, 1e-8) (:70). */
+/* theta [N,69] axis-angle (SMPL body pose) -> q [N,21,4] real-part-first quaternions of the first 21 joints
+ * (pytorch3d.transforms.axis_angle_to_quaternion, :81). */
+int pndf_aa2quat(const float* theta, float* q, int64_t N, void* stream);
+/* theta_in/theta_out/theta0/m/v: [S,T,69]; d: [S*T]; dq, q_next: [S*T,21,4].  theta_in != theta_out (frames read their
+ * neighbours; swap the buffers every step).  `it` = outer iteration (weights), `adam_step` = 1, 2, ... */
+int pndf_denoise_update(const float* theta_in, float* theta_out, const float* theta0, const float* d, const float* dq,
+                        float* m, float* v, float* q_next, int32_t S, int32_t T, int32_t it, int32_t adam_step, float lr,
+                        void* stream);
+
 const char* pndf_last_error(pndf_handle h);   /* h may be NULL: last error of a failed pndf_create */
 const char* pndf_version(void);
 

@@ -12,6 +12,11 @@ and its first-order autograd contract.  The reference's temporal / data terms ne
 pluggable: pass `body_model(pose_body[T,69]) -> (vertices[T,V,3], joints[T,J,3])`, or leave it None to use
 pose-space surrogates (per-joint axis-angle differences), which keep the objective's structure.
 
+`optimize(fused=True)` runs the same loop without PyTorch in it: per Adam step one engine launch (distances and
+d d / d q for all S x T frames) and one HIP kernel (`pndf_denoise_update`, posendf_amd/csrc/pndf_denoise.hip) that
+does the per-sequence mean, the weights, the axis-angle Jacobian, the pose-space terms, Adam and the next step's
+quaternions -- 3 launches per step instead of ~60.  It needs `body_model is None` (the surrogate terms).
+
 Sequences are independent problems (one `main()` per sequence in the reference, :171-188): a batch [S, T, 69] is
 optimised with per-sequence means, one engine launch per Adam step for all S x T frames.
 """
@@ -80,8 +85,46 @@ class MotionDenoise:
         return torch.stack([w[k](v, it) for k, v in loss.items()]).sum(dim=0)         # backward_step, :37-45
 
     # ---- optimiser ------------------------------------------------------------------------------
-    def optimize(self, noisy_poses, iterations=10, steps_per_iter=50, lr=0.02, record=True):
-        """noisy_poses: [T,69] or [S,T,69] axis-angle.  Returns (denoised poses, history of per-step mean losses)."""
+    def _optimize_fused(self, pose, iterations, steps_per_iter, lr):
+        """The loop of `optimize` on the engine + pndf_denoise_update, no autograd (module docstring)."""
+        import ctypes
+        if self.body_model is not None:
+            raise ValueError("fused=True implements the pose-space surrogate terms only (body_model must be None)")
+        S, T = pose.shape[:2]
+        N = S * T
+        dev = pose.device
+        eng = self.pose_prior._engine_for(dev)
+        lib = eng.lib
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        theta0 = pose.contiguous()
+        bufs = [theta0.clone(), torch.empty_like(theta0)]
+        m, v = torch.zeros_like(theta0), torch.zeros_like(theta0)
+        q = torch.empty(N, 21, 4, device=dev, dtype=torch.float32)
+        d = torch.empty(N, device=dev, dtype=torch.float32)
+        dq = torch.empty(N, 21, 4, device=dev, dtype=torch.float32)
+        if lib.pndf_aa2quat(bufs[0].data_ptr(), q.data_ptr(), N, stream) != 0:
+            raise RuntimeError("pndf_aa2quat failed")
+        k = 0
+        for it in range(iterations):
+            for _ in range(steps_per_iter):
+                k += 1
+                eng.forward_grad(q.data_ptr(), None, d.data_ptr(), dq.data_ptr(), N, stream.value or 0)
+                rc = lib.pndf_denoise_update(bufs[0].data_ptr(), bufs[1].data_ptr(), theta0.data_ptr(), d.data_ptr(),
+                                             dq.data_ptr(), m.data_ptr(), v.data_ptr(), q.data_ptr(), S, T, it, k,
+                                             float(lr), stream)
+                if rc != 0:
+                    raise RuntimeError(f"pndf_denoise_update failed ({rc})")
+                bufs.reverse()
+        return bufs[0]
+
+    def optimize(self, noisy_poses, iterations=10, steps_per_iter=50, lr=0.02, record=True, fused=False):
+        """noisy_poses: [T,69] or [S,T,69] axis-angle.  Returns (denoised poses, history of per-step mean losses;
+        empty with fused=True)."""
+        if fused:
+            single = noisy_poses.dim() == 2
+            pose = noisy_poses.to(self.device, torch.float32)
+            out = self._optimize_fused(pose[None] if single else pose, iterations, steps_per_iter, lr)
+            return (out[0] if single else out), []
         single = noisy_poses.dim() == 2
         pose = noisy_poses.to(self.device, torch.float32)
         if single:

@@ -83,3 +83,52 @@ def test_denoise_matches_oracle_loop(precision):
     assert err < 2e-3, err
     moved = (ref - noisy).abs().max().item()
     assert moved > 0.05 and err < 0.05 * moved
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_fused_step_matches_autograd_driver(precision):
+    """optimize(fused=True) -- engine launch + pndf_denoise_update, no PyTorch in the loop -- against the autograd
+    driver around the same engine: same terms, same Adam; differences are rounding order only."""
+    from posendf_amd import PoseNDF, amass_config
+    from posendf_amd.motion_denoise import MotionDenoise
+    sd = golden_weights("live")
+    cfg = amass_config("lrelu", "cuda:0")
+    cfg["engine"] = {"precision": precision}
+    net = PoseNDF(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    noisy = _noisy_sequences(5, 31, seed=3)
+    noisy[0, 3, 6:9] = 0.0                                   # a zero rotation: small-angle branch and its Jacobian
+    md = MotionDenoise(net, device="cuda:0")
+    # one step: the update is lr * sign-like, so compare the step itself tightly
+    a1, _ = md.optimize(noisy, iterations=1, steps_per_iter=1, record=False)
+    f1, _ = md.optimize(noisy, iterations=1, steps_per_iter=1, fused=True)
+    assert (a1 - f1).abs().max().item() < 2e-4               # Adam's first step is lr * g / (|g| + eps): +-lr unless g ~ 0
+    ref, _ = md.optimize(noisy, iterations=2, steps_per_iter=10, record=False)
+    got, _ = md.optimize(noisy, iterations=2, steps_per_iter=10, fused=True)
+    assert torch.isfinite(got).all()
+    # 20 steps: d d / d q is discontinuous at activation kinks and Adam turns a flipped gradient component into a
+    # +-lr step, so a few elements drift apart; the bulk must agree to rounding
+    diff = (got - ref).abs().flatten()
+    moved = (ref.cpu() - noisy).abs().max().item()
+    print(f"fused vs autograd driver after 20 steps: median {diff.median().item():.2e} p99 "
+          f"{diff.kthvalue(int(0.99 * diff.numel())).values.item():.2e} max {diff.max().item():.2e} (moved {moved:.2f})")
+    assert diff.median().item() < 1e-5
+    assert (diff > 1e-3).float().mean().item() < 0.01
+    assert diff.max().item() < 0.1 * moved
+    assert torch.equal(got[..., 63:].cpu(), noisy[..., 63:])  # hand joints: no term, Adam leaves them in place
+
+
+@pytest.mark.gpu
+def test_aa2quat_kernel_matches_restatement():
+    import ctypes
+    from posendf_amd.engine import load_library
+    from posendf_amd.motion_denoise import axis_angle_to_quaternion
+    lib = load_library()
+    theta = (0.8 * torch.randn(257, 69)).cuda()
+    theta[5, 0:3] = 0.0
+    theta[6, 3:6] = 1e-8
+    q = torch.empty(257, 21, 4, device="cuda")
+    assert lib.pndf_aa2quat(theta.data_ptr(), q.data_ptr(), 257, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    want = axis_angle_to_quaternion(theta.reshape(257, 23, 3)[:, :21])
+    assert torch.allclose(q, want, atol=2e-7, rtol=1e-6)
