@@ -309,57 +309,124 @@ __device__ __forceinline__ void enc_dact(f32x4& gz, uint32_t bits4, const ActP& 
     }
 }
 
-template <int J, bool SP>
-__device__ __forceinline__ void enc_fwd_joint(const float* my_q, float* my_f, const float* encb,
-                                              const float (&denom)[4], f32x4 (&F)[NJ], float (&ebf)[NJ],
-                                              f32x4 t1, f32x4 t2, Ring& ring, const ActP& ap, int g) {
-    f32x4 n1 = t1, n2 = t2;
-    if constexpr (J + 1 < NJ) {            // prefetch the next joint's two tiles
-        n1 = enc_tile<2 * (J + 1)>(ring);
-        n2 = enc_tile<2 * (J + 1) + 1>(ring);
-    }
-    const f32x4 qj = *(const f32x4*)(my_q + 4 * J);
+// Joints J and J+1 are processed as a PAIR when they are independent (J+1 is not a child of J): their MFMA chains
+// (four dependent 16x16x4 steps per layer, 40 cycles of latency each at 32 cycles of issue) and activation VALU are
+// interleaved by hand, which hides the dependent latency that made the encoder 9.5 % of a split-precision step.
+// SMPL order: pairs (0,1) (2,3) ... (14,15), then the chain 16 -> 17 -> 18 -> 19 -> 20 one joint at a time.
+constexpr bool enc_pairable(int j) { return j + 1 < NJ && PARENT[j + 1] != j; }
+
+template <int J>
+__device__ __forceinline__ f32x4 enc_input(const f32x4& qj, const float (&inv)[4], const f32x4 (&F)[NJ], int g) {
     f32x4 X;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) X[c] = qj[c] / denom[c];       // posendf.py:71
-    if constexpr (PARENT[J] >= 0) {
-        X = (g == 0) ? X : F[PARENT[J]];                       // cat(quat, parent feature), net_modules.py:167
+    for (int c = 0; c < 4; ++c) X[c] = qj[c] * inv[c];         // posendf.py:71 (x / max(norm, eps), as x * (1 / .))
+    if constexpr (PARENT[J] >= 0) X = (g == 0) ? X : F[PARENT[J]];   // cat(quat, parent feature), net_modules.py:167
+    else X = (g == 0) ? X : f32x4{0.f, 0.f, 0.f, 0.f};
+    return X;
+}
+
+template <int J>
+__device__ __forceinline__ void enc_store_features(float* my_f, const f32x4& Fj, int g) {
+    // features of the joint -> per-pose buffer (rows 4..7 live in lane group 1, rows 8..9 in lane group 2):
+    // two predicated 8-byte stores
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    float* dst = my_f + FEAT * J + ((g == 2) ? 4 : 0);
+    if (g == 1 || g == 2) *(f32x2*)dst = f32x2{Fj[0], Fj[1]};
+    if (g == 1) *(f32x2*)(dst + 2) = f32x2{Fj[2], Fj[3]};
+}
+
+// what a step needs from LDS, fetched one step ahead: weight tiles (2 per joint), biases (2 per joint), quaternions
+struct EncIn {
+    f32x4 t[4];
+    f32x4 b[4];
+    f32x4 q[2];
+};
+template <int J, int NJOINTS>
+__device__ __forceinline__ void enc_fetch(EncIn& in, const float* my_q, const float* encb, Ring& ring, int g) {
+    in.t[0] = enc_tile<2 * J>(ring);
+    in.t[1] = enc_tile<2 * J + 1>(ring);
+    in.b[0] = *(const f32x4*)(encb + 32 * J + 4 * g);
+    in.b[1] = *(const f32x4*)(encb + 32 * J + 16 + 4 * g);
+    in.q[0] = *(const f32x4*)(my_q + 4 * J);
+    if constexpr (NJOINTS == 2) {
+        in.t[2] = enc_tile<2 * J + 2>(ring);
+        in.t[3] = enc_tile<2 * J + 3>(ring);
+        in.b[2] = *(const f32x4*)(encb + 32 * (J + 1) + 4 * g);
+        in.b[3] = *(const f32x4*)(encb + 32 * (J + 1) + 16 + 4 * g);
+        in.q[1] = *(const f32x4*)(my_q + 4 * (J + 1));
+    }
+}
+
+// NT tiles (2 per joint) starting at stream tile T0 of the encoder section
+template <int T0, int NT>
+__device__ __forceinline__ void enc_tiles(f32x4 (&t)[4], Ring& ring) {
+    if constexpr (NT >= 1) t[0] = enc_tile<T0>(ring);
+    if constexpr (NT >= 2) t[1] = enc_tile<T0 + 1>(ring);
+    if constexpr (NT >= 3) t[2] = enc_tile<T0 + 2>(ring);
+    if constexpr (NT >= 4) t[3] = enc_tile<T0 + 3>(ring);
+}
+
+template <int J, bool SP>
+__device__ __forceinline__ void enc_fwd_step(const float* my_q, float* my_f, const float* encb, const float (&inv)[4],
+                                             f32x4 (&F)[NJ], float (&ebf)[NJ], const EncIn& in, Ring& ring,
+                                             const ActP& ap, int g) {
+    constexpr bool PAIR = enc_pairable(J);
+    constexpr int JN = J + (PAIR ? 2 : 1);                     // first joint of the next step
+    EncIn nx = in;
+    if constexpr (JN < NJ) enc_fetch<JN, enc_pairable(JN) ? 2 : 1>(nx, my_q, encb, ring, g);   // next step's operands
+    if constexpr (PAIR) {
+        const f32x4 Xa = enc_input<J>(in.q[0], inv, F, g), Xb = enc_input<J + 1>(in.q[1], inv, F, g);
+        f32x4 Ha = in.b[0], Hb = in.b[2];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            Ha = mfma4(in.t[0][s], Xa[s], Ha);
+            Hb = mfma4(in.t[2][s], Xb[s], Hb);
+        }
+        const float hba = enc_act<SP>(Ha, ap, SP_SLOT_ENC + 2 * J);
+        const float hbb = enc_act<SP>(Hb, ap, SP_SLOT_ENC + 2 * (J + 1));
+        f32x4 Fa = in.b[1], Fb = in.b[3];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            Fa = mfma4(in.t[1][s], Ha[s], Fa);
+            Fb = mfma4(in.t[3][s], Hb[s], Fb);
+        }
+        const float fba = enc_act<SP>(Fa, ap, SP_SLOT_ENC + 2 * J + 1);
+        const float fbb = enc_act<SP>(Fb, ap, SP_SLOT_ENC + 2 * (J + 1) + 1);
+        ebf[J] = fmaf(fba, 16.f, hba);          // 8 derivative bits of the joint, as an exact small float
+        ebf[J + 1] = fmaf(fbb, 16.f, hbb);
+        F[J] = Fa;
+        F[J + 1] = Fb;
+        enc_store_features<J>(my_f, Fa, g);
+        enc_store_features<J + 1>(my_f, Fb, g);
     } else {
-        X = (g == 0) ? X : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 X = enc_input<J>(in.q[0], inv, F, g);
+        f32x4 H = in.b[0];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) H = mfma4(in.t[0][s], X[s], H);
+        const float hb = enc_act<SP>(H, ap, SP_SLOT_ENC + 2 * J);
+        f32x4 Fj = in.b[1];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) Fj = mfma4(in.t[1][s], H[s], Fj);
+        const float fb = enc_act<SP>(Fj, ap, SP_SLOT_ENC + 2 * J + 1);
+        ebf[J] = fmaf(fb, 16.f, hb);
+        F[J] = Fj;
+        enc_store_features<J>(my_f, Fj, g);
     }
-    f32x4 H = *(const f32x4*)(encb + 32 * J + 4 * g);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) H = mfma4(t1[s], X[s], H);
-    const float hb = enc_act<SP>(H, ap, SP_SLOT_ENC + 2 * J);
-    f32x4 Fj = *(const f32x4*)(encb + 32 * J + 16 + 4 * g);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) Fj = mfma4(t2[s], H[s], Fj);
-    const float fb = enc_act<SP>(Fj, ap, SP_SLOT_ENC + 2 * J + 1);
-    ebf[J] = fmaf(fb, 16.f, hb);            // 8 derivative bits of this joint, as an exact small float
-    F[J] = Fj;
-    // features of the joint -> per-pose buffer (rows 4..7 live in lane group 1, rows 8..9 in lane group 2)
-    if (g == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) my_f[FEAT * J + r] = Fj[r];
-    } else if (g == 2) {
-        my_f[FEAT * J + 4] = Fj[0];
-        my_f[FEAT * J + 5] = Fj[1];
-    }
-    if constexpr (J + 1 < NJ) enc_fwd_joint<J + 1, SP>(my_q, my_f, encb, denom, F, ebf, n1, n2, ring, ap, g);
+    if constexpr (JN < NJ) enc_fwd_step<JN, SP>(my_q, my_f, encb, inv, F, ebf, nx, ring, ap, g);
 }
 
 template <bool SP>
 __device__ __forceinline__ void encoder_forward(const float* my_q, float* my_f, const float* encb,
                                                 uint32_t (&eb)[6], Ring& ring, const ActP& ap, int g) {
-    float ss[4], denom[4];
+    float ss[4], inv[4];
     joint_axis_norms(my_q, ss);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) denom[c] = fmaxf(sqrtf(ss[c]), 1e-12f);
+    for (int c = 0; c < 4; ++c) inv[c] = 1.0f / fmaxf(sqrtf(ss[c]), 1e-12f);
     f32x4 F[NJ];
     float ebf[NJ];
-    const f32x4 t1 = enc_tile<0>(ring);
-    const f32x4 t2 = enc_tile<1>(ring);
-    enc_fwd_joint<0, SP>(my_q, my_f, encb, denom, F, ebf, t1, t2, ring, ap, g);
+    EncIn in;
+    enc_fetch<0, enc_pairable(0) ? 2 : 1>(in, my_q, encb, ring, g);
+    enc_fwd_step<0, SP>(my_q, my_f, encb, inv, F, ebf, in, ring, ap, g);
     if (g == 0) {
         my_f[126] = 0.f;
         my_f[127] = 0.f;
@@ -379,27 +446,58 @@ __device__ __forceinline__ void encoder_forward(const float* my_q, float* my_f, 
 // Joint J, backward: GF[J] (rows 4..9 = d d / d feature, from the trunk plus the children) ->
 //   gz2 = GF * act'(z2);  GH = W2^T gz2 (rows = hidden);  gz1 = GH * act'(z1);  GI = W1^T gz1
 //   GI rows 0..3 = d d / d n_J (lane group 0 -> LDS), rows 4..9 = contribution to the parent's GF.
+// Stream order is joint 20 .. 0; joints J and J-1 are paired when J is not a child of J-1 (then GF[J-1] is already
+// complete: all its children have higher indices and were processed in earlier steps).
+constexpr bool enc_bwd_pairable(int j) { return j >= 1 && PARENT[j] != j - 1; }
+
 template <int J, bool SP>
-__device__ __forceinline__ void enc_bwd_joint(float* my_gn, f32x4 (&GF)[NJ], const uint32_t (&eb)[6],
-                                              f32x4 t1, f32x4 t2, Ring& ring, const ActP& ap, int g) {
-    f32x4 n1 = t1, n2 = t2;
-    if constexpr (J > 0) {
-        n1 = enc_tile<2 * (NJ - J)>(ring);          // tiles of joint J-1: stream order is joint 20 .. 0
-        n2 = enc_tile<2 * (NJ - J) + 1>(ring);
+__device__ __forceinline__ void enc_bwd_step(float* my_gn, f32x4 (&GF)[NJ], const uint32_t (&eb)[6], const f32x4 (&t)[4],
+                                             Ring& ring, const ActP& ap, int g) {
+    constexpr bool PAIR = enc_bwd_pairable(J);
+    constexpr int JN = J - (PAIR ? 2 : 1);                     // first joint of the next step (may be < 0)
+    f32x4 n[4] = {t[0], t[1], t[2], t[3]};
+    if constexpr (JN >= 0) enc_tiles<2 * (NJ - 1 - JN), enc_bwd_pairable(JN) ? 4 : 2>(n, ring);
+    if constexpr (PAIR) {
+        constexpr int K = J - 1;
+        const uint32_t ba = (eb[J / 4] >> (8 * (J % 4))) & 0xffu, bb = (eb[K / 4] >> (8 * (K % 4))) & 0xffu;
+        f32x4 za = GF[J], zb = GF[K];
+        enc_dact<SP>(za, ba >> 4, ap, SP_SLOT_ENC + 2 * J + 1);
+        enc_dact<SP>(zb, bb >> 4, ap, SP_SLOT_ENC + 2 * K + 1);
+        f32x4 Ha = f32x4{0.f, 0.f, 0.f, 0.f}, Hb = Ha;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            Ha = mfma4(t[0][s], za[s], Ha);
+            Hb = mfma4(t[2][s], zb[s], Hb);
+        }
+        enc_dact<SP>(Ha, ba & 0xfu, ap, SP_SLOT_ENC + 2 * J);
+        enc_dact<SP>(Hb, bb & 0xfu, ap, SP_SLOT_ENC + 2 * K);
+        f32x4 Ia = f32x4{0.f, 0.f, 0.f, 0.f}, Ib = Ia;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            Ia = mfma4(t[1][s], Ha[s], Ia);
+            Ib = mfma4(t[3][s], Hb[s], Ib);
+        }
+        if (g == 0) {
+            *(f32x4*)(my_gn + 4 * J) = Ia;
+            *(f32x4*)(my_gn + 4 * K) = Ib;
+        }
+        if constexpr (PARENT[J] >= 0) GF[PARENT[J]] = GF[PARENT[J]] + Ia;   // rows 0..3 of GF are never read back
+        if constexpr (PARENT[K] >= 0) GF[PARENT[K]] = GF[PARENT[K]] + Ib;
+    } else {
+        const uint32_t byte = (eb[J / 4] >> (8 * (J % 4))) & 0xffu;
+        f32x4 gz2 = GF[J];
+        enc_dact<SP>(gz2, byte >> 4, ap, SP_SLOT_ENC + 2 * J + 1);
+        f32x4 GH = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) GH = mfma4(t[0][s], gz2[s], GH);
+        enc_dact<SP>(GH, byte & 0xfu, ap, SP_SLOT_ENC + 2 * J);
+        f32x4 GI = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) GI = mfma4(t[1][s], GH[s], GI);
+        if (g == 0) *(f32x4*)(my_gn + 4 * J) = GI;
+        if constexpr (PARENT[J] >= 0) GF[PARENT[J]] = GF[PARENT[J]] + GI;
     }
-    const uint32_t byte = (eb[J / 4] >> (8 * (J % 4))) & 0xffu;
-    f32x4 gz2 = GF[J];
-    enc_dact<SP>(gz2, byte >> 4, ap, SP_SLOT_ENC + 2 * J + 1);
-    f32x4 GH = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) GH = mfma4(t1[s], gz2[s], GH);
-    enc_dact<SP>(GH, byte & 0xfu, ap, SP_SLOT_ENC + 2 * J);
-    f32x4 GI = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) GI = mfma4(t2[s], GH[s], GI);
-    if (g == 0) *(f32x4*)(my_gn + 4 * J) = GI;
-    if constexpr (PARENT[J] >= 0) GF[PARENT[J]] = GF[PARENT[J]] + GI;   // rows 0..3 of GF are never read back
-    if constexpr (J > 0) enc_bwd_joint<J - 1, SP>(my_gn, GF, eb, n1, n2, ring, ap, g);
+    if constexpr (JN >= 0) enc_bwd_step<JN, SP>(my_gn, GF, eb, n, ring, ap, g);
 }
 
 // consumes d d / d feature from my_f, leaves d d / d n in my_gn
@@ -416,9 +514,9 @@ __device__ __forceinline__ void encoder_backward(float* my_f, float* my_gn, cons
         const bool live = (g == 1) || (g == 2);
         GF[j] = live ? f32x4{a, b, c, d} : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const f32x4 t1 = enc_tile<0>(ring);
-    const f32x4 t2 = enc_tile<1>(ring);
-    enc_bwd_joint<NJ - 1, SP>(my_gn, GF, eb, t1, t2, ring, ap, g);
+    f32x4 t[4];
+    enc_tiles<0, enc_bwd_pairable(NJ - 1) ? 4 : 2>(t, ring);
+    enc_bwd_step<NJ - 1, SP>(my_gn, GF, eb, t, ring, ap, g);
     wave_lds_fence();      // d d / d n written by lane group 0 is read by all lane groups
 }
 

@@ -48,10 +48,12 @@ def main():
         ideal = t * cyc_per_tile
         extra = f"  ideal {ideal:9,d}  eff {ideal / m * 100:5.1f} %  over {m - ideal:9,.0f}" if t else f"  {'':40s}"
         print(f"{n:24s} {m:11,.0f} cyc {m / tot * 100:5.1f} %{extra}")
-    grp = call[:, 12:].mean(0) / 32          # per chunk of the (lin2,lin3) phase; ideal = 16 MFMAs = 512 cycles
-    print("per-group cycles inside one (lin2,lin3) chunk (ideal 512; includes the s_memtime stamp itself):")
-    print("  part A:", " ".join(f"{x:5.0f}" for x in grp[:16]))
-    print("  part B:", " ".join(f"{x:5.0f}" for x in grp[16:]))
+    grp = call[:, 12:].mean(0)
+    if prec == "fp32":
+        grp = grp / 32                       # per chunk of the (lin2,lin3) phase; ideal = 16 MFMAs = 512 cycles
+        print("per-group cycles inside one (lin2,lin3) chunk (ideal 512; includes the s_memtime stamp itself):")
+        print("  part A:", " ".join(f"{v:5.0f}" for v in grp[:16]))
+        print("  part B:", " ".join(f"{v:5.0f}" for v in grp[16:]))
     print("spread over waves (min/max of total):", c.sum(1).min(), c.sum(1).max())
 
 
