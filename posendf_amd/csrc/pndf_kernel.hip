@@ -9,8 +9,18 @@
 //   -> normalise backward -> q <- q - d * grad.
 // See pndf_layout.h for the register/tile layout and DESIGN.md for the roofline.
 #include "pndf_device.h"
+#include <utility>
 
 namespace {
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 // One fused layer pair.  xin: KA input tiles (B operands); acc: NB output tiles (accumulators).
 // Forward: chunk accumulators start from the A-layer bias, get the activation, and their sign bits are
@@ -38,31 +48,38 @@ struct PhaseBody {
             constexpr int TNEXT = ((GI + 1) * GT) % CHUNK_TILES;
             constexpr bool MID = group_has_mid<GT, TNEXT>();
             const bool loaded = (GI + 1 < NG || c + 1 < NC);
-            if (loaded) load_group<GT, TNEXT>(nxt, ring);
-            // the slot fetch that follows a mid-slot barrier: four 1-KiB DMA instructions, each issued behind
-            // an MFMA of this group (a VMEM issue blocks the wave ~16+ cycles; back to back they starve the
-            // MFMA pipe, behind an MFMA they are free)
+            // The next group's tiles are read ONE PER MFMA STEP of this group (not as a burst: right after the
+            // workgroup barrier all four waves would queue their reads at once with an empty MFMA pipe), the ring
+            // events ride on the read they belong to (always read 0 of the group), and the slot fetch that follows
+            // a mid-slot barrier is issued as four 1-KiB DMA pieces behind the group's last four MFMA steps.
             DmaSrc dsrc{nullptr, 0u};
             uint32_t ddst = 0;
-            if (MID && loaded) ring_dma_begin(ring, ring_fill_buffer(ring), dsrc, ddst);
-            int piece = 0;
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE this group's MFMAs
+            auto feed = [&](auto pc, auto npc) {
+                constexpr int P = decltype(pc)::value, NP = decltype(npc)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                if (loaded) {
+                    if constexpr (P < GT) {
+                        constexpr int t = (TNEXT + P) % SLOT_TILES;
+                        if constexpr (t == 0) ring_boundary(ring);
+                        if constexpr (t == SLOT_TILES / 2) {
+                            ring_midslot_sync(ring);
+                            ring_dma_begin(ring, ring_fill_buffer(ring), dsrc, ddst);
+                        }
+                        nxt[P] = ring_tile(ring, t);
+                    }
+                    if constexpr (MID && P >= NP - 4) ring_dma_piece(dsrc, ddst, P - (NP - 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
             if constexpr (GI < NGA) {
                 // ---- part A: two k-tiles of the chunk rows; tile order (kt, ci)
+                static_for<8>([&](auto pc) {
+                    constexpr int P = decltype(pc)::value, k2 = P / 4, s = P % 4;
 #pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                        for (int ci = 0; ci < CT; ++ci)
-                            ch[ci] = mfma4(cur[k2 * CT + ci][s], xin[2 * GI + k2][s], ch[ci]);
-                        if (MID && s < 2 && loaded) {      // 2 k-tiles x 2 = 4 pieces
-                            __builtin_amdgcn_sched_barrier(0);
-                            ring_dma_piece(dsrc, ddst, piece++);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                }
+                    for (int ci = 0; ci < CT; ++ci)
+                        ch[ci] = mfma4(cur[k2 * CT + ci][s], xin[2 * GI + k2][s], ch[ci]);
+                    feed(pc, std::integral_constant<int, 8>{});
+                });
                 if constexpr (GI == NGA - 1) {
                     // ---- chunk epilogue
                     if constexpr (SP) {
@@ -109,20 +126,13 @@ struct PhaseBody {
             } else {
                 // ---- part B: two output tiles get this chunk's contribution; tile order (ci, h)
                 constexpr int nbp = GI - NGA;
+                static_for<CT * 4>([&](auto pc) {
+                    constexpr int P = decltype(pc)::value, ci = P / 4, s = P % 4;
 #pragma unroll
-                for (int ci = 0; ci < CT; ++ci) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-                            acc[2 * nbp + h] = mfma4(cur[ci * 2 + h][s], ch[ci][s], acc[2 * nbp + h]);
-                        if (MID && ci < 2 && s < 2 && loaded) {   // 4 pieces
-                            __builtin_amdgcn_sched_barrier(0);
-                            ring_dma_piece(dsrc, ddst, piece++);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                }
+                    for (int h = 0; h < 2; ++h)
+                        acc[2 * nbp + h] = mfma4(cur[ci * 2 + h][s], ch[ci][s], acc[2 * nbp + h]);
+                    feed(pc, std::integral_constant<int, CT * 4>{});
+                });
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
