@@ -122,6 +122,14 @@ int pndf_denoise_update(const float* theta_in, float* theta_out, const float* th
                         float* m, float* v, float* q_next, int32_t S, int32_t T, int32_t it, int32_t adam_step, float lr,
                         void* stream);
 
+/* ---- quaternion pose distance + k nearest candidates (data/dist_utils.py:9-50, classes euc / geo; caller
+ * data/prepare_traindata.py:159).  noise [B,21,4], valid [B,K,21,4] (device, 16-byte aligned);
+ * metric 0 = geo: sum_j w_j (1 - |<q_valid_j, q_noise_j>|), 1 = euc: sum_j w_j ||q_noise_j - q_valid_j||;
+ * weights = 21 HOST floats (the reference's normalised joint ranks) or NULL for the unweighted mean;
+ * vals [B,k] ascending, idx [B,k] int64, ties towards the lower index; k <= min(K, 16), K <= ~1850. */
+int pndf_quat_topk(const float* noise, const float* valid, int64_t B, int32_t K, int32_t metric, const float* weights,
+                   int32_t k, float* vals, long long* idx, void* stream);
+
 const char* pndf_last_error(pndf_handle h);   /* h may be NULL: last error of a failed pndf_create */
 const char* pndf_version(void);
 

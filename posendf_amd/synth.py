@@ -62,3 +62,18 @@ def make_poses(batch: int, seed: int = 1234, signed: bool = False, offset: int =
         q = q * 2.0 - 1.0
     n = np.sqrt((q.astype(np.float64) ** 2).sum(-1, keepdims=True))
     return (q / np.maximum(n, 1e-12)).astype(np.float32)
+
+
+def make_candidates(B: int, K: int, seed: int):
+    """Inputs of the quaternion distance + top-k op (reference data/dist_utils.py): B signed-unit-quaternion query
+    poses and K candidate poses each, with an exact match + a tie (query 0), and an antipodal copy (query 1:
+    geodesic distance 0, euclidean 2).  Used by tests/golden/make_golden_dist.py and the tests, so only outputs are
+    stored as fixtures."""
+    noise = make_poses(B, seed=seed, signed=True)
+    valid = make_poses(B * K, seed=seed + 100, signed=True).reshape(B, K, 21, 4)
+    if K > 7:
+        valid[0, 3] = noise[0]
+        valid[0, 7] = noise[0]
+        if B > 1:
+            valid[1, 5] = -noise[1]
+    return noise, valid

@@ -1,0 +1,68 @@
+"""Quaternion distance + top-k op (reference data/dist_utils.py): oracle against vectors produced by
+the reference itself; HIP kernel (through the C ABI) against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from posendf_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = [(8, 64, 11), (3, 500, 12)]
+
+
+def golden():
+    return np.load(os.path.join(HERE, "golden", "quat_dist.npz"))
+
+
+@pytest.mark.parametrize("metric", ["geo", "euc"])
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("B,K,seed", CASES)
+def test_oracle_matches_reference_vectors(metric, weighted, B, K, seed):
+    from oracle import quat_dist_np as oq
+    g = golden()
+    tag = f"{metric}_{'w' if weighted else 'u'}_{B}x{K}"
+    noise, valid = synth.make_candidates(B, K, seed)
+    val, idx = oq.dist_calc(noise, valid, 5, metric, weighted)
+    assert np.allclose(val, g[tag + "_val"], rtol=2e-6, atol=2e-7)
+    # indices: equal wherever the reference's k values are distinct (torch.topk does not define the order of ties)
+    ref_idx, ref_val = g[tag + "_idx"], g[tag + "_val"]
+    distinct = np.ones_like(ref_idx, dtype=bool)
+    distinct[:, 1:] &= np.abs(ref_val[:, 1:] - ref_val[:, :-1]) > 1e-6
+    distinct[:, :-1] &= np.abs(ref_val[:, 1:] - ref_val[:, :-1]) > 1e-6
+    assert (idx[distinct] == ref_idx[distinct]).all()
+    if metric == "geo" and B > 1:
+        assert val[1, 0] < 1e-6 and idx[1, 0] == 5          # antipodal copy: same rotation
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", ["geo", "euc"])
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("B,K,k", [(8, 64, 5), (3, 500, 5), (70, 500, 5), (5, 1, 1), (4, 37, 8), (2, 1500, 5)])
+def test_kernel_matches_oracle(metric, weighted, B, K, k):
+    import torch
+    from oracle import quat_dist_np as oq
+    from posendf_amd import dist_utils
+    noise, valid = synth.make_candidates(B, K, seed=21)
+    calc = getattr(dist_utils, metric)(B, device="cuda:0", weighted=weighted)
+    val, idx = calc.dist_calc(torch.from_numpy(noise).cuda(), torch.from_numpy(valid).cuda(), K, k)
+    assert val.shape == (B, k) and idx.shape == (B, k) and idx.dtype == torch.int64
+    want_v, want_i = oq.dist_calc(noise, valid, k, metric, weighted, dtype=np.float64)
+    got_v, got_i = val.cpu().numpy(), idx.cpu().numpy()
+    assert np.allclose(got_v, want_v, rtol=5e-6, atol=5e-7)
+    # the selected candidates really have those distances (robust to ties)
+    full = oq.pose_distances(noise, valid, metric, weighted, dtype=np.float64)
+    assert np.allclose(np.take_along_axis(full, got_i, axis=1), got_v, rtol=5e-6, atol=5e-7)
+    assert (np.diff(got_v, axis=1) >= 0).all()
+    for b in range(B):
+        assert len(set(got_i[b])) == k
+
+
+@pytest.mark.gpu
+def test_kernel_rejects_bad_arguments():
+    import torch
+    from posendf_amd import dist_utils
+    calc = dist_utils.geo(2, device="cuda:0")
+    noise, valid = synth.make_candidates(2, 4, seed=1)
+    with pytest.raises(RuntimeError):
+        calc.dist_calc(torch.from_numpy(noise).cuda(), torch.from_numpy(valid).cuda(), 4, 5)     # k > K
