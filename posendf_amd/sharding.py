@@ -38,3 +38,12 @@ def project_sharded(project_fn, q_shard: torch.Tensor, steps: int, total: int, g
     Returns (q_all [total,21,4], d_all [total,1]) on every rank."""
     q_out, d_last = project_fn(q_shard, steps)
     return all_gather_blocks(q_out, total, group), all_gather_blocks(d_last, total, group)
+
+
+def denoise_sharded(optimize_fn, theta_shard: torch.Tensor, total_sequences: int, group=None):
+    """Motion denoising shards by WHOLE sequences (BASELINE.json configs[4]: 512 sequences over 8 GPUs): the
+    per-sequence mean of the pose prior and the temporal coupling never cross a sequence (reference
+    experiments/motion_denoise.py:83,88-89 -- one main() per sequence :171-188), so there is no collective until
+    the final gather of the denoised poses.  optimize_fn(theta_shard [S_r,T,69]) -> denoised [S_r,T,69]."""
+    out = optimize_fn(theta_shard)
+    return all_gather_blocks(out, total_sequences, group)

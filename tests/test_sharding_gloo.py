@@ -61,3 +61,37 @@ def test_two_rank_gloo_matches_unsharded(tmp_path, total):
         assert q.shape == (total, 21, 4) and d.shape == (total, 1)
         # numpy's BLAS is not bitwise batch-size invariant (the HIP kernel is: test_full_size_properties)
         assert np.allclose(q, q_ref, rtol=1e-5, atol=1e-6) and np.allclose(d, d_ref, rtol=1e-5, atol=1e-7)
+
+
+def _denoise_worker(rank, world, port, S, T, outdir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as dist
+    from test_motion_denoise import _OraclePrior, _noisy_sequences
+    from posendf_amd.motion_denoise import MotionDenoise
+    from posendf_amd.sharding import denoise_sharded, shard_bounds
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    md = MotionDenoise(_OraclePrior("lrelu", golden_weights("live")), device="cpu")
+    theta = _noisy_sequences(S, T, seed=4)
+    lo, hi = shard_bounds(S, rank, world)
+    out = denoise_sharded(lambda th: md.optimize(th, iterations=2, steps_per_iter=2, record=False)[0], theta[lo:hi], S)
+    np.save(os.path.join(outdir, f"th_{rank}.npy"), out.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_denoise_shards_whole_sequences(tmp_path):
+    """Sequences are independent problems: 2 ranks x (2 + 1) sequences == one process with all 3."""
+    from test_motion_denoise import _OraclePrior, _noisy_sequences
+    from posendf_amd.motion_denoise import MotionDenoise
+    S, T, world = 3, 6, 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_denoise_worker, args=(world, port, S, T, str(tmp_path)), nprocs=world, join=True)
+    md = MotionDenoise(_OraclePrior("lrelu", golden_weights("live")), device="cpu")
+    ref, _ = md.optimize(_noisy_sequences(S, T, seed=4), iterations=2, steps_per_iter=2, record=False)
+    for r in range(world):
+        got = np.load(tmp_path / f"th_{r}.npy")
+        assert got.shape == (S, T, 69)
+        assert np.allclose(got, ref.numpy(), atol=1e-5)
