@@ -41,12 +41,26 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
         lo = 0u;
         return;
     }
-    const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
-    hi = __builtin_bit_cast(unsigned, h);
+    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+    hi = hp;
+    // remainders a - hi_a, b - hi_b (exact in fp32) in ONE mixed-precision FMA each: fma(f16 half of hp, -1.0, a)
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hp), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hp), "v"(b));
     f16x2 l;
-    l[0] = (_Float16)(a - (float)h[0]);
-    l[1] = (_Float16)(b - (float)h[1]);
+    l[0] = (_Float16)ra;
+    l[1] = (_Float16)rb;
     lo = __builtin_bit_cast(unsigned, l);
+}
+
+// LeakyReLU / ReLU forward on the split path: y = max(z, slope z) (exact for 0 <= slope < 1) and the derivative bit
+// (z > 0, PyTorch's convention at 0) shifted into a per-lane word: 0 - z has its sign bit set exactly when z > 0
+// (+-0 -> +0), and v_alignbit(m, t, 31) = (m << 1) | (t >> 31).  Four VALU per value instead of five, and no
+// float bit-sum chain.  Values are fed from the HIGHEST bit position down so that value k ends at bit k.
+__device__ __forceinline__ float lrelu_bit(float z, float slope, uint32_t& m) {
+    const float t = 0.0f - z;
+    m = __builtin_amdgcn_alignbit(m, __builtin_bit_cast(uint32_t, t), 31);
+    return fmaxf(z, z * slope);
 }
 
 // two activated fp32 C/D tiles -> the B operand of the k-block they form (8 halfs = 4 dwords, hi and lo)
@@ -134,6 +148,7 @@ struct SplitPhase {
     static constexpr int AP = KA2 * CT, BP = NB * CB; // pairs per chunk
     static constexpr int AG = AP / 4, BG = BP / 4;    // groups of 4 pairs
     static constexpr int A_TILES = 2 * AP;
+    static constexpr int PARTIALS = 1;                // accumulators per chunk tile (3 = one per term)
     static_assert(AP % 4 == 0 && BP % 4 == 0 && A_TILES % SLOT_TILES == 0, "group / slot alignment");
 
     // ---- part A: chunk rows of layer A.  Three partial accumulators per chunk tile (hh, hl, lh terms) keep
@@ -147,7 +162,7 @@ struct SplitPhase {
             if constexpr (M == 8) __builtin_amdgcn_s_waitcnt(0xC87F);     // lgkmcnt(8): this group's lo tiles
             const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
             const f16x8 x = (term == 1) ? xin[kb].l : xin[kb].h;
-            ch[term][ci] = mf16(w, x, ch[term][ci]);
+            ch[PARTIALS == 3 ? term : 0][ci] = mf16(w, x, ch[PARTIALS == 3 ? term : 0][ci]);
             __builtin_amdgcn_sched_barrier(0);
             feed<TN, M>(nxt, ring, dp, true);     // part B follows, so there is always a next group
             __builtin_amdgcn_sched_barrier(0);
@@ -172,25 +187,24 @@ struct SplitPhase {
     static __device__ __forceinline__ void epilogue(f32x4 (&ch)[3][CT], Blk (&out)[CB], uint8_t* mask, int c, float slope) {
         f32x4 y[CT];
         if (!BWD) {
-            float bitsum = 0.f;
+            uint32_t bits = 0;
 #pragma unroll
-            for (int ci = 0; ci < CT; ++ci) {
+            for (int ci = CT - 1; ci >= 0; --ci) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float z = (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r];
-                    const float st = step01(z);
-                    y[ci][r] = z * relu_factor(st, slope);
-                    bitsum = fmaf(st, (float)(1u << (ci * 4 + r)), bitsum);
+                for (int r = 3; r >= 0; --r) {
+                    const float z = (PARTIALS == 3) ? (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r] : ch[0][ci][r];
+                    y[ci][r] = lrelu_bit(z, slope, bits);
                 }
             }
-            store_chunk_bits<CT>(mask, c, (uint32_t)bitsum);
+            asm volatile("" : "+v"(bits));      // pin the chain here (see pndf_kernel.hip act_tiles)
+            store_chunk_bits<CT>(mask, c, bits);
         } else {
             const uint32_t bits = load_chunk_bits<CT>(mask, c);
 #pragma unroll
             for (int ci = 0; ci < CT; ++ci) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float z = (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r];
+                    const float z = (PARTIALS == 3) ? (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r] : ch[0][ci][r];
                     y[ci][r] = z * relu_factor((float)((bits >> (ci * 4 + r)) & 1u), slope);
                 }
             }
@@ -434,26 +448,21 @@ struct PhaseSel<1, KA2, CT, NC, NB, BWD> { using type = HalfPhase<KA2, CT, NC, N
 template <int NT, bool SINGLE = false>
 __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 2], uint32_t (&m)[(NT * 4 + 31) / 32], float slope) {
     constexpr int NW = (NT * 4 + 31) / 32;
-    float lo[NW], hi[NW];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) lo[w] = hi[w] = 0.f;
+    for (int w = NW - 1; w >= 0; --w) {
+        constexpr int dummy = 0; (void)dummy;
+        uint32_t bits = 0;
+        const int top = (NT * 4 < 32 * (w + 1) ? NT * 4 : 32 * (w + 1)) - 1;      // highest value index of this word
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float st = step01(x[t][r]);
-            x[t][r] = x[t][r] * relu_factor(st, slope);
-            const int w = (t * 4 + r) / 32, b = (t * 4 + r) % 32;
-            if (b < 16) lo[w] = fmaf(st, (float)(1u << b), lo[w]);
-            else hi[w] = fmaf(st, (float)(1u << (b - 16)), hi[w]);
+        for (int k = top; k >= 32 * w; --k) {
+            const int t = k / 4, r = k % 4;
+            x[t][r] = lrelu_bit(x[t][r], slope, bits);
         }
-        if (t & 1) pack_blk<SINGLE>(x[t - 1], x[t], out[t / 2]);
-    }
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        m[w] = (uint32_t)lo[w] | ((uint32_t)hi[w] << 16);
+        m[w] = bits;
         asm volatile("" : "+v"(m[w]));      // pin the packing here (see pndf_kernel.hip act_tiles)
     }
+#pragma unroll
+    for (int t = 1; t < NT; t += 2) pack_blk<SINGLE>(x[t - 1], x[t], out[t / 2]);
 }
 
 template <int NT, bool SINGLE = false>

@@ -63,20 +63,23 @@ def d_err(a, b, floor_frac=0.05):
     return float((np.abs(a - b) / den).max())
 
 
-def outlier_gate(mine_rows, ref_rows, tol=1e-4, what=""):
+def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0):
     """Gate for quantities that are DISCONTINUOUS in the input (d d/d q and everything derived from it):
     a pre-activation within rounding of a ReLU/LeakyReLU kink flips its derivative (1 vs slope), so any two
     fp32 evaluations -- including the reference's own fp32 run against its fp64 run -- disagree by O(1) on a
     few poses per thousand (measured: 1/1000 and 2/4096 poses for the numpy oracle, 3 % after 100 steps).
     Both error vectors are per-pose relative errors against the SAME fp64 truth; `ref_rows` is the
-    reference-arithmetic (fp32) run that sets the envelope."""
+    reference-arithmetic (fp32) run that sets the envelope.  `ratio`: how many times the reference's own outlier
+    fraction is tolerated -- the kink-crossing probability is proportional to the size of the rounding perturbation,
+    so 2 for fp32 arithmetic in a different summation order and 3 for the split-precision kernel, whose
+    pre-activations carry 2.6e-6 against the fp32 run's 1e-6."""
     mine_rows = np.asarray(mine_rows)
     ref_rows = np.asarray(ref_rows)
     n = len(mine_rows)
     slack = max(0.003, 2.0 / n)
     assert np.median(mine_rows) < tol / 10, (what, float(np.median(mine_rows)))
     frac, ref_frac = float((mine_rows > tol).mean()), float((ref_rows > tol).mean())
-    assert frac <= 2 * ref_frac + slack, (what, frac, ref_frac, float(mine_rows.max()), float(ref_rows.max()))
+    assert frac <= ratio * ref_frac + slack, (what, frac, ref_frac, float(mine_rows.max()), float(ref_rows.max()))
 
 
 @pytest.fixture(params=[(a, r) for a in ACTS for r in REGIMES], ids=lambda p: f"{p[0]}-{p[1]}")
