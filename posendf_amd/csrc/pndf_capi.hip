@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <string>
+#include <cmath>
 #include <vector>
 
 #include "../../include/posendf_amd.h"
@@ -290,6 +291,21 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
     int rc = pndf_pack_host(tensors, numel, n_tensors, stream, bias);
     if (rc != PNDF_OK) return rc;
     const float* const* lin = tensors + 4 * NJ;
+    // Operating range of the fp16 hi/lo split: the lo half of a weight w is ~2^-11 |w|, and fp16 turns subnormal below
+    // 2^-14, so a layer whose LARGEST weight is below 2^-9 would carry most of its lo halves with < 6 bits
+    // (relative weight error > 3e-5 instead of 2^-22); above 65504 the hi half overflows.  Refuse instead of
+    // degrading silently: such a network runs on the exact fp32 kernel.
+    for (int l = 0; l < 6; ++l) {
+        float mx = 0.f;
+        bool nan = false;
+        const int64_t n = (int64_t)DIMS[l + 1] * DIMS[l];
+        for (int64_t i = 0; i < n; ++i) {
+            const float a = std::fabs(lin[2 * l][i]);
+            nan |= (a != a);
+            if (a > mx) mx = a;
+        }
+        if (nan || !(mx >= 0x1p-9f && mx <= 60000.f)) return PNDF_ERR_UNSUPPORTED;
+    }
     float* dst = stream + (size_t)ENC_TILES_PADDED * TILE_FLOATS;
     for (int ph = 0; ph < 6; ++ph) {
         const Phase& P = PHASES[ph];
@@ -320,6 +336,9 @@ extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, con
     const int prc = (h->cfg.precision != PNDF_PREC_FP32)
                         ? pndf_pack_host_split(tensors, numel, n_tensors, stream.data(), bias.data())
                         : pndf_pack_host(tensors, numel, n_tensors, stream.data(), bias.data());
+    if (prc == PNDF_ERR_UNSUPPORTED)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "a trunk layer's largest |weight| is outside [2^-9, 6e4]: outside the operating "
+                                             "range of the fp16 hi/lo split -- use precision fp32 for this network");
     if (prc != PNDF_OK)
         return fail(h, PNDF_ERR_BAD_SHAPE, "internal: packed stream length mismatch");
     HIP_TRY(h, hipSetDevice(h->device));

@@ -81,6 +81,29 @@ def test_pack_host_rejects_bad_tables(lib):
         engine.pack_host(bad, lib)
 
 
+def test_split_packer_refuses_weights_outside_the_fp16_split_range(lib):
+    """The fp16 hi/lo split has an operating range (include/posendf_amd.h, PNDF_PREC_F16X3): a layer whose largest
+    |weight| is below 2^-9 (lo halves subnormal) or above 6e4 (hi half overflows) is refused, not degraded."""
+    from posendf_amd import engine, synth
+    sd = synth.make_weights(1)
+    engine.pack_host(sd, lib, split=True)                       # ordinary weights pack
+    tiny = dict(sd)
+    tiny["dfnet.lin2.weight"] = sd["dfnet.lin2.weight"] * 1e-3
+    engine.pack_host(tiny, lib)                                  # fine for the exact fp32 stream
+    with pytest.raises(engine.PndfError):
+        engine.pack_host(tiny, lib, split=True)
+    huge = dict(sd)
+    huge["dfnet.lin4.weight"] = sd["dfnet.lin4.weight"] * 1e7
+    with pytest.raises(engine.PndfError):
+        engine.pack_host(huge, lib, split=True)
+    nan = dict(sd)
+    w = sd["dfnet.lin0.weight"].copy()
+    w[3, 5] = np.nan
+    nan["dfnet.lin0.weight"] = w
+    with pytest.raises(engine.PndfError):
+        engine.pack_host(nan, lib, split=True)
+
+
 def test_facade_surface_cpu():
     """Reference-compatible surface without touching the engine: state-dict keys, train=True objective
     (pinned against the reference in tests/golden), loud failure of train=False on CPU."""
