@@ -164,6 +164,29 @@ def main():
         return {"kernel": KERNELS[prec][0], "kernel_ms": ms, "poses_per_s_per_gpu": B / (ms * 1e-3),
                 "achieved_tflops": tf, "median_rel_diff_of_projected_poses_vs_f16x3": diff}
 
+    # BASELINE.json configs[1]: the single forward + d d/d q launch on the same batch (outside the timed region)
+    def fwd_grad_ms(model):
+        eng = model._engine_for(dev)
+        d1 = torch.empty(B, device=dev)
+        g1 = torch.empty_like(q0)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        eng.forward_grad(q0.data_ptr(), None, d1.data_ptr(), g1.data_ptr(), B, st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            eng.forward_grad(q0.data_ptr(), None, d1.data_ptr(), g1.data_ptr(), B, st)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 5
+
+    fwd_grad = None
+    if not args.no_fp32_ref:
+        ms1 = fwd_grad_ms(net)
+        fwd_grad = {"workload": f"BASELINE.json configs[1]: one forward + d d/d q launch, batch={B}", "precision": precision,
+                    "ms": ms1, "pose_steps_per_s": B / (ms1 * 1e-3),
+                    "achieved_tflops": B * FLOP_PER_POSE_STEP / (ms1 * 1e-3) / 1e12}
+
     fp32_ref = f16_ref = None
     if precision == "f16x3" and not args.no_fp32_ref:
         fp32_ref = side_run("fp32")
@@ -216,6 +239,8 @@ def main():
                          "kernel": kname, "kernel_ms": kern_ms,
                          "algorithmic_flop_per_launch": B * args.proj_steps * FLOP_PER_POSE_STEP},
         }
+        if fwd_grad is not None:
+            out["forward_grad_single_launch"] = fwd_grad
         if fp32_ref is not None:
             out["fp32_exact"] = fp32_ref
         if f16_ref is not None:

@@ -60,7 +60,9 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 __device__ __forceinline__ float lrelu_bit(float z, float slope, uint32_t& m) {
     const float t = 0.0f - z;
     m = __builtin_amdgcn_alignbit(m, __builtin_bit_cast(uint32_t, t), 31);
-    return fmaxf(z, z * slope);
+    float y;      // one v_max: fmaxf() makes hipcc quiet both operands first (a second v_max per value)
+    asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(z), "v"(z * slope));
+    return y;
 }
 
 // two activated fp32 C/D tiles -> the B operand of the k-block they form (8 halfs = 4 dwords, hi and lo)
