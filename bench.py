@@ -97,7 +97,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     sd = synth.make_weights(0, 2.0, 0.1)                        # BASELINE.md section 3 "live regime"
-    precision = "fp32" if args.act == "softplus" else args.precision
+    precision = "fp32" if (args.act == "softplus" and args.precision == "f16") else args.precision
 
     def build(prec):
         cfg = amass_config(args.act, f"cuda:{local}")
@@ -191,6 +191,9 @@ def main():
     if precision == "f16x3" and not args.no_fp32_ref:
         fp32_ref = side_run("fp32")
         fp32_ref["frac_of_fp32_mfma_peak"] = fp32_ref["achieved_tflops"] / PEAK_FP32_MFMA_TFLOPS
+        if args.act == "softplus":
+            fp32_ref["kernel"] = "pndf_fused_softplus_kernel"
+    if precision == "f16x3" and not args.no_fp32_ref and args.act != "softplus":
         f16_ref = side_run("f16")
         f16_ref["frac_of_fp16_mfma_peak"] = f16_ref["achieved_tflops"] / PEAK_F16_MFMA_TFLOPS
         f16_ref["note"] = ("reduced precision: operands rounded to fp16, one MFMA per product block; outside the 1e-4 "
@@ -200,7 +203,7 @@ def main():
     if rank == 0:
         kname, peak, dtype = KERNELS[precision]
         if args.act == "softplus":
-            kname = "pndf_fused_softplus_kernel"
+            kname = "pndf_fused_split_softplus_kernel" if precision == "f16x3" else "pndf_fused_softplus_kernel"
         # HBM traffic of the dominant kernel: from the committed PMC passes of the same command
         # (tools/gpu_profile.sh -> profiles/traffic.json); bench.py itself cannot run rocprofv3
         traffic = None

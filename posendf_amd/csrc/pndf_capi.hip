@@ -35,6 +35,7 @@ extern "C" __global__ void pndf_fused_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_softplus_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_split_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_split_relu_kernel_timing(PndfKernelArgs args);
+extern "C" __global__ void pndf_fused_split_softplus_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_half_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_half_relu_kernel_timing(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_relu_kernel_timing(PndfKernelArgs args);
@@ -71,7 +72,7 @@ static int fail(pndf_engine* h, int code, const std::string& msg) {
             return fail(h, PNDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-extern "C" const char* pndf_version(void) { return "posendf_amd 0.2 (gfx950, fp32 MFMA 16x16x4; relu, lrelu, softplus)"; }
+extern "C" const char* pndf_version(void) { return "posendf_amd 0.3 (gfx950; fp32 MFMA 16x16x4 and split-fp16 MFMA 16x16x32; relu, lrelu, softplus)"; }
 
 extern "C" const char* pndf_last_error(pndf_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
@@ -101,8 +102,8 @@ static int check_config(pndf_engine* h, const pndf_config* cfg) {
         return fail(h, PNDF_ERR_BAD_ARG, "softplus beta must be positive");
     if (cfg->precision != PNDF_PREC_FP32 && cfg->precision != PNDF_PREC_F16X3 && cfg->precision != PNDF_PREC_F16)
         return fail(h, PNDF_ERR_UNSUPPORTED, "unknown precision (fp32, f16x3 and f16 are implemented)");
-    if (cfg->precision != PNDF_PREC_FP32 && cfg->act == PNDF_ACT_SOFTPLUS)
-        return fail(h, PNDF_ERR_UNSUPPORTED, "the split-precision kernel implements relu / lrelu; softplus runs in fp32");
+    if (cfg->precision == PNDF_PREC_F16 && cfg->act == PNDF_ACT_SOFTPLUS)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "the plain-f16 comparison kernel implements relu / lrelu only");
     return PNDF_OK;
 }
 
@@ -130,6 +131,8 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
         e = hipFuncSetAttribute((const void*)pndf_fused_split_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_split_relu_kernel_timing, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)pndf_fused_split_softplus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_half_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
@@ -268,7 +271,10 @@ extern "C" int pndf_pack_host(const float* const* tensors, const int64_t* numel,
 }
 
 // ---- split-precision stream
+// Exact power-of-two operand scaling (pndf_kernel_split.hip, "operand scaling"): weights travel as 2^8 W so that their
+// fp16 lo halves stay in the normal range, the trunk biases as 2^12 b (= weight scale x forward activation scale).
 namespace {
+constexpr float SPLIT_W_SCALE = 256.0f, SPLIT_BIAS_SCALE = 4096.0f;
 inline void split_f16(float w, _Float16& hi, _Float16& lo) {
     hi = (_Float16)w;                       // round to nearest even
     lo = (_Float16)(w - (float)hi);
@@ -280,7 +286,7 @@ void emit_pair(const Mat& m, int nt, int kb, float* dst) {
     for (int lane = 0; lane < 64; ++lane)
         for (int jj = 0; jj < 8; ++jj) {
             const float w = m.at(16 * nt + (lane & 15), 16 * (2 * kb + (jj >> 2)) + 4 * (lane >> 4) + (jj & 3));
-            split_f16(w, hi[lane * 8 + jj], lo[lane * 8 + jj]);
+            split_f16(w * SPLIT_W_SCALE, hi[lane * 8 + jj], lo[lane * 8 + jj]);
         }
 }
 }  // namespace
@@ -290,11 +296,12 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
     // biases and encoder tiles are identical to the fp32 stream (the encoder stays on fp32 MFMA)
     int rc = pndf_pack_host(tensors, numel, n_tensors, stream, bias);
     if (rc != PNDF_OK) return rc;
+    for (int i = 0; i < W6_OFF; ++i) bias[i] *= SPLIT_BIAS_SCALE;      // biases of lin0..lin5 (lin6 runs in fp32)
     const float* const* lin = tensors + 4 * NJ;
-    // Operating range of the fp16 hi/lo split: the lo half of a weight w is ~2^-11 |w|, and fp16 turns subnormal below
-    // 2^-14, so a layer whose LARGEST weight is below 2^-9 would carry most of its lo halves with < 6 bits
-    // (relative weight error > 3e-5 instead of 2^-22); above 65504 the hi half overflows.  Refuse instead of
-    // degrading silently: such a network runs on the exact fp32 kernel.
+    // Operating range of the fp16 hi/lo split: the lo half of a (2^8-scaled) weight is ~2^-3 |w|, and fp16 turns
+    // subnormal below 2^-14, so a layer whose LARGEST weight is below 2^-14 would carry most of its lo halves with a
+    // few bits only; above 2^-8 * 65504 the hi half overflows.  Refuse instead of degrading silently: such a
+    // network runs on the exact fp32 kernel.
     for (int l = 0; l < 6; ++l) {
         float mx = 0.f;
         bool nan = false;
@@ -304,7 +311,7 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
             nan |= (a != a);
             if (a > mx) mx = a;
         }
-        if (nan || !(mx >= 0x1p-9f && mx <= 60000.f)) return PNDF_ERR_UNSUPPORTED;
+        if (nan || !(mx >= 0x1p-14f && mx <= 200.f)) return PNDF_ERR_UNSUPPORTED;
     }
     float* dst = stream + (size_t)ENC_TILES_PADDED * TILE_FLOATS;
     for (int ph = 0; ph < 6; ++ph) {
@@ -337,7 +344,7 @@ extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, con
                         ? pndf_pack_host_split(tensors, numel, n_tensors, stream.data(), bias.data())
                         : pndf_pack_host(tensors, numel, n_tensors, stream.data(), bias.data());
     if (prc == PNDF_ERR_UNSUPPORTED)
-        return fail(h, PNDF_ERR_UNSUPPORTED, "a trunk layer's largest |weight| is outside [2^-9, 6e4]: outside the operating "
+        return fail(h, PNDF_ERR_UNSUPPORTED, "a trunk layer's largest |weight| is outside [2^-14, 200]: outside the operating "
                                              "range of the fp16 hi/lo split -- use precision fp32 for this network");
     if (prc != PNDF_OK)
         return fail(h, PNDF_ERR_BAD_SHAPE, "internal: packed stream length mismatch");
@@ -391,7 +398,10 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
             h->scratch_wgs = grid.x;
         }
         a.scratch = h->d_scratch;
-        hipLaunchKernelGGL(pndf_fused_softplus_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+        if (h->cfg.precision == PNDF_PREC_F16X3)
+            hipLaunchKernelGGL(pndf_fused_split_softplus_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(pndf_fused_softplus_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
         HIP_TRY(h, hipGetLastError());
         return PNDF_OK;
     }

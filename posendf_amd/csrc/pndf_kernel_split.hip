@@ -65,6 +65,23 @@ __device__ __forceinline__ float lrelu_bit(float z, float slope, uint32_t& m) {
     return y;
 }
 
+// activation parameters of one layer: relu family (slope) or softplus (beta + this thread's column of the derivative
+// scratch, first slot of the layer; see ActP / SP_SLOT_* in pndf_device.h)
+struct SAct {
+    float slope, beta;
+    f32x4* sp;
+    int spslot;
+};
+
+// Power-of-two operand scaling (exact).  An fp16 lo half is ~2^-11 of its value and turns SUBNORMAL below 2^-14: with
+// weights of a few 1e-2 and gradients of 1e-3..1e-1 most lo halves would keep only a few bits.  So the stream carries
+// 2^8 W, forward activations travel as 2^4 x and backward gradients as 2^10 g; the fp32 accumulators then hold
+// 2^12 (forward, the packed biases are scaled to match) or 2^18 (backward) times the true value, and ONE multiply by
+// 2^-8 in the epilogue turns either into the next layer's scaled operand (LeakyReLU commutes with positive scales).
+constexpr float W_SCALE = 256.0f, XF_SCALE = 16.0f, XB_SCALE = 1024.0f;
+constexpr float ACC_TO_OPERAND = 1.0f / W_SCALE;               // accumulator -> scaled operand of the next layer
+constexpr float ACC_TO_TRUE_F = 1.0f / (W_SCALE * XF_SCALE);   // forward accumulator -> true pre-activation
+
 // two activated fp32 C/D tiles -> the B operand of the k-block they form (8 halfs = 4 dwords, hi and lo)
 template <bool SINGLE = false>
 __device__ __forceinline__ void pack_blk(const f32x4& t0, const f32x4& t1, Blk& o) {
@@ -144,7 +161,7 @@ __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, 
 }
 
 // ------------------------------------------------------------------ one fused layer pair, split precision
-template <int KA2, int CT, int NC, int NB, bool BWD, bool SINGLE = false>
+template <int KA2, int CT, int NC, int NB, bool BWD, bool SINGLE = false, bool SP = false>
 struct SplitPhase {
     static constexpr int CB = CT / 2;                 // k-blocks of part B per chunk
     static constexpr int AP = KA2 * CT, BP = NB * CB; // pairs per chunk
@@ -152,6 +169,7 @@ struct SplitPhase {
     static constexpr int A_TILES = 2 * AP;
     static constexpr int PARTIALS = 1;                // accumulators per chunk tile (3 = one per term)
     static_assert(AP % 4 == 0 && BP % 4 == 0 && A_TILES % SLOT_TILES == 0, "group / slot alignment");
+    static_assert(!SP || PARTIALS == 1, "the softplus epilogue reads one accumulator per chunk tile");
 
     // ---- part A: chunk rows of layer A.  Three partial accumulators per chunk tile (hh, hl, lh terms) keep
     // dependent MFMAs far apart; they are summed in the epilogue.
@@ -186,15 +204,34 @@ struct SplitPhase {
     }
 
     // ---- chunk epilogue: sum the three partials, (forward) bias is already in ch[0], activation or mask, split
-    static __device__ __forceinline__ void epilogue(f32x4 (&ch)[3][CT], Blk (&out)[CB], uint8_t* mask, int c, float slope) {
+    static __device__ __forceinline__ void epilogue(f32x4 (&ch)[3][CT], Blk (&out)[CB], uint8_t* mask, int c, const SAct& act) {
         f32x4 y[CT];
-        if (!BWD) {
+        const float slope = act.slope;
+        if constexpr (SP) {
+            // softplus: fp32 derivatives parked in the per-workgroup scratch, one float4 per lane per chunk tile
+#pragma unroll
+            for (int ci = 0; ci < CT; ++ci) {
+                f32x4* slot = act.sp + (size_t)(act.spslot + c * CT + ci) * WG_THREADS;
+                if (!BWD) {
+                    f32x4 dv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float dr;
+                        y[ci][r] = act_softplus(ch[0][ci][r] * ACC_TO_TRUE_F, act.beta, dr) * XF_SCALE;
+                        dv[r] = dr;
+                    }
+                    *slot = dv;
+                } else {
+                    y[ci] = (ch[0][ci] * ACC_TO_OPERAND) * *slot;
+                }
+            }
+        } else if (!BWD) {
             uint32_t bits = 0;
 #pragma unroll
             for (int ci = CT - 1; ci >= 0; --ci) {
 #pragma unroll
                 for (int r = 3; r >= 0; --r) {
-                    const float z = (PARTIALS == 3) ? (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r] : ch[0][ci][r];
+                    const float z = ((PARTIALS == 3) ? (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r] : ch[0][ci][r]) * ACC_TO_OPERAND;
                     y[ci][r] = lrelu_bit(z, slope, bits);
                 }
             }
@@ -206,7 +243,7 @@ struct SplitPhase {
             for (int ci = 0; ci < CT; ++ci) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float z = (PARTIALS == 3) ? (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r] : ch[0][ci][r];
+                    const float z = ((PARTIALS == 3) ? (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r] : ch[0][ci][r]) * ACC_TO_OPERAND;
                     y[ci][r] = z * relu_factor((float)((bits >> (ci * 4 + r)) & 1u), slope);
                 }
             }
@@ -249,7 +286,7 @@ struct SplitPhase {
     template <int GB>
     static __device__ __forceinline__ void part_b(const Blk (&chb)[CB], f32x4 (&acc)[NB], Pair (&cur)[4], Ring& ring,
                                                   DmaPieces& dp, bool more, f32x4 (&chn)[3][CT], Blk (&nextb)[CB],
-                                                  uint8_t* mask, int c, float slope) {
+                                                  uint8_t* mask, int c, const SAct& act) {
         if constexpr (GB < BG) {
             Pair nxt[4];
             constexpr int TN = (A_TILES + 8 * (GB + 1)) % SLOT_TILES;
@@ -276,7 +313,7 @@ struct SplitPhase {
                         }
                     }
                 }
-                if (more) epilogue(chn, nextb, mask, c + 1, slope);
+                if (more) epilogue(chn, nextb, mask, c + 1, act);
                 __builtin_amdgcn_sched_barrier(0);
             } else {
                 if (loaded) __builtin_amdgcn_s_waitcnt(0xC47F);   // lgkmcnt(4): hi tiles of this group
@@ -285,12 +322,12 @@ struct SplitPhase {
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
-            part_b<GB + 1>(chb, acc, cur, ring, dp, more, chn, nextb, mask, c, slope);
+            part_b<GB + 1>(chb, acc, cur, ring, dp, more, chn, nextb, mask, c, act);
         }
     }
 
     static __device__ __forceinline__ void run(const Blk (&xin)[KA2], f32x4 (&acc)[NB], Ring& ring, const float* biasA,
-                                               uint8_t* mask, float slope, int g) {
+                                               uint8_t* mask, const SAct& act, int g) {
         Pair cur[4];
         load_pairs<0>(cur, ring);
         DmaPieces dp;
@@ -300,7 +337,7 @@ struct SplitPhase {
         Blk chb[CB];
         init_chunk(ch, biasA, 0, g);
         part_a<0>(xin, ch, cur, ring, dp);
-        epilogue(ch, chb, mask, 0, slope);
+        epilogue(ch, chb, mask, 0, act);
         for (int c = 0; c < NC; ++c) {
             const bool more = c + 1 < NC;
             Blk nextb[CB];
@@ -308,7 +345,7 @@ struct SplitPhase {
                 init_chunk(ch, biasA, c + 1, g);
                 part_a<0>(xin, ch, cur, ring, dp);
             }
-            part_b<0>(chb, acc, cur, ring, dp, more, ch, nextb, mask, c, slope);
+            part_b<0>(chb, acc, cur, ring, dp, more, ch, nextb, mask, c, act);
 #pragma unroll
             for (int b = 0; b < CB; ++b) chb[b] = nextb[b];
         }
@@ -391,7 +428,7 @@ struct HalfPhase {
     template <int GB>
     static __device__ __forceinline__ void part_b(const Blk (&chb)[CB], f32x4 (&acc)[NB], f16x8 (&cur)[8], Ring& ring,
                                                   DmaPieces& dp, bool more, f32x4 (&chn)[3][CT], Blk (&nextb)[CB],
-                                                  uint8_t* mask, int c, float slope) {
+                                                  uint8_t* mask, int c, const SAct& act) {
         if constexpr (GB < BG) {
             f16x8 nxt[8];
             const bool loaded = (GB + 1 < BG) || more;
@@ -404,19 +441,19 @@ struct HalfPhase {
                     const int nb = i / CB, b = i % CB;
                     acc[nb] = mf16(cur[i], chb[b].h, acc[nb]);
                 }
-                if (more) Base::epilogue(chn, nextb, mask, c + 1, slope);
+                if (more) Base::epilogue(chn, nextb, mask, c + 1, act);
                 __builtin_amdgcn_sched_barrier(0);
             } else {
                 b_steps<GB, 0>(chb, acc, cur, nxt, ring, dp, loaded);
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
-            part_b<GB + 1>(chb, acc, cur, ring, dp, more, chn, nextb, mask, c, slope);
+            part_b<GB + 1>(chb, acc, cur, ring, dp, more, chn, nextb, mask, c, act);
         }
     }
 
     static __device__ __forceinline__ void run(const Blk (&xin)[KA2], f32x4 (&acc)[NB], Ring& ring, const float* biasA,
-                                               uint8_t* mask, float slope, int g) {
+                                               uint8_t* mask, const SAct& act, int g) {
         f16x8 cur[8];
         load_half(cur, ring);
         DmaPieces dp;
@@ -426,7 +463,7 @@ struct HalfPhase {
         Blk chb[CB];
         Base::init_chunk(ch, biasA, 0, g);
         part_a<0>(xin, ch, cur, ring, dp);
-        Base::epilogue(ch, chb, mask, 0, slope);
+        Base::epilogue(ch, chb, mask, 0, act);
         for (int c = 0; c < NC; ++c) {
             const bool more = c + 1 < NC;
             Blk nextb[CB];
@@ -434,55 +471,76 @@ struct HalfPhase {
                 Base::init_chunk(ch, biasA, c + 1, g);
                 part_a<0>(xin, ch, cur, ring, dp);
             }
-            part_b<0>(chb, acc, cur, ring, dp, more, ch, nextb, mask, c, slope);
+            part_b<0>(chb, acc, cur, ring, dp, more, ch, nextb, mask, c, act);
 #pragma unroll
             for (int b = 0; b < CB; ++b) chb[b] = nextb[b];
         }
     }
 };
 
-template <int TERMS, int KA2, int CT, int NC, int NB, bool BWD>
-struct PhaseSel { using type = SplitPhase<KA2, CT, NC, NB, BWD, false>; };
+template <int TERMS, bool SP, int KA2, int CT, int NC, int NB, bool BWD>
+struct PhaseSel { using type = SplitPhase<KA2, CT, NC, NB, BWD, false, SP>; };
 template <int KA2, int CT, int NC, int NB, bool BWD>
-struct PhaseSel<1, KA2, CT, NC, NB, BWD> { using type = HalfPhase<KA2, CT, NC, NB, BWD>; };
+struct PhaseSel<1, false, KA2, CT, NC, NB, BWD> { using type = HalfPhase<KA2, CT, NC, NB, BWD>; };
 
-// activation of an accumulator layer + split into the next phase's B operands; sign bits in registers
-template <int NT, bool SINGLE = false>
-__device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 2], uint32_t (&m)[(NT * 4 + 31) / 32], float slope) {
+// activation of an accumulator layer + split into the next phase's B operands; relu family: sign bits in registers,
+// softplus: fp32 derivatives to the scratch (slot act.spslot + tile)
+template <int NT, bool SINGLE = false, bool SP = false>
+__device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 2], uint32_t (&m)[(NT * 4 + 31) / 32], const SAct& act) {
     constexpr int NW = (NT * 4 + 31) / 32;
+    if constexpr (SP) {
 #pragma unroll
-    for (int w = NW - 1; w >= 0; --w) {
-        constexpr int dummy = 0; (void)dummy;
-        uint32_t bits = 0;
-        const int top = (NT * 4 < 32 * (w + 1) ? NT * 4 : 32 * (w + 1)) - 1;      // highest value index of this word
+        for (int t = 0; t < NT; ++t) {
+            f32x4 dv;
 #pragma unroll
-        for (int k = top; k >= 32 * w; --k) {
-            const int t = k / 4, r = k % 4;
-            x[t][r] = lrelu_bit(x[t][r], slope, bits);
+            for (int r = 0; r < 4; ++r) {
+                float dr;
+                x[t][r] = act_softplus(x[t][r] * ACC_TO_TRUE_F, act.beta, dr) * XF_SCALE;
+                dv[r] = dr;
+            }
+            act.sp[(size_t)(act.spslot + t) * WG_THREADS] = dv;
         }
-        m[w] = bits;
-        asm volatile("" : "+v"(m[w]));      // pin the packing here (see pndf_kernel.hip act_tiles)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) m[w] = 0;
+    } else {
+#pragma unroll
+        for (int w = NW - 1; w >= 0; --w) {
+            uint32_t bits = 0;
+            const int top = (NT * 4 < 32 * (w + 1) ? NT * 4 : 32 * (w + 1)) - 1;      // highest value index of this word
+#pragma unroll
+            for (int k = top; k >= 32 * w; --k) {
+                const int t = k / 4, r = k % 4;
+                x[t][r] = lrelu_bit(x[t][r] * ACC_TO_OPERAND, act.slope, bits);
+            }
+            m[w] = bits;
+            asm volatile("" : "+v"(m[w]));      // pin the packing here (see pndf_kernel.hip act_tiles)
+        }
     }
 #pragma unroll
     for (int t = 1; t < NT; t += 2) pack_blk<SINGLE>(x[t - 1], x[t], out[t / 2]);
 }
 
-template <int NT, bool SINGLE = false>
-__device__ __forceinline__ void dact_split_tiles(f32x4 (&gx)[NT], Blk (&out)[NT / 2], const uint32_t (&m)[(NT * 4 + 31) / 32], float slope) {
+template <int NT, bool SINGLE = false, bool SP = false>
+__device__ __forceinline__ void dact_split_tiles(f32x4 (&gx)[NT], Blk (&out)[NT / 2], const uint32_t (&m)[(NT * 4 + 31) / 32], const SAct& act) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+        if constexpr (SP) {
+            gx[t] = (gx[t] * ACC_TO_OPERAND) * act.sp[(size_t)(act.spslot + t) * WG_THREADS];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            gx[t][r] = gx[t][r] * relu_factor((float)((m[(t * 4 + r) / 32] >> ((t * 4 + r) % 32)) & 1u), slope);
+            for (int r = 0; r < 4; ++r)
+                gx[t][r] = (gx[t][r] * ACC_TO_OPERAND) * relu_factor((float)((m[(t * 4 + r) / 32] >> ((t * 4 + r) % 32)) & 1u), act.slope);
+        }
         if (t & 1) pack_blk<SINGLE>(gx[t - 1], gx[t], out[t / 2]);
     }
 }
 
 }  // namespace
 
-template <bool TIMING, int TERMS>
+template <bool TIMING, int TERMS, bool SP = false>
 __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args) {
     constexpr bool SG = (TERMS == 1);
+    static_assert(!(SG && SP), "the single-term comparison mode is relu-family only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -493,8 +551,8 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
     ActP ap;
     ap.slope = args.slope;
     ap.beta = args.beta;
-    ap.sp = nullptr;
-    const float slope = args.slope;
+    ap.sp = SP ? (f32x4*)(args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS) + tid : nullptr;
+    auto layer = [&](int spslot) { return SAct{args.slope, args.beta, ap.sp, spslot}; };
     const long long pose0 = (long long)blockIdx.x * WG_POSES;
     float* const lds_bias = (float*)(smem + LDS_BIAS);
     uint8_t* const lds_mask = (uint8_t*)(smem + LDS_MASK) + tid;
@@ -545,31 +603,31 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
         {
             Blk b2[16];
             {
-                encoder_forward<false>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ap, g);
+                encoder_forward<SP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ap, g);
                 Blk b0[4];
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
-                    pack_blk<SG>(*(const f32x4*)(my_f + 32 * kb + 4 * g), *(const f32x4*)(my_f + 32 * kb + 16 + 4 * g), b0[kb]);
+                    pack_blk<SG>(*(const f32x4*)(my_f + 32 * kb + 4 * g) * XF_SCALE, *(const f32x4*)(my_f + 32 * kb + 16 + 4 * g) * XF_SCALE, b0[kb]);
                 tick<TIMING>(rc, 0);
                 f32x4 x2[32];
                 load_bias<32>(x2, lds_bias + BIAS_OFF[1], g);
-                PhaseSel<TERMS, 4, 2, 8, 32, false>::type::run(b0, x2, ring, lds_bias + BIAS_OFF[0], lds_mask + MASK_BASE[0] * WG_THREADS, slope, g);
+                PhaseSel<TERMS, SP, 4, 2, 8, 32, false>::type::run(b0, x2, ring, lds_bias + BIAS_OFF[0], lds_mask + MASK_BASE[0] * WG_THREADS, layer(SP_SLOT_CHUNK[0]), g);
                 tick<TIMING>(rc, 1);
-                act_split_tiles<32, SG>(x2, b2, m2, slope);
+                act_split_tiles<32, SG, SP>(x2, b2, m2, layer(SP_SLOT_X2));
                 tick<TIMING>(rc, 2);
             }
             f32x4 x4[32];
             load_bias<32>(x4, lds_bias + BIAS_OFF[3], g);
-            PhaseSel<TERMS, 16, 2, 32, 32, false>::type::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, slope, g);
+            PhaseSel<TERMS, SP, 16, 2, 32, 32, false>::type::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1]), g);
             tick<TIMING>(rc, 3);
-            act_split_tiles<32, SG>(x4, b4, m4, slope);
+            act_split_tiles<32, SG, SP>(x4, b4, m4, layer(SP_SLOT_X4));
             tick<TIMING>(rc, 4);
         }
         load_bias<4>(x6, lds_bias + BIAS_OFF[5], g);
-        PhaseSel<TERMS, 16, 4, 4, 4, false>::type::run(b4, x6, ring, lds_bias + BIAS_OFF[4], lds_mask + MASK_BASE[2] * WG_THREADS, slope, g);
+        PhaseSel<TERMS, SP, 16, 4, 4, 4, false>::type::run(b4, x6, ring, lds_bias + BIAS_OFF[4], lds_mask + MASK_BASE[2] * WG_THREADS, layer(SP_SLOT_CHUNK[2]), g);
         tick<TIMING>(rc, 5);
         Blk b6[2];
-        act_split_tiles<4, SG>(x6, b6, m6, slope);      // b6 unused forward; x6 (fp32) feeds lin6
+        act_split_tiles<4, SG, SP>(x6, b6, m6, layer(SP_SLOT_X6));      // b6 unused forward; x6 (fp32) feeds lin6
 
         // ---------------- lin6 (64 -> 1) + output ReLU, fp32 on the VALU
         f32x4 w6[4];
@@ -582,17 +640,23 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
         }
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);
-        const float z7 = part + lds_bias[BIAS_OFF[6]];
-        dval = fmaxf(z7, 0.f);
+        const float z7 = part * (1.0f / XF_SCALE) + lds_bias[BIAS_OFF[6]];      // x6 travels as 2^4 x
+        float gz7;
+        if constexpr (SP) {
+            dval = act_softplus(z7, ap.beta, gz7);      // output Softplus, net_modules.py:39-41,69
+        } else {
+            dval = fmaxf(z7, 0.f);                       // output ReLU for relu AND lrelu, net_modules.py:30-37
+            gz7 = (z7 > 0.f) ? 1.f : 0.f;
+        }
         if (args.mode == MODE_FORWARD) break;
-        const float gz7 = (z7 > 0.f) ? 1.f : 0.f;
-        // grad_outputs scale the RESULT, not the seed of the backward pass: the pass is linear in the seed, and a
-        // seed of 1e-7 (or 1e+6: motion_denoise.py's 1e7 * c^2 weight) would leave the fp16 range of the operands
-        float gscale = 1.f;
+        // grad_outputs and the output activation's derivative (softplus: anything in (0, 1]) scale the RESULT, not the
+        // seed of the backward pass: the pass is linear in the seed, and a seed of 1e-7 (or 1e+6: motion_denoise.py's
+        // 1e7 * c^2 weight) would leave the fp16 range of the operands.  The seed is XB_SCALE, undone in g0 below.
+        float gscale = gz7;
         if (args.mode == MODE_FORWARD_GRAD && args.grad_out) {
             long long pidx = pose0 + wp;
             if (pidx >= args.B) pidx = args.B - 1;
-            gscale = args.grad_out[pidx];
+            gscale = gz7 * args.grad_out[pidx];
         }
 
         // ---------------- trunk backward
@@ -605,36 +669,36 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
                     {
                         f32x4 g6[4];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) g6[t] = w6[t] * gz7;
+                        for (int t = 0; t < 4; ++t) g6[t] = w6[t] * (XB_SCALE * W_SCALE);     // dact multiplies by 1 / W_SCALE
                         Blk gb6[2];
-                        dact_split_tiles<4, SG>(g6, gb6, m6, slope);
+                        dact_split_tiles<4, SG, SP>(g6, gb6, m6, layer(SP_SLOT_X6));
                         tick<TIMING>(rc, 6);
                         f32x4 g4[32];
 #pragma unroll
                         for (int t = 0; t < 32; ++t) g4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        PhaseSel<TERMS, 2, 4, 4, 32, true>::type::run(gb6, g4, ring, nullptr, lds_mask + MASK_BASE[2] * WG_THREADS, slope, g);
-                        dact_split_tiles<32, SG>(g4, gb4, m4, slope);
+                        PhaseSel<TERMS, SP, 2, 4, 4, 32, true>::type::run(gb6, g4, ring, nullptr, lds_mask + MASK_BASE[2] * WG_THREADS, layer(SP_SLOT_CHUNK[2]), g);
+                        dact_split_tiles<32, SG, SP>(g4, gb4, m4, layer(SP_SLOT_X4));
                         tick<TIMING>(rc, 7);
                     }
                     f32x4 g2[32];
 #pragma unroll
                     for (int t = 0; t < 32; ++t) g2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    PhaseSel<TERMS, 16, 2, 32, 32, true>::type::run(gb4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, slope, g);
-                    dact_split_tiles<32, SG>(g2, gb2, m2, slope);
+                    PhaseSel<TERMS, SP, 16, 2, 32, 32, true>::type::run(gb4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1]), g);
+                    dact_split_tiles<32, SG, SP>(g2, gb2, m2, layer(SP_SLOT_X2));
                     tick<TIMING>(rc, 8);
                 }
 #pragma unroll
                 for (int t = 0; t < 8; ++t) g0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                PhaseSel<TERMS, 16, 2, 8, 8, true>::type::run(gb2, g0, ring, nullptr, lds_mask + MASK_BASE[0] * WG_THREADS, slope, g);
+                PhaseSel<TERMS, SP, 16, 2, 8, 8, true>::type::run(gb2, g0, ring, nullptr, lds_mask + MASK_BASE[0] * WG_THREADS, layer(SP_SLOT_CHUNK[0]), g);
             }
 #pragma unroll
-            for (int t = 0; t < 8; ++t) *(f32x4*)(my_f + 16 * t + 4 * g) = g0[t];
+            for (int t = 0; t < 8; ++t) *(f32x4*)(my_f + 16 * t + 4 * g) = g0[t] * (1.0f / (W_SCALE * XB_SCALE));
         }
         __syncthreads();
 
         tick<TIMING>(rc, 9);
         // ---------------- encoder backward + normalise backward + update (fp32, as pndf_kernel.hip)
-        encoder_backward<false>(my_f, my_gn, eb, ring, ap, g);
+        encoder_backward<SP>(my_f, my_gn, eb, ring, ap, g);
         tick<TIMING>(rc, 10);
         {
             float ss[4], dot[4], denom[4], kk[4];
@@ -663,7 +727,8 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float dq = gv[c] / denom[c] - qv[c] * kk[c];
-                    o[c] = (args.mode == MODE_PROJECT) ? __fsub_rn(qv[c], __fmul_rn(dval, dq)) : dq * gscale;
+                    const float dqs = dq * gscale;
+                    o[c] = (args.mode == MODE_PROJECT) ? __fsub_rn(qv[c], __fmul_rn(dval, dqs)) : dqs;
                 }
                 *(f32x4*)(my_q + 4 * j) = o;
             }
@@ -704,6 +769,12 @@ extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_rel
 // split-precision kernel with s_memtime region stamps (performance analysis only)
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_relu_kernel_timing(PndfKernelArgs args) {
     pndf_fused_split_body<true, 3>(args);
+}
+
+// Softplus(beta) on the split path (the reference's experiment scripts default to softplus checkpoints,
+// motion_denoise.py:162-163, sample_poses.py:115): fp32 derivatives through `scratch` as in the fp32 kernel
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_softplus_kernel(PndfKernelArgs args) {
+    pndf_fused_split_body<false, 3, true>(args);
 }
 
 // plain-fp16 kernel (precision "f16"): one MFMA per product block, operands rounded to fp16 -- a measured comparison

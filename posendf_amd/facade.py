@@ -98,7 +98,8 @@ class PoseNDF(nn.Module):
         fp = self._fingerprint()
         entry = self._engines.get(idx)
         if entry is None:
-            prec = "fp32" if self._act == "softplus" else self._precision     # softplus runs in fp32 only
+            # the plain-f16 comparison kernel is relu-family only; fp32 and f16x3 implement all three activations
+            prec = "fp32" if (self._act == "softplus" and self._precision == "f16") else self._precision
             entry = [Engine(self._act, self._beta, idx, precision=prec), None]
             self._engines[idx] = entry
         if entry[1] != fp:          # first use, load_state_dict, optimiser step, .to(): re-pack the weights

@@ -47,7 +47,7 @@ def test_create_rejects_unsupported(lib):
     lib.pndf_default_config(ctypes.byref(cfg), 2, -1.0)             # softplus needs beta > 0
     assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -1
     lib.pndf_default_config(ctypes.byref(cfg), 2, 100.0)
-    cfg.precision = 1                                               # softplus has no split-precision kernel
+    cfg.precision = 2                                               # the plain-f16 comparison kernel is relu-family only
     assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -4
     lib.pndf_default_config(ctypes.byref(cfg), 1, 100.0)
     cfg.precision = 9                                               # unknown precision code
@@ -83,12 +83,12 @@ def test_pack_host_rejects_bad_tables(lib):
 
 def test_split_packer_refuses_weights_outside_the_fp16_split_range(lib):
     """The fp16 hi/lo split has an operating range (include/posendf_amd.h, PNDF_PREC_F16X3): a layer whose largest
-    |weight| is below 2^-9 (lo halves subnormal) or above 6e4 (hi half overflows) is refused, not degraded."""
+    |weight| is below 2^-14 (lo halves subnormal even after the 2^8 scaling) or above 200 (hi half overflows) is refused, not degraded."""
     from posendf_amd import engine, synth
     sd = synth.make_weights(1)
     engine.pack_host(sd, lib, split=True)                       # ordinary weights pack
     tiny = dict(sd)
-    tiny["dfnet.lin2.weight"] = sd["dfnet.lin2.weight"] * 1e-3
+    tiny["dfnet.lin2.weight"] = sd["dfnet.lin2.weight"] * 1e-4
     engine.pack_host(tiny, lib)                                  # fine for the exact fp32 stream
     with pytest.raises(engine.PndfError):
         engine.pack_host(tiny, lib, split=True)

@@ -19,11 +19,11 @@ def torch_cuda():
     return torch
 
 
-PRECISIONS = ["fp32", "f16x3"]      # f16x3: fp16 hi/lo split operands, fp32 accumulate (relu / lrelu only)
+PRECISIONS = ["fp32", "f16x3"]      # f16x3: fp16 hi/lo split operands, fp32 accumulate
 
 
 def cases(acts):
-    return [(a, p) for a in acts for p in PRECISIONS if not (a == "softplus" and p == "f16x3")]
+    return [(a, p) for a in acts for p in PRECISIONS]
 
 
 def make_net(torch, act, regime=None, sd=None, precision="fp32"):
