@@ -70,9 +70,8 @@ def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0):
     few poses per thousand (measured: 1/1000 and 2/4096 poses for the numpy oracle, 3 % after 100 steps).
     Both error vectors are per-pose relative errors against the SAME fp64 truth; `ref_rows` is the
     reference-arithmetic (fp32) run that sets the envelope.  `ratio`: how many times the reference's own outlier
-    fraction is tolerated -- the kink-crossing probability is proportional to the size of the rounding perturbation,
-    so 2 for fp32 arithmetic in a different summation order and 3 for the split-precision kernel, whose
-    pre-activations carry 2.6e-6 against the fp32 run's 1e-6."""
+    fraction is tolerated (the kink-crossing probability is proportional to the size of the rounding perturbation;
+    both kernels are held to 2)."""
     mine_rows = np.asarray(mine_rows)
     ref_rows = np.asarray(ref_rows)
     n = len(mine_rows)
