@@ -323,3 +323,28 @@ def test_f16_single_is_a_bounded_approximation(torch_cuda):
     assert not torch.equal(d3, d.detach())
     qp, dl = net.project(q.detach(), steps=100)
     assert torch.isfinite(qp).all() and (dl >= 0).all()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_large_batch_indexing(torch_cuda, precision):
+    """1,000,003 poses (15,626 workgroups, ragged tail): 64-bit indexing of poses, outputs and the softplus scratch;
+    spot-checked against the oracle at the start, in the middle and at the very end."""
+    torch = torch_cuda
+    from oracle import posendf_np as onp
+    from posendf_amd import synth
+    B = 1_000_003
+    sd = golden_weights("live")
+    q = torch.from_numpy(synth.make_poses(B, seed=31)).cuda()
+    for act in ("lrelu", "softplus"):
+        net = make_net(torch, act, sd=sd, precision=precision)
+        with torch.no_grad():
+            d = net(q, train=False)["dist_pred"]
+        qp, dl = net.project(q, steps=2)
+        assert d.shape == (B, 1) and torch.isfinite(d).all() and torch.isfinite(qp).all()
+        for lo in (0, B // 2 - 3, B - 70):
+            sl = slice(lo, lo + 70 if lo + 70 <= B else B)
+            qs = q[sl].cpu().numpy()
+            d_o, _ = onp.forward_grad(qs, sd, act)
+            assert d_err(d[sl, 0].cpu().numpy(), d_o) < TOL
+            qp_o, _ = onp.project(qs, sd, steps=2, act=act)
+            assert np.median(rel_err_rows(qp[sl].cpu().numpy(), qp_o)) < TOL / 10
