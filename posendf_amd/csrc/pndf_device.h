@@ -190,17 +190,19 @@ __device__ __forceinline__ float relu_factor(float step, float slope) { return f
 // derivative as PyTorch's softplus_backward: e / (e + 1) with e = exp(beta x), 1 above the threshold.
 // On the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each) instead of libm's expf / log1pf /
 // IEEE division (~70 instructions per value: they made the softplus kernel 57 % slower than the relu one):
-//   e = 2^(min(beta x, 20) log2 e);  u = 1 + e;  log1p(e) = ln(u) * e / (u - 1)  (the rounding of 1 + e cancels; u == 1
-//   -> e);  derivative e / u.  ~18 instructions, a few ulp.
+//   e = 2^(min(beta x, 20) log2 e);  u = 1 + e;  log1p(e) = ln(u) + (e - (u - 1)) / u;  derivative e / u.
+//   ~15 instructions, a few ulp.
 __device__ __forceinline__ float act_softplus(float z, float beta, float& deriv) {
     const float bz = z * beta;
     const float e = __builtin_amdgcn_exp2f(fminf(bz, 20.0f) * 1.44269504088896341f);
     const bool lin = bz > 20.0f;
     const float u = 1.0f + e;
-    const float dm = u - 1.0f;                                   // exact
-    const float l = (dm == 0.0f) ? e : (__builtin_amdgcn_logf(u) * 0.693147180559945309f) * (e * __builtin_amdgcn_rcpf(dm));
-    deriv = lin ? 1.0f : e * __builtin_amdgcn_rcpf(u);
-    return lin ? z : l * __builtin_amdgcn_rcpf(beta);
+    const float ru = __builtin_amdgcn_rcpf(u);
+    // log1p(e) = ln(u) + ln((1 + e) / u) = ln(u) + (e - (u - 1)) / u + O(2^-48): the rounding of 1 + e is put back to
+    // first order, with the reciprocal the derivative needs anyway (three quarter-rate transcendentals per value)
+    const float l = fmaf(e - (u - 1.0f), ru, __builtin_amdgcn_logf(u) * 0.693147180559945309f);
+    deriv = lin ? 1.0f : e * ru;
+    return lin ? z : l * __builtin_amdgcn_rcpf(beta);      // beta is uniform: hipcc hoists this reciprocal
 }
 
 // Activation parameters + where derivatives are parked between the forward and the backward pass.
@@ -307,9 +309,9 @@ __device__ __forceinline__ float enc_act(f32x4& z, const ActP& ap, int spslot) {
 }
 
 template <bool SP>
-__device__ __forceinline__ void enc_dact(f32x4& gz, uint32_t bits4, const ActP& ap, int spslot) {
+__device__ __forceinline__ void enc_dact(f32x4& gz, uint32_t bits4, const ActP& ap, const f32x4& dpre) {
     if constexpr (SP) {
-        gz = gz * ap.sp[(size_t)spslot * WG_THREADS];
+        gz = gz * dpre;              // derivative fetched from the scratch at the start of encoder_backward
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) gz[r] = gz[r] * relu_factor((float)((bits4 >> r) & 1u), ap.slope);
@@ -459,7 +461,8 @@ constexpr bool enc_bwd_pairable(int j) { return j >= 1 && PARENT[j] != j - 1; }
 
 template <int J, bool SP>
 __device__ __forceinline__ void enc_bwd_step(float* my_gn, f32x4 (&GF)[NJ], const uint32_t (&eb)[6], const f32x4 (&t)[4],
-                                             Ring& ring, const ActP& ap, int g) {
+                                             Ring& ring, const ActP& ap, int g, const f32x4 (&D)[SP ? 2 * NJ : 1]) {
+    constexpr auto dslot = [](int tile) { return SP ? tile : 0; };
     constexpr bool PAIR = enc_bwd_pairable(J);
     constexpr int JN = J - (PAIR ? 2 : 1);                     // first joint of the next step (may be < 0)
     f32x4 n[4] = {t[0], t[1], t[2], t[3]};
@@ -468,16 +471,16 @@ __device__ __forceinline__ void enc_bwd_step(float* my_gn, f32x4 (&GF)[NJ], cons
         constexpr int K = J - 1;
         const uint32_t ba = (eb[J / 4] >> (8 * (J % 4))) & 0xffu, bb = (eb[K / 4] >> (8 * (K % 4))) & 0xffu;
         f32x4 za = GF[J], zb = GF[K];
-        enc_dact<SP>(za, ba >> 4, ap, SP_SLOT_ENC + 2 * J + 1);
-        enc_dact<SP>(zb, bb >> 4, ap, SP_SLOT_ENC + 2 * K + 1);
+        enc_dact<SP>(za, ba >> 4, ap, D[dslot(2 * J + 1)]);
+        enc_dact<SP>(zb, bb >> 4, ap, D[dslot(2 * K + 1)]);
         f32x4 Ha = f32x4{0.f, 0.f, 0.f, 0.f}, Hb = Ha;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             Ha = mfma4(t[0][s], za[s], Ha);
             Hb = mfma4(t[2][s], zb[s], Hb);
         }
-        enc_dact<SP>(Ha, ba & 0xfu, ap, SP_SLOT_ENC + 2 * J);
-        enc_dact<SP>(Hb, bb & 0xfu, ap, SP_SLOT_ENC + 2 * K);
+        enc_dact<SP>(Ha, ba & 0xfu, ap, D[dslot(2 * J)]);
+        enc_dact<SP>(Hb, bb & 0xfu, ap, D[dslot(2 * K)]);
         f32x4 Ia = f32x4{0.f, 0.f, 0.f, 0.f}, Ib = Ia;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -493,18 +496,18 @@ __device__ __forceinline__ void enc_bwd_step(float* my_gn, f32x4 (&GF)[NJ], cons
     } else {
         const uint32_t byte = (eb[J / 4] >> (8 * (J % 4))) & 0xffu;
         f32x4 gz2 = GF[J];
-        enc_dact<SP>(gz2, byte >> 4, ap, SP_SLOT_ENC + 2 * J + 1);
+        enc_dact<SP>(gz2, byte >> 4, ap, D[dslot(2 * J + 1)]);
         f32x4 GH = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) GH = mfma4(t[0][s], gz2[s], GH);
-        enc_dact<SP>(GH, byte & 0xfu, ap, SP_SLOT_ENC + 2 * J);
+        enc_dact<SP>(GH, byte & 0xfu, ap, D[dslot(2 * J)]);
         f32x4 GI = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s) GI = mfma4(t[1][s], GH[s], GI);
         if (g == 0) *(f32x4*)(my_gn + 4 * J) = GI;
         if constexpr (PARENT[J] >= 0) GF[PARENT[J]] = GF[PARENT[J]] + GI;
     }
-    if constexpr (JN >= 0) enc_bwd_step<JN, SP>(my_gn, GF, eb, n, ring, ap, g);
+    if constexpr (JN >= 0) enc_bwd_step<JN, SP>(my_gn, GF, eb, n, ring, ap, g, D);
 }
 
 // consumes d d / d feature from my_f, leaves d d / d n in my_gn
@@ -521,9 +524,16 @@ __device__ __forceinline__ void encoder_backward(float* my_f, float* my_gn, cons
         const bool live = (g == 1) || (g == 2);
         GF[j] = live ? f32x4{a, b, c, d} : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // softplus: all 42 parked derivatives of the encoder are fetched up front (at the point of use every joint
+    // stalled for two global-memory round trips)
+    f32x4 D[SP ? 2 * NJ : 1];
+    if constexpr (SP) {
+#pragma unroll
+        for (int i = 0; i < 2 * NJ; ++i) D[i] = ap.sp[(size_t)(SP_SLOT_ENC + i) * WG_THREADS];
+    }
     f32x4 t[4];
     enc_tiles<0, enc_bwd_pairable(NJ - 1) ? 4 : 2>(t, ring);
-    enc_bwd_step<NJ - 1, SP>(my_gn, GF, eb, t, ring, ap, g);
+    enc_bwd_step<NJ - 1, SP>(my_gn, GF, eb, t, ring, ap, g, D);
     wave_lds_fence();      // d d / d n written by lane group 0 is read by all lane groups
 }
 

@@ -42,7 +42,7 @@ struct PhaseBody {
     template <int GI>
     static __device__ __forceinline__ void groups(const f32x4 (&xin)[KA], f32x4 (&acc)[NB], f32x4 (&ch)[CT],
                                                   f32x4 (&cur)[GT], Ring& ring, uint8_t* mask, const ActP& ap,
-                                                  int spslot, int c, RegionClock* rc) {
+                                                  int spslot, int c, RegionClock* rc, const f32x4 (&dpre)[CT]) {
         if constexpr (GI < NG) {
             f32x4 nxt[GT];
             constexpr int TNEXT = ((GI + 1) * GT) % CHUNK_TILES;
@@ -96,7 +96,7 @@ struct PhaseBody {
                                 }
                                 *slot = dv;
                             } else {
-                                ch[ci] = ch[ci] * *slot;
+                                ch[ci] = ch[ci] * dpre[ci];
                             }
                         }
                     } else if (!BWD) {
@@ -142,7 +142,7 @@ struct PhaseBody {
                 rc->grp[GI] += now - rc->last;
                 rc->last = now;
             }
-            groups<GI + 1>(xin, acc, ch, cur, ring, mask, ap, spslot, c, rc);
+            groups<GI + 1>(xin, acc, ch, cur, ring, mask, ap, spslot, c, rc, dpre);
         }
     }
 };
@@ -161,8 +161,14 @@ __device__ __forceinline__ void run_phase(const f32x4 (&xin)[KA], f32x4 (&acc)[N
             if (!BWD) ch[ci] = *(const f32x4*)(biasA + 16 * (c * CT + ci) + 4 * g);
             else ch[ci] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        // backward softplus: the chunk's parked derivatives are fetched here, a whole part A before the epilogue needs
+        // them (fetched at the point of use, every chunk stalled for a global-memory round trip)
+        f32x4 dpre[CT];
+#pragma unroll
+        for (int ci = 0; ci < CT; ++ci)
+            dpre[ci] = (SP && BWD) ? ap.sp[(size_t)(spslot + c * CT + ci) * WG_THREADS] : f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (GTIME) rc->last = __builtin_amdgcn_s_memtime();
-        Body::template groups<0>(xin, acc, ch, cur, ring, mask, ap, spslot, c, rc);
+        Body::template groups<0>(xin, acc, ch, cur, ring, mask, ap, spslot, c, rc, dpre);
     }
 }
 

@@ -222,7 +222,7 @@ struct SplitPhase {
                     }
                     *slot = dv;
                 } else {
-                    y[ci] = (ch[0][ci] * ACC_TO_OPERAND) * *slot;
+                    y[ci] = (ch[0][ci] * ACC_TO_OPERAND) * ch[1][ci];      // derivative prefetched by init_chunk
                 }
             }
         } else if (!BWD) {
@@ -252,11 +252,15 @@ struct SplitPhase {
         for (int b = 0; b < CB; ++b) pack_blk<SINGLE>(y[2 * b], y[2 * b + 1], out[b]);
     }
 
-    static __device__ __forceinline__ void init_chunk(f32x4 (&ch)[3][CT], const float* biasA, int c, int g) {
+    // Backward softplus: the chunk's parked derivatives are fetched HERE, a whole part A (thousands of cycles) before the
+    // epilogue multiplies by them -- fetched at the point of use, every chunk stalled for a global-memory round trip.
+    // They ride in the second partial-accumulator slot, which is free when PARTIALS == 1.
+    static __device__ __forceinline__ void init_chunk(f32x4 (&ch)[3][CT], const float* biasA, int c, int g, const SAct& act) {
 #pragma unroll
         for (int ci = 0; ci < CT; ++ci) {
             ch[0][ci] = BWD ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(biasA + 16 * (c * CT + ci) + 4 * g);
-            ch[1][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (SP && BWD) ch[1][ci] = act.sp[(size_t)(act.spslot + c * CT + ci) * WG_THREADS];
+            else ch[1][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
             ch[2][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -335,14 +339,14 @@ struct SplitPhase {
         dp.dst = 0;
         f32x4 ch[3][CT];
         Blk chb[CB];
-        init_chunk(ch, biasA, 0, g);
+        init_chunk(ch, biasA, 0, g, act);
         part_a<0>(xin, ch, cur, ring, dp);
         epilogue(ch, chb, mask, 0, act);
         for (int c = 0; c < NC; ++c) {
             const bool more = c + 1 < NC;
             Blk nextb[CB];
             if (more) {
-                init_chunk(ch, biasA, c + 1, g);
+                init_chunk(ch, biasA, c + 1, g, act);
                 part_a<0>(xin, ch, cur, ring, dp);
             }
             part_b<0>(chb, acc, cur, ring, dp, more, ch, nextb, mask, c, act);
@@ -461,14 +465,14 @@ struct HalfPhase {
         dp.dst = 0;
         f32x4 ch[3][CT];
         Blk chb[CB];
-        Base::init_chunk(ch, biasA, 0, g);
+        Base::init_chunk(ch, biasA, 0, g, act);
         part_a<0>(xin, ch, cur, ring, dp);
         Base::epilogue(ch, chb, mask, 0, act);
         for (int c = 0; c < NC; ++c) {
             const bool more = c + 1 < NC;
             Blk nextb[CB];
             if (more) {
-                Base::init_chunk(ch, biasA, c + 1, g);
+                Base::init_chunk(ch, biasA, c + 1, g, act);
                 part_a<0>(xin, ch, cur, ring, dp);
             }
             part_b<0>(chb, acc, cur, ring, dp, more, ch, nextb, mask, c, act);
