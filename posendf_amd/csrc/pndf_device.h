@@ -212,7 +212,25 @@ struct ActP {
     float slope;        // relu family
     float beta;         // softplus
     f32x4* sp;          // softplus: this thread's column of the scratch ([slot][256] float4), else null
+    char* stage;        // softplus backward: this wave's LDS staging window for derivative tiles (its own F rows,
+    int lane;           //   free between the forward trunk and the end of the backward trunk); lane id
 };
+
+// One parked derivative tile of this wave (64 lanes x 16 B, contiguous in the scratch) -> LDS by DMA.  The chunk
+// layers' derivatives must not come in as ordinary global loads: those share the in-order vmcnt queue with the ring's
+// inline-asm DMA, which hipcc cannot see, so its own `s_waitcnt vmcnt(0)` at the point of use would drain every DMA
+// piece in flight.  The consumer waits with `vmcnt(N)`, N = number of ring pieces certainly issued in between.
+__device__ __forceinline__ void stage_derivative_tile(const f32x4* src, char* stage_tile) {
+    const uint32_t dst = (uint32_t)(size_t)(PNDF_LDS char*)stage_tile;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory", "m0");
+}
+template <int YOUNGER>
+__device__ __forceinline__ void wait_staged_derivatives() {
+    if constexpr (YOUNGER >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (YOUNGER >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (YOUNGER >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 constexpr int SP_SLOT_CHUNK[3] = {0, 16, 80};      // chunk layers x1 (8x2), x3 (32x2), x5 (4x4)
 constexpr int SP_SLOT_X2 = 96, SP_SLOT_X4 = 128, SP_SLOT_X6 = 160, SP_SLOT_ENC = 164;   // encoder: 2 tiles per joint
 constexpr int SP_SLOTS = SP_SLOT_ENC + 2 * NJ;

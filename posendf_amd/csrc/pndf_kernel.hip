@@ -96,7 +96,8 @@ struct PhaseBody {
                                 }
                                 *slot = dv;
                             } else {
-                                ch[ci] = ch[ci] * dpre[ci];
+                                if (ci == 0) wait_staged_derivatives<(KA * CT / 4 < 12) ? KA * CT / 4 : 12>();
+                                ch[ci] = ch[ci] * *(const f32x4*)(ap.stage + ci * 1024 + ap.lane * 16);
                             }
                         }
                     } else if (!BWD) {
@@ -162,11 +163,13 @@ __device__ __forceinline__ void run_phase(const f32x4 (&xin)[KA], f32x4 (&acc)[N
             else ch[ci] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         // backward softplus: the chunk's parked derivatives are fetched here, a whole part A before the epilogue needs
-        // them (fetched at the point of use, every chunk stalled for a global-memory round trip)
+        // them, by DMA into the wave's LDS staging window (stage_derivative_tile); part A issues KA * CT / 4 ring pieces
         f32x4 dpre[CT];
 #pragma unroll
-        for (int ci = 0; ci < CT; ++ci)
-            dpre[ci] = (SP && BWD) ? ap.sp[(size_t)(spslot + c * CT + ci) * WG_THREADS] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ci = 0; ci < CT; ++ci) {
+            dpre[ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (SP && BWD) stage_derivative_tile(ap.sp + (size_t)(spslot + c * CT + ci) * WG_THREADS, ap.stage + ci * 1024);
+        }
         if constexpr (GTIME) rc->last = __builtin_amdgcn_s_memtime();
         Body::template groups<0>(xin, acc, ch, cur, ring, mask, ap, spslot, c, rc, dpre);
     }
@@ -242,6 +245,8 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     ap.beta = args.beta;
     float* const wg_scratch = SP ? args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS : nullptr;
     ap.sp = SP ? (f32x4*)wg_scratch + tid : nullptr;
+    ap.stage = (char*)(smem + LDS_F) + wave * (16 * FSTRIDE * 4);
+    ap.lane = lane;
     const long long pose0 = (long long)blockIdx.x * WG_POSES;
     float* const lds_bias = (float*)(smem + LDS_BIAS);
     uint8_t* const lds_mask = (uint8_t*)(smem + LDS_MASK) + tid;

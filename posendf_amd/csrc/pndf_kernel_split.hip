@@ -71,6 +71,8 @@ struct SAct {
     float slope, beta;
     f32x4* sp;
     int spslot;
+    char* stage;      // softplus backward: this wave's LDS staging window for derivative tiles (1 KiB per tile)
+    int lane;
 };
 
 // Power-of-two operand scaling (exact).  An fp16 lo half is ~2^-11 of its value and turns SUBNORMAL below 2^-14: with
@@ -222,7 +224,8 @@ struct SplitPhase {
                     }
                     *slot = dv;
                 } else {
-                    y[ci] = (ch[0][ci] * ACC_TO_OPERAND) * ch[1][ci];      // derivative prefetched by init_chunk
+                    if (ci == 0) wait_staged_derivatives<STAGE_YOUNGER>();
+                    y[ci] = (ch[0][ci] * ACC_TO_OPERAND) * *(const f32x4*)(act.stage + ci * 1024 + act.lane * 16);
                 }
             }
         } else if (!BWD) {
@@ -253,14 +256,16 @@ struct SplitPhase {
     }
 
     // Backward softplus: the chunk's parked derivatives are fetched HERE, a whole part A (thousands of cycles) before the
-    // epilogue multiplies by them -- fetched at the point of use, every chunk stalled for a global-memory round trip.
-    // They ride in the second partial-accumulator slot, which is free when PARTIALS == 1.
+    // epilogue multiplies by them, by DMA into the wave's staging window (single-buffered: the epilogue that reads it
+    // runs before the next init_chunk).  At least STAGE_YOUNGER ring pieces are issued between the fetch and its use,
+    // so `vmcnt(STAGE_YOUNGER)` there proves the tiles have landed without draining the ring.
+    static constexpr int STAGE_YOUNGER = (2 * AG < 12) ? 2 * AG : 12;
     static __device__ __forceinline__ void init_chunk(f32x4 (&ch)[3][CT], const float* biasA, int c, int g, const SAct& act) {
 #pragma unroll
         for (int ci = 0; ci < CT; ++ci) {
             ch[0][ci] = BWD ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(biasA + 16 * (c * CT + ci) + 4 * g);
-            if constexpr (SP && BWD) ch[1][ci] = act.sp[(size_t)(act.spslot + c * CT + ci) * WG_THREADS];
-            else ch[1][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (SP && BWD) stage_derivative_tile(act.sp + (size_t)(act.spslot + c * CT + ci) * WG_THREADS, act.stage + ci * 1024);
+            ch[1][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
             ch[2][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
@@ -556,7 +561,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
     ap.slope = args.slope;
     ap.beta = args.beta;
     ap.sp = SP ? (f32x4*)(args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS) + tid : nullptr;
-    auto layer = [&](int spslot) { return SAct{args.slope, args.beta, ap.sp, spslot}; };
+    auto layer = [&](int spslot) { return SAct{args.slope, args.beta, ap.sp, spslot, (char*)(smem + LDS_F) + wave * (16 * FSTRIDE * 4), lane}; };
     const long long pose0 = (long long)blockIdx.x * WG_POSES;
     float* const lds_bias = (float*)(smem + LDS_BIAS);
     uint8_t* const lds_mask = (uint8_t*)(smem + LDS_MASK) + tid;
