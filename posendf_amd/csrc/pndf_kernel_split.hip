@@ -246,8 +246,9 @@ struct SplitPhase {
             for (int ci = 0; ci < CT; ++ci) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float z = ((PARTIALS == 3) ? (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r] : ch[0][ci][r]) * ACC_TO_OPERAND;
-                    y[ci][r] = z * relu_factor((float)((bits >> (ci * 4 + r)) & 1u), slope);
+                    const float z = (PARTIALS == 3) ? (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r] : ch[0][ci][r];
+                    // derivative factor with the accumulator -> operand scale folded in (both exact powers of two apart)
+                    y[ci][r] = z * fmaf((float)((bits >> (ci * 4 + r)) & 1u), (1.0f - slope) * ACC_TO_OPERAND, slope * ACC_TO_OPERAND);
                 }
             }
         }
@@ -538,7 +539,7 @@ __device__ __forceinline__ void dact_split_tiles(f32x4 (&gx)[NT], Blk (&out)[NT 
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                gx[t][r] = (gx[t][r] * ACC_TO_OPERAND) * relu_factor((float)((m[(t * 4 + r) / 32] >> ((t * 4 + r) % 32)) & 1u), act.slope);
+                gx[t][r] = gx[t][r] * fmaf((float)((m[(t * 4 + r) / 32] >> ((t * 4 + r) % 32)) & 1u), (1.0f - act.slope) * ACC_TO_OPERAND, act.slope * ACC_TO_OPERAND);
         }
         if (t & 1) pack_blk<SINGLE>(gx[t - 1], gx[t], out[t / 2]);
     }
