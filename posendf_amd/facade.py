@@ -12,6 +12,7 @@ gfx950 device, train=False raises.
 from __future__ import annotations
 
 import os
+import warnings
 
 import torch
 import torch.nn as nn
@@ -71,9 +72,11 @@ class PoseNDF(nn.Module):
             self.loss_l1 = nn.L1Loss()
         elif self.loss == "l2":
             self.loss_l1 = nn.MSELoss()
-        # engine knob (no reference counterpart): arithmetic of the trunk, "fp32" (exact) or "f16x3" (fp16 hi/lo
-        # split, fp32 accumulate, fp32-class accuracy); opt["engine"]["precision"] or $PNDF_PRECISION
-        self._precision = (opt.get("engine") or {}).get("precision") or os.environ.get("PNDF_PRECISION", "fp32")
+        # engine knob (no reference counterpart): arithmetic of the trunk -- "fp32" (exact fp32 MFMA), "f16x3" (fp16
+        # hi/lo split, fp32 accumulate: fp32-class accuracy, same parity gates, ~3x the throughput), "auto" (default:
+        # f16x3, or fp32 with a warning when a layer's weights are outside the split's operating range), "f16"
+        # (reduced precision, comparison only); opt["engine"]["precision"] or $PNDF_PRECISION
+        self._precision = (opt.get("engine") or {}).get("precision") or os.environ.get("PNDF_PRECISION", "auto")
         self._act = opt["model"]["DFNet"]["act"]
         self._beta = float(opt["model"]["DFNet"].get("beta", 100.0))
         if self.enc is not None and opt["model"]["StrEnc"]["act"] != self._act:
@@ -100,11 +103,20 @@ class PoseNDF(nn.Module):
         if entry is None:
             # the plain-f16 comparison kernel is relu-family only; fp32 and f16x3 implement all three activations
             prec = "fp32" if (self._act == "softplus" and self._precision == "f16") else self._precision
-            entry = [Engine(self._act, self._beta, idx, precision=prec), None]
+            entry = [Engine(self._act, self._beta, idx, precision="f16x3" if prec == "auto" else prec), None]
             self._engines[idx] = entry
         if entry[1] != fp:          # first use, load_state_dict, optimiser step, .to(): re-pack the weights
             sd = self.state_dict()
-            entry[0].load_weights({k: sd[k].detach().float().cpu().numpy() for k in state_dict_order()})
+            weights = {k: sd[k].detach().float().cpu().numpy() for k in state_dict_order()}
+            try:
+                entry[0].load_weights(weights)
+            except PndfError as e:
+                if self._precision != "auto" or entry[0].precision != "f16x3" or "operating" not in str(e):
+                    raise
+                # both are HIP kernels: this is a choice of arithmetic, not a fallback off the engine
+                warnings.warn(f"posendf_amd: {e}; precision 'auto' selects the exact fp32 kernel for this network")
+                entry[0] = Engine(self._act, self._beta, idx, precision="fp32")
+                entry[0].load_weights(weights)
             entry[1] = fp
         return entry[0]
 

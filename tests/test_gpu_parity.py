@@ -348,3 +348,29 @@ def test_large_batch_indexing(torch_cuda, precision):
             assert d_err(d[sl, 0].cpu().numpy(), d_o) < TOL
             qp_o, _ = onp.project(qs, sd, steps=2, act=act)
             assert np.median(rel_err_rows(qp[sl].cpu().numpy(), qp_o)) < TOL / 10
+
+
+def test_precision_auto_selects_by_weight_range(torch_cuda):
+    """Default precision 'auto': the split kernel when every trunk layer is inside its operating range, the exact
+    fp32 kernel (with a warning) when not -- both are HIP kernels, there is no fallback off the engine."""
+    import warnings
+    torch = torch_cuda
+    from posendf_amd import PoseNDF, amass_config, synth
+    sd = golden_weights("live")
+    q = torch.from_numpy(synth.make_poses(64, seed=3)).cuda()
+    net = PoseNDF(amass_config("lrelu", "cuda:0"))                 # no engine key, no env override -> auto
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    d = net(q, train=False)["dist_pred"]
+    assert net._engine_for(q.device).precision == "f16x3"
+    tiny = {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+    tiny["dfnet.lin3.weight"] *= 1e-5                              # lo halves would be subnormal
+    net2 = PoseNDF(amass_config("lrelu", "cuda:0"))
+    net2.load_state_dict(tiny)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        d2 = net2(q, train=False)["dist_pred"]
+    assert net2._engine_for(q.device).precision == "fp32" and any("operating range" in str(x.message) for x in w)
+    from oracle import posendf_np as onp
+    d_o, _ = onp.forward_grad(q.cpu().numpy(), {k: v.numpy() for k, v in tiny.items()}, "lrelu")
+    assert d_err(d2.detach().cpu().numpy().ravel(), d_o.ravel()) < TOL
+    assert torch.isfinite(d).all()

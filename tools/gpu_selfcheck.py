@@ -56,7 +56,9 @@ def err(a, b):
 def main():
     act = sys.argv[1] if len(sys.argv) > 1 else "lrelu"
     sd = synth.make_weights(0, 2.5, 0.05)
-    net = PoseNDF(amass_config(act, "cuda:0"))
+    cfg = amass_config(act, "cuda:0")
+    cfg["engine"] = {"precision": "fp32"}          # the stage-dump kernel exists for the exact fp32 arithmetic
+    net = PoseNDF(cfg)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     q_np = synth.make_poses(64, seed=7, signed=True)
     q = torch.from_numpy(q_np).cuda()
