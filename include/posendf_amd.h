@@ -45,7 +45,8 @@ typedef struct {
     float beta;             /* Softplus beta (amass.yaml:32,43); ignored for relu / lrelu */
     int32_t num_joints;     /* 21 */
     int32_t n_dims;         /* 8: in_dim, dims..., 1 */
-    int32_t dims[16];       /* 126,256,512,1024,512,256,64,1 (amass.yaml:26,30) */
+    int32_t dims[16];       /* 126,256,512,1024,512,256,64,1 (amass.yaml:26,30); dims[0] = 84 selects the
+                               encoder-less model (model.StrEnc.use = False, model/posendf.py:40-42,73-74) */
     int32_t parent[32];     /* net_utils.py:46 */
     int32_t precision;      /* pndf_precision: arithmetic of the trunk (engine knob, no reference counterpart) */
 } pndf_config;
@@ -70,7 +71,8 @@ int pndf_destroy(pndf_handle h);
 
 /* load_state_dict (sample_poses.py:90-91).  `tensors` are HOST pointers in state-dict order:
  * for i in 0..20: enc.net.i.net.0.weight [10,in], .bias [10], enc.net.i.net.2.weight [6,10], .bias [6];
- * then for l in 0..6: dfnet.lin{l}.weight [out,in] row-major, .bias [out]   (98 tensors).
+ * then for l in 0..6: dfnet.lin{l}.weight [out,in] row-major, .bias [out]   (98 tensors; the 14 dfnet tensors
+ * only when dims[0] == 84).
  * `numel[i]` is checked against the architecture.  Weights are re-packed into MFMA tile order and
  * uploaded; the call synchronises. */
 int pndf_load_weights(pndf_handle h, const float* const* tensors, const int64_t* numel, int n_tensors);

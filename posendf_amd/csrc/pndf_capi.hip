@@ -30,6 +30,7 @@ struct PndfKernelArgs {
     float beta;
     float* scratch;
     int dbg_nslots;
+    int noenc;
 };
 extern "C" __global__ void pndf_fused_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_softplus_kernel(PndfKernelArgs args);
@@ -92,8 +93,8 @@ static int check_config(pndf_engine* h, const pndf_config* cfg) {
     if (cfg->num_joints != NJ || cfg->n_dims != NLIN + 1)
         return fail(h, PNDF_ERR_UNSUPPORTED, "only the 21-joint, 7-layer configs/amass.yaml architecture is implemented");
     for (int i = 0; i <= NLIN; ++i)
-        if (cfg->dims[i] != DIMS[i])
-            return fail(h, PNDF_ERR_UNSUPPORTED, "DFNet dims must be 126,256,512,1024,512,256,64,1 (StrEnc.use=True)");
+        if (cfg->dims[i] != DIMS[i] && !(i == 0 && cfg->dims[0] == NOENC_IN))
+            return fail(h, PNDF_ERR_UNSUPPORTED, "DFNet dims must be 126 (StrEnc.use=True) or 84 (False),256,512,1024,512,256,64,1");
     for (int i = 0; i < NJ; ++i)
         if (cfg->parent[i] != PARENT[i]) return fail(h, PNDF_ERR_UNSUPPORTED, "parent table must be get_parent_mapping('smpl')");
     if (cfg->act != PNDF_ACT_RELU && cfg->act != PNDF_ACT_LRELU && cfg->act != PNDF_ACT_SOFTPLUS)
@@ -211,17 +212,24 @@ void emit_enc_tile(const EncMat& m, float* dst) {
 }
 }  // namespace
 
+// in_dim of the trunk: 126 with the structure encoder, 84 = 21 x 4 without it (model.StrEnc.use = False, reference
+// model/posendf.py:40-42,73-74: DFNet sees the normalised quaternions, `p.reshape(len(p), -1)` net_modules.py:49)
+static bool table_has_encoder(int n) { return n == 4 * NJ + 2 * NLIN; }
+static int lin_in(int l, bool enc) { return (l == 0 && !enc) ? NOENC_IN : DIMS[l]; }
+
 static const char* check_tensors(const float* const* tensors, const int64_t* numel, int n) {
     if (!tensors || !numel) return "tensors / numel is null";
-    if (n != 4 * NJ + 2 * NLIN) return "expected 98 tensors in state-dict order";
+    if (n != 4 * NJ + 2 * NLIN && n != 2 * NLIN)
+        return "expected 98 tensors (encoder + dfnet) or 14 (dfnet only, StrEnc.use = False) in state-dict order";
+    const bool enc = table_has_encoder(n);
     int t = 0;
-    for (int j = 0; j < NJ; ++j) {
+    for (int j = 0; enc && j < NJ; ++j) {
         const int64_t want[4] = {HID * enc_in(j), HID, FEAT * HID, FEAT};
         for (int k = 0; k < 4; ++k, ++t)
             if (!tensors[t] || numel[t] != want[k]) return "encoder tensor missing or of the wrong size";
     }
     for (int l = 0; l < NLIN; ++l) {
-        if (!tensors[t] || numel[t] != (int64_t)DIMS[l + 1] * DIMS[l]) return "dfnet weight missing or of the wrong size";
+        if (!tensors[t] || numel[t] != (int64_t)DIMS[l + 1] * lin_in(l, enc)) return "dfnet weight missing or of the wrong size";
         ++t;
         if (!tensors[t] || numel[t] != DIMS[l + 1]) return "dfnet bias missing or of the wrong size";
         ++t;
@@ -234,26 +242,27 @@ extern "C" int pndf_pack_host(const float* const* tensors, const int64_t* numel,
     if (check_tensors(tensors, numel, n_tensors) || !stream || !bias) return PNDF_ERR_BAD_SHAPE;
     // ---- bias block: b0..b5 | w6 | b6 | per joint: b1 padded to 16, b2 on rows 4..9 of 16
     memset(bias, 0, BIAS_FLOATS * sizeof(float));
-    const float* const* lin = tensors + 4 * NJ;
+    const bool enc = table_has_encoder(n_tensors);     // without the encoder its tiles / biases stay zero (skipped on chip)
+    const float* const* lin = tensors + (enc ? 4 * NJ : 0);
     for (int l = 0; l < NLIN - 1; ++l) memcpy(bias + BIAS_OFF[l], lin[2 * l + 1], sizeof(float) * DIMS[l + 1]);
     memcpy(bias + W6_OFF, lin[2 * (NLIN - 1)], sizeof(float) * DIMS[NLIN - 1]);
     bias[BIAS_OFF[NLIN - 1]] = lin[2 * (NLIN - 1) + 1][0];
-    for (int j = 0; j < NJ; ++j) {
+    for (int j = 0; enc && j < NJ; ++j) {
         memcpy(bias + ENCB_OFF + 32 * j, tensors[4 * j + 1], sizeof(float) * HID);
         memcpy(bias + ENCB_OFF + 32 * j + 16 + ENC_FEAT_ROW, tensors[4 * j + 3], sizeof(float) * FEAT);
     }
     // ---- stream: encoder forward tiles | trunk phases | encoder backward tiles, in consumption order
     float* dst = stream;
     memset(stream, 0, (size_t)STEP_TILES * TILE_FLOATS * sizeof(float));
-    for (int j = 0; j < NJ; ++j) {                                  // forward: joint order, W1 then W2
+    for (int j = 0; enc && j < NJ; ++j) {                           // forward: joint order, W1 then W2
         for (int kind = 0; kind < 2; ++kind, dst += TILE_FLOATS)
             emit_enc_tile(EncMat{tensors[4 * j], tensors[4 * j + 2], enc_in(j), kind}, dst);
     }
     dst = stream + (size_t)ENC_TILES_PADDED * TILE_FLOATS;
     for (int ph = 0; ph < 6; ++ph) {
         const Phase& P = PHASES[ph];
-        const Mat A{lin[2 * P.a_lin], DIMS[P.a_lin + 1], DIMS[P.a_lin], P.transposed};
-        const Mat B{lin[2 * P.b_lin], DIMS[P.b_lin + 1], DIMS[P.b_lin], P.transposed};
+        const Mat A{lin[2 * P.a_lin], DIMS[P.a_lin + 1], lin_in(P.a_lin, enc), P.transposed};
+        const Mat B{lin[2 * P.b_lin], DIMS[P.b_lin + 1], lin_in(P.b_lin, enc), P.transposed};
         for (int c = 0; c < P.NC; ++c) {
             for (int kt = 0; kt < P.KA; ++kt)                       // part A: (kt, ci)
                 for (int ci = 0; ci < P.CT; ++ci, dst += TILE_FLOATS) emit_tile(A, c * P.CT + ci, kt, dst);
@@ -263,7 +272,7 @@ extern "C" int pndf_pack_host(const float* const* tensors, const int64_t* numel,
         }
     }
     if (dst - stream != (ptrdiff_t)(ENC_TILES_PADDED + TRUNK_FWD_TILES + TRUNK_BWD_TILES) * TILE_FLOATS) return PNDF_ERR_BAD_SHAPE;
-    for (int j = NJ - 1; j >= 0; --j) {                             // backward: reverse joint order, W2^T then W1^T
+    for (int j = NJ - 1; enc && j >= 0; --j) {                      // backward: reverse joint order, W2^T then W1^T
         for (int kind = 2; kind < 4; ++kind, dst += TILE_FLOATS)
             emit_enc_tile(EncMat{tensors[4 * j], tensors[4 * j + 2], enc_in(j), kind}, dst);
     }
@@ -297,7 +306,8 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
     int rc = pndf_pack_host(tensors, numel, n_tensors, stream, bias);
     if (rc != PNDF_OK) return rc;
     for (int i = 0; i < W6_OFF; ++i) bias[i] *= SPLIT_BIAS_SCALE;      // biases of lin0..lin5 (lin6 runs in fp32)
-    const float* const* lin = tensors + 4 * NJ;
+    const bool enc = table_has_encoder(n_tensors);
+    const float* const* lin = tensors + (enc ? 4 * NJ : 0);
     // Operating range of the fp16 hi/lo split: the lo half of a (2^8-scaled) weight is ~2^-3 |w|, and fp16 turns
     // subnormal below 2^-14, so a layer whose LARGEST weight is below 2^-14 would carry most of its lo halves with a
     // few bits only; above 2^-8 * 65504 the hi half overflows.  Refuse instead of degrading silently: such a
@@ -305,7 +315,7 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
     for (int l = 0; l < 6; ++l) {
         float mx = 0.f;
         bool nan = false;
-        const int64_t n = (int64_t)DIMS[l + 1] * DIMS[l];
+        const int64_t n = (int64_t)DIMS[l + 1] * lin_in(l, enc);
         for (int64_t i = 0; i < n; ++i) {
             const float a = std::fabs(lin[2 * l][i]);
             nan |= (a != a);
@@ -316,8 +326,8 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
     float* dst = stream + (size_t)ENC_TILES_PADDED * TILE_FLOATS;
     for (int ph = 0; ph < 6; ++ph) {
         const Phase& P = PHASES[ph];
-        const Mat A{lin[2 * P.a_lin], DIMS[P.a_lin + 1], DIMS[P.a_lin], P.transposed};
-        const Mat B{lin[2 * P.b_lin], DIMS[P.b_lin + 1], DIMS[P.b_lin], P.transposed};
+        const Mat A{lin[2 * P.a_lin], DIMS[P.a_lin + 1], lin_in(P.a_lin, enc), P.transposed};
+        const Mat B{lin[2 * P.b_lin], DIMS[P.b_lin + 1], lin_in(P.b_lin, enc), P.transposed};
         auto partA = [&](int c) {
             for (int kb = 0; kb < P.KA / 2; ++kb)
                 for (int ci = 0; ci < P.CT; ++ci, dst += 2 * TILE_FLOATS) emit_pair(A, c * P.CT + ci, kb, dst);
@@ -339,6 +349,8 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
 extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, const int64_t* numel, int n_tensors) {
     if (!h) return PNDF_ERR_BAD_ARG;
     if (const char* why = check_tensors(tensors, numel, n_tensors)) return fail(h, PNDF_ERR_BAD_SHAPE, why);
+    if (table_has_encoder(n_tensors) != (h->cfg.dims[0] == DIMS[0]))
+        return fail(h, PNDF_ERR_BAD_SHAPE, "tensor table does not match the configured in_dim (98 tensors for 126, 14 for 84)");
     std::vector<float> stream((size_t)STEP_TILES * TILE_FLOATS), bias(BIAS_FLOATS);
     const int prc = (h->cfg.precision != PNDF_PREC_FP32)
                         ? pndf_pack_host_split(tensors, numel, n_tensors, stream.data(), bias.data())
@@ -375,8 +387,10 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
     a.beta = h->cfg.beta;
     a.scratch = nullptr;
     a.dbg_nslots = 0;
+    a.noenc = (h->cfg.dims[0] == NOENC_IN) ? 1 : 0;
     if (const char* e = getenv("PNDF_DEBUG_NSLOTS")) a.dbg_nslots = atoi(e);   // timing experiments only
     const bool softplus = h->cfg.act == PNDF_ACT_SOFTPLUS;
+    if (a.noenc && dbg && !timing) return fail(h, PNDF_ERR_UNSUPPORTED, "the stage-dump kernel expects the structure encoder");
     if (softplus && dbg) return fail(h, PNDF_ERR_UNSUPPORTED, "the debug dump exists for the relu-family kernel only");
     if (mode == MODE_PROJECT && steps == 0) {
         // zero iterations: the loop body never runs (sample_poses.py:70); poses pass through

@@ -555,6 +555,35 @@ __device__ __forceinline__ void encoder_backward(float* my_f, float* my_gn, cons
     wave_lds_fence();      // d d / d n written by lane group 0 is read by all lane groups
 }
 
+// ---- model.StrEnc.use = False (reference model/posendf.py:40-42,73-74): no encoder, DFNet's input is the normalised
+// pose itself, x0[4 j + c] = n[j][c] (p.reshape(len(p), -1), net_modules.py:49), zero padded to 128 rows; lin0's packed
+// tiles carry zero columns beyond 84.  The stream keeps its (now all-zero) encoder sections so that every phase starts on
+// the same slot as with the encoder: they are skipped slot by slot with the ring's usual events.
+__device__ __forceinline__ void ring_skip_encoder_section(Ring& ring) {
+#pragma unroll 1
+    for (int s = 0; s < ENC_TILES_PADDED / SLOT_TILES; ++s) {
+        ring_boundary(ring);
+        ring_midslot_sync(ring);
+        ring_dma(ring, ring_fill_buffer(ring));
+    }
+}
+__device__ __forceinline__ void noenc_forward(const float* my_q, float* my_f, int g) {
+    float ss[4], inv[4];
+    joint_axis_norms(my_q, ss);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) inv[c] = 1.0f / fmaxf(sqrtf(ss[c]), 1e-12f);
+    for (int j = g; j < 32; j += 4) {          // rows 84..127 of x0 are zero
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j < NJ) {
+            const f32x4 qj = *(const f32x4*)(my_q + 4 * j);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = qj[c] * inv[c];
+        }
+        *(f32x4*)(my_f + 4 * j) = v;
+    }
+    wave_lds_fence();      // written by one lane group each, read by all (x0)
+}
+
 template <int NT>
 __device__ __forceinline__ void load_bias(f32x4 (&acc)[NT], const float* bias, int g) {
 #pragma unroll
@@ -589,5 +618,6 @@ struct PndfKernelArgs {
     float beta;             // softplus beta
     float* scratch;         // softplus: gridDim.x * SP_WG_FLOATS floats of derivative scratch, else null
     int dbg_nslots;         // 0, or (timing experiments only, wrong results) wrap the weight stream after n slots
+    int noenc;              // 1 = model.StrEnc.use False: the trunk sees the normalised quaternions (in_dim 84)
 };
 

@@ -301,7 +301,12 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
             f32x4 x2[32];
             {
                 // ---------------- normalise + encoder forward (posendf.py:71, net_modules.py:162-169)
-                encoder_forward<SP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ap, g);
+                if (args.noenc) {
+                    noenc_forward(my_q, my_f, g);
+                    ring_skip_encoder_section(ring);
+                } else {
+                    encoder_forward<SP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ap, g);
+                }
                 if (DBG && dbg && step == 0) {
                     for (int i = 0; i < NFEAT; ++i) dbg[(size_t)(DBG_FEAT + i) * WG_THREADS + tid] = my_f[i];
                 }
@@ -404,7 +409,8 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
 
         tick<TIMING>(rc, 9);
         // ---------------- encoder backward + normalise backward + update
-        encoder_backward<SP>(my_f, my_gn, eb, ring, ap, g);
+        if (args.noenc) ring_skip_encoder_section(ring);     // d d / d n is already where my_gn expects it (my_gn aliases my_f)
+        else encoder_backward<SP>(my_f, my_gn, eb, ring, ap, g);
         if (DBG && dbg && step == 0) {
             for (int i = 0; i < NQ; ++i) dbg[(size_t)(DBG_GN + i) * WG_THREADS + tid] = my_gn[i];
         }

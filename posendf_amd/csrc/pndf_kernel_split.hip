@@ -613,7 +613,12 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
         {
             Blk b2[16];
             {
-                encoder_forward<SP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ap, g);
+                if (args.noenc) {
+                    noenc_forward(my_q, my_f, g);
+                    ring_skip_encoder_section(ring);
+                } else {
+                    encoder_forward<SP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ap, g);
+                }
                 Blk b0[4];
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
@@ -708,7 +713,8 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
 
         tick<TIMING>(rc, 9);
         // ---------------- encoder backward + normalise backward + update (fp32, as pndf_kernel.hip)
-        encoder_backward<SP>(my_f, my_gn, eb, ring, ap, g);
+        if (args.noenc) ring_skip_encoder_section(ring);     // d d / d n is already where my_gn expects it (my_gn aliases my_f)
+        else encoder_backward<SP>(my_f, my_gn, eb, ring, ap, g);
         tick<TIMING>(rc, 10);
         {
             float ss[4], dot[4], denom[4], kk[4];

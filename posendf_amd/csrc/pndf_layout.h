@@ -95,6 +95,7 @@ enum Precision { PREC_FP32 = 0, PREC_F16X3 = 1, PREC_F16 = 2 };
 // bias block (floats) copied to LDS: b0..b5, then w6 (64), then b6
 constexpr int BIAS_OFF[NLIN] = {0, 256, 768, 1792, 2304, 2560, 2688};
 constexpr int W6_OFF = 2624;
+constexpr int NOENC_IN = 84;        // DFNet in_dim without the structure encoder (model.StrEnc.use = False): 21 x 4
 constexpr int ENCB_OFF = 2692;      // encoder biases: per joint b1 padded to 16, then b2 on rows 4..9 of 16
 constexpr int BIAS_FLOATS = ENCB_OFF + 21 * 32;
 

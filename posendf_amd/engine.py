@@ -82,14 +82,15 @@ EXPORTS = ("pndf_default_config", "pndf_create", "pndf_destroy", "pndf_load_weig
            "pndf_last_error", "pndf_version")
 
 
-def state_dict_order():
-    """Keys in the order pndf_load_weights expects (== reference state_dict order)."""
-    from .synth import state_dict_shapes
-    return list(state_dict_shapes().keys())
+def state_dict_order(encoder: bool = True):
+    """Keys in the order pndf_load_weights expects (== reference state_dict order): 98 tensors with the structure
+    encoder, the 14 dfnet.* tensors without it (model.StrEnc.use = False, in_dim 84)."""
+    from .synth import DFNET_DIMS, DFNET_DIMS_NOENC, state_dict_shapes
+    return list(state_dict_shapes(DFNET_DIMS if encoder else DFNET_DIMS_NOENC).keys())
 
 
 def _tensor_table(sd_np):
-    keys = state_dict_order()
+    keys = state_dict_order(encoder=any(k.startswith("enc.") for k in sd_np))
     arrs = [np.ascontiguousarray(np.asarray(sd_np[k], dtype=np.float32)) for k in keys]
     ptrs = (c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
     numel = (c_int64 * len(arrs))(*[a.size for a in arrs])
@@ -115,7 +116,8 @@ def pack_host(sd_np, lib=None, split=False):
 class Engine:
     """One engine per device.  All compute methods take raw device pointers and a stream handle."""
 
-    def __init__(self, act: str = "lrelu", beta: float = 100.0, device: int = 0, lib=None, precision: str = "fp32"):
+    def __init__(self, act: str = "lrelu", beta: float = 100.0, device: int = 0, lib=None, precision: str = "fp32",
+                 encoder: bool = True):
         self.lib = lib or load_library()
         if act not in ACT_CODES:
             raise PndfError(f"unknown activation {act!r}")
@@ -124,6 +126,8 @@ class Engine:
         cfg = PndfConfig()
         self.lib.pndf_default_config(ctypes.byref(cfg), ACT_CODES[act], float(beta))
         cfg.precision = PRECISION_CODES[precision]
+        if not encoder:
+            cfg.dims[0] = 84          # model.StrEnc.use = False: DFNet on the 21 x 4 normalised quaternions
         self.precision = precision
         self.handle = c_void_p()
         rc = self.lib.pndf_create(ctypes.byref(self.handle), ctypes.byref(cfg), int(device))

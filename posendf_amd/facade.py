@@ -93,8 +93,6 @@ class PoseNDF(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _engine_for(self, device):
-        if self.enc is None:
-            raise PndfError("StrEnc.use=False (in_dim=84) is not implemented by the HIP engine")
         if device.type != "cuda":
             raise PndfError("PoseNDF inference runs on the HIP engine only; no CPU path exists")
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -103,11 +101,12 @@ class PoseNDF(nn.Module):
         if entry is None:
             # the plain-f16 comparison kernel is relu-family only; fp32 and f16x3 implement all three activations
             prec = "fp32" if (self._act == "softplus" and self._precision == "f16") else self._precision
-            entry = [Engine(self._act, self._beta, idx, precision="f16x3" if prec == "auto" else prec), None]
+            entry = [Engine(self._act, self._beta, idx, precision="f16x3" if prec == "auto" else prec,
+                            encoder=self.enc is not None), None]
             self._engines[idx] = entry
         if entry[1] != fp:          # first use, load_state_dict, optimiser step, .to(): re-pack the weights
             sd = self.state_dict()
-            weights = {k: sd[k].detach().float().cpu().numpy() for k in state_dict_order()}
+            weights = {k: sd[k].detach().float().cpu().numpy() for k in state_dict_order(self.enc is not None)}
             try:
                 entry[0].load_weights(weights)
             except PndfError as e:
@@ -115,7 +114,7 @@ class PoseNDF(nn.Module):
                     raise
                 # both are HIP kernels: this is a choice of arithmetic, not a fallback off the engine
                 warnings.warn(f"posendf_amd: {e}; precision 'auto' selects the exact fp32 kernel for this network")
-                entry[0] = Engine(self._act, self._beta, idx, precision="fp32")
+                entry[0] = Engine(self._act, self._beta, idx, precision="fp32", encoder=self.enc is not None)
                 entry[0].load_weights(weights)
             entry[1] = fp
         return entry[0]

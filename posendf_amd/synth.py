@@ -20,12 +20,14 @@ FEAT = 6            # local_feature_size, reference net_modules.py:116
 BONE_DIM = 4
 HID = BONE_DIM + FEAT   # 10, reference net_modules.py:84
 DFNET_DIMS = (126, 256, 512, 1024, 512, 256, 64, 1)   # configs/amass.yaml:26,30
+DFNET_DIMS_NOENC = (84,) + DFNET_DIMS[1:]              # model.StrEnc.use = False: DFNet on the 21 x 4 quaternions
 
 
 def state_dict_shapes(dims=DFNET_DIMS):
-    """Ordered {key: shape} of the reference state dict."""
+    """Ordered {key: shape} of the reference state dict.  dims[0] == 84 is the
+    encoder-less variant (reference model/posendf.py:40-42,73-74): 14 DFNet tensors only."""
     shapes = {}
-    for i, p in enumerate(PARENT):
+    for i, p in (enumerate(PARENT) if dims[0] != NUM_JOINTS * BONE_DIM else ()):
         fin = BONE_DIM if p == -1 else BONE_DIM + FEAT
         shapes[f"enc.net.{i}.net.0.weight"] = (HID, fin)
         shapes[f"enc.net.{i}.net.0.bias"] = (HID,)

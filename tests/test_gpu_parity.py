@@ -216,8 +216,7 @@ def test_weight_reload_and_errors(torch_cuda):
     d_c = net(q, train=False)["dist_pred"]
     assert torch.allclose(d_c, d_b + 1.0, atol=1e-5)
     cfg = amass_config("lrelu", "cuda:0")
-    cfg["model"]["StrEnc"]["use"] = False                  # in_dim = 84 variant: not implemented -> loud failure
-    cfg["model"]["DFNet"]["in_dim"] = 84
+    cfg["model"]["DFNet"]["dims"] = [256, 512, 768, 512, 256, 64]      # another architecture: loud failure
     with pytest.raises(PndfError):
         PoseNDF(cfg)(q, train=False)
     with pytest.raises(RuntimeError):                      # no double backward on the engine path
