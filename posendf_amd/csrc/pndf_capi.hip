@@ -242,6 +242,7 @@ extern "C" int pndf_pack_host(const float* const* tensors, const int64_t* numel,
     if (check_tensors(tensors, numel, n_tensors) || !stream || !bias) return PNDF_ERR_BAD_SHAPE;
     // ---- bias block: b0..b5 | w6 | b6 | per joint: b1 padded to 16, b2 on rows 4..9 of 16
     memset(bias, 0, BIAS_FLOATS * sizeof(float));
+    for (int l = 0; l < 8; ++l) bias[SCALE_OFF + l] = 1.0f;
     const bool enc = table_has_encoder(n_tensors);     // without the encoder its tiles / biases stay zero (skipped on chip)
     const float* const* lin = tensors + (enc ? 4 * NJ : 0);
     for (int l = 0; l < NLIN - 1; ++l) memcpy(bias + BIAS_OFF[l], lin[2 * l + 1], sizeof(float) * DIMS[l + 1]);
@@ -280,22 +281,24 @@ extern "C" int pndf_pack_host(const float* const* tensors, const int64_t* numel,
 }
 
 // ---- split-precision stream
-// Exact power-of-two operand scaling (pndf_kernel_split.hip, "operand scaling"): weights travel as 2^8 W so that their
-// fp16 lo halves stay in the normal range, the trunk biases as 2^12 b (= weight scale x forward activation scale).
+// Exact power-of-two operand scaling (pndf_kernel_split.hip, "operand scaling"): the weights of layer l travel as
+// s_l W with s_l = the power of two that brings the layer's largest |weight| into [2^12, 2^13) -- the hi halves cannot
+// overflow and the lo halves of all weights down to 2^-14 of the largest stay in fp16's normal range -- and the trunk
+// biases as s_l 2^4 b (weight scale x forward activation scale).  1 / s_l goes to the bias block (SCALE_OFF + l).
 namespace {
-constexpr float SPLIT_W_SCALE = 256.0f, SPLIT_BIAS_SCALE = 4096.0f;
+constexpr float SPLIT_XF_SCALE = 16.0f;
 inline void split_f16(float w, _Float16& hi, _Float16& lo) {
     hi = (_Float16)w;                       // round to nearest even
     lo = (_Float16)(w - (float)hi);
 }
 // block(M, nt, kb): hi tile then lo tile, 8 halfs per lane each
-void emit_pair(const Mat& m, int nt, int kb, float* dst) {
+void emit_pair(const Mat& m, int nt, int kb, float* dst, float scale) {
     _Float16* hi = (_Float16*)dst;
     _Float16* lo = (_Float16*)(dst + TILE_FLOATS);
     for (int lane = 0; lane < 64; ++lane)
         for (int jj = 0; jj < 8; ++jj) {
             const float w = m.at(16 * nt + (lane & 15), 16 * (2 * kb + (jj >> 2)) + 4 * (lane >> 4) + (jj & 3));
-            split_f16(w * SPLIT_W_SCALE, hi[lane * 8 + jj], lo[lane * 8 + jj]);
+            split_f16(w * scale, hi[lane * 8 + jj], lo[lane * 8 + jj]);
         }
 }
 }  // namespace
@@ -305,13 +308,10 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
     // biases and encoder tiles are identical to the fp32 stream (the encoder stays on fp32 MFMA)
     int rc = pndf_pack_host(tensors, numel, n_tensors, stream, bias);
     if (rc != PNDF_OK) return rc;
-    for (int i = 0; i < W6_OFF; ++i) bias[i] *= SPLIT_BIAS_SCALE;      // biases of lin0..lin5 (lin6 runs in fp32)
     const bool enc = table_has_encoder(n_tensors);
     const float* const* lin = tensors + (enc ? 4 * NJ : 0);
-    // Operating range of the fp16 hi/lo split: the lo half of a (2^8-scaled) weight is ~2^-3 |w|, and fp16 turns
-    // subnormal below 2^-14, so a layer whose LARGEST weight is below 2^-14 would carry most of its lo halves with a
-    // few bits only; above 2^-8 * 65504 the hi half overflows.  Refuse instead of degrading silently: such a
-    // network runs on the exact fp32 kernel.
+    // per-layer weight scale; a layer without a finite non-zero weight cannot be scaled: refused (-> fp32 kernel)
+    float wscale[6];
     for (int l = 0; l < 6; ++l) {
         float mx = 0.f;
         bool nan = false;
@@ -321,7 +321,12 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
             nan |= (a != a);
             if (a > mx) mx = a;
         }
-        if (nan || !(mx >= 0x1p-14f && mx <= 200.f)) return PNDF_ERR_UNSUPPORTED;
+        if (nan || !(mx > 0x1p-100f && mx < 0x1p100f)) return PNDF_ERR_UNSUPPORTED;
+        int e;
+        (void)std::frexp(mx, &e);                       // mx = f * 2^e, f in [0.5, 1)
+        wscale[l] = std::ldexp(1.0f, 13 - e);           // s_l * mx in [2^12, 2^13)
+        bias[SCALE_OFF + l] = 1.0f / wscale[l];
+        for (int i = BIAS_OFF[l]; i < BIAS_OFF[l] + DIMS[l + 1]; ++i) bias[i] *= wscale[l] * SPLIT_XF_SCALE;
     }
     float* dst = stream + (size_t)ENC_TILES_PADDED * TILE_FLOATS;
     for (int ph = 0; ph < 6; ++ph) {
@@ -330,11 +335,11 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
         const Mat B{lin[2 * P.b_lin], DIMS[P.b_lin + 1], lin_in(P.b_lin, enc), P.transposed};
         auto partA = [&](int c) {
             for (int kb = 0; kb < P.KA / 2; ++kb)
-                for (int ci = 0; ci < P.CT; ++ci, dst += 2 * TILE_FLOATS) emit_pair(A, c * P.CT + ci, kb, dst);
+                for (int ci = 0; ci < P.CT; ++ci, dst += 2 * TILE_FLOATS) emit_pair(A, c * P.CT + ci, kb, dst, wscale[P.a_lin]);
         };
         auto partB = [&](int c) {
             for (int nb = 0; nb < P.NB; ++nb)
-                for (int b = 0; b < P.CT / 2; ++b, dst += 2 * TILE_FLOATS) emit_pair(B, nb, (c * P.CT) / 2 + b, dst);
+                for (int b = 0; b < P.CT / 2; ++b, dst += 2 * TILE_FLOATS) emit_pair(B, nb, (c * P.CT) / 2 + b, dst, wscale[P.b_lin]);
         };
         partA(0);
         for (int c = 0; c < P.NC; ++c) {
@@ -356,7 +361,7 @@ extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, con
                         ? pndf_pack_host_split(tensors, numel, n_tensors, stream.data(), bias.data())
                         : pndf_pack_host(tensors, numel, n_tensors, stream.data(), bias.data());
     if (prc == PNDF_ERR_UNSUPPORTED)
-        return fail(h, PNDF_ERR_UNSUPPORTED, "a trunk layer's largest |weight| is outside [2^-14, 200]: outside the operating "
+        return fail(h, PNDF_ERR_UNSUPPORTED, "a trunk layer has no finite non-zero weight: outside the operating "
                                              "range of the fp16 hi/lo split -- use precision fp32 for this network");
     if (prc != PNDF_OK)
         return fail(h, PNDF_ERR_BAD_SHAPE, "internal: packed stream length mismatch");

@@ -221,7 +221,8 @@ struct ActP {
 // inline-asm DMA, which hipcc cannot see, so its own `s_waitcnt vmcnt(0)` at the point of use would drain every DMA
 // piece in flight.  The consumer waits with `vmcnt(N)`, N = number of ring pieces certainly issued in between.
 __device__ __forceinline__ void stage_derivative_tile(const f32x4* src, char* stage_tile) {
-    const uint32_t dst = (uint32_t)(size_t)(PNDF_LDS char*)stage_tile;
+    // wave-uniform by construction (the wave's window); readfirstlane keeps it in an SGPR whatever hipcc infers
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(PNDF_LDS char*)stage_tile);
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory", "m0");
 }
 template <int YOUNGER>

@@ -71,18 +71,19 @@ struct SAct {
     float slope, beta;
     f32x4* sp;
     int spslot;
+    float inv_w;      // 1 / (weight scale of the layer whose accumulators this activation consumes), a power of two
     char* stage;      // softplus backward: this wave's LDS staging window for derivative tiles (1 KiB per tile)
     int lane;
 };
 
 // Power-of-two operand scaling (exact).  An fp16 lo half is ~2^-11 of its value and turns SUBNORMAL below 2^-14: with
 // weights of a few 1e-2 and gradients of 1e-3..1e-1 most lo halves would keep only a few bits.  So the stream carries
-// 2^8 W, forward activations travel as 2^4 x and backward gradients as 2^10 g; the fp32 accumulators then hold
-// 2^12 (forward, the packed biases are scaled to match) or 2^18 (backward) times the true value, and ONE multiply by
-// 2^-8 in the epilogue turns either into the next layer's scaled operand (LeakyReLU commutes with positive scales).
-constexpr float W_SCALE = 256.0f, XF_SCALE = 16.0f, XB_SCALE = 1024.0f;
-constexpr float ACC_TO_OPERAND = 1.0f / W_SCALE;               // accumulator -> scaled operand of the next layer
-constexpr float ACC_TO_TRUE_F = 1.0f / (W_SCALE * XF_SCALE);   // forward accumulator -> true pre-activation
+// s_l W (s_l: the per-layer power of two that brings the largest |weight| into [2^12, 2^13), chosen by the packer),
+// forward activations travel as 2^4 x and backward gradients as 2^10 g; the fp32 accumulators then hold s_l 2^4
+// (forward, the packed biases are scaled to match) or s_l 2^10 (backward) times the true value, and ONE multiply by
+// 1 / s_l (SAct::inv_w, from the bias block) in the epilogue turns either into the next layer's scaled operand
+// (LeakyReLU commutes with positive scales).
+constexpr float XF_SCALE = 16.0f, XB_SCALE = 1024.0f;
 
 // two activated fp32 C/D tiles -> the B operand of the k-block they form (8 halfs = 4 dwords, hi and lo)
 template <bool SINGLE = false>
@@ -219,13 +220,13 @@ struct SplitPhase {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float dr;
-                        y[ci][r] = act_softplus(ch[0][ci][r] * ACC_TO_TRUE_F, act.beta, dr) * XF_SCALE;
+                        y[ci][r] = act_softplus(ch[0][ci][r] * (act.inv_w * (1.0f / XF_SCALE)), act.beta, dr) * XF_SCALE;
                         dv[r] = dr;
                     }
                     *slot = dv;
                 } else {
                     if (ci == 0) wait_staged_derivatives<STAGE_YOUNGER>();
-                    y[ci] = (ch[0][ci] * ACC_TO_OPERAND) * *(const f32x4*)(act.stage + ci * 1024 + act.lane * 16);
+                    y[ci] = (ch[0][ci] * act.inv_w) * *(const f32x4*)(act.stage + ci * 1024 + act.lane * 16);
                 }
             }
         } else if (!BWD) {
@@ -234,7 +235,7 @@ struct SplitPhase {
             for (int ci = CT - 1; ci >= 0; --ci) {
 #pragma unroll
                 for (int r = 3; r >= 0; --r) {
-                    const float z = ((PARTIALS == 3) ? (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r] : ch[0][ci][r]) * ACC_TO_OPERAND;
+                    const float z = ((PARTIALS == 3) ? (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r] : ch[0][ci][r]) * act.inv_w;
                     y[ci][r] = lrelu_bit(z, slope, bits);
                 }
             }
@@ -248,7 +249,7 @@ struct SplitPhase {
                 for (int r = 0; r < 4; ++r) {
                     const float z = (PARTIALS == 3) ? (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r] : ch[0][ci][r];
                     // derivative factor with the accumulator -> operand scale folded in (both exact powers of two apart)
-                    y[ci][r] = z * fmaf((float)((bits >> (ci * 4 + r)) & 1u), (1.0f - slope) * ACC_TO_OPERAND, slope * ACC_TO_OPERAND);
+                    y[ci][r] = z * fmaf((float)((bits >> (ci * 4 + r)) & 1u), (1.0f - slope) * act.inv_w, slope * act.inv_w);
                 }
             }
         }
@@ -505,7 +506,7 @@ __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float dr;
-                x[t][r] = act_softplus(x[t][r] * ACC_TO_TRUE_F, act.beta, dr) * XF_SCALE;
+                x[t][r] = act_softplus(x[t][r] * (act.inv_w * (1.0f / XF_SCALE)), act.beta, dr) * XF_SCALE;
                 dv[r] = dr;
             }
             act.sp[(size_t)(act.spslot + t) * WG_THREADS] = dv;
@@ -520,7 +521,7 @@ __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 
 #pragma unroll
             for (int k = top; k >= 32 * w; --k) {
                 const int t = k / 4, r = k % 4;
-                x[t][r] = lrelu_bit(x[t][r] * ACC_TO_OPERAND, act.slope, bits);
+                x[t][r] = lrelu_bit(x[t][r] * act.inv_w, act.slope, bits);
             }
             m[w] = bits;
             asm volatile("" : "+v"(m[w]));      // pin the packing here (see pndf_kernel.hip act_tiles)
@@ -535,11 +536,11 @@ __device__ __forceinline__ void dact_split_tiles(f32x4 (&gx)[NT], Blk (&out)[NT 
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if constexpr (SP) {
-            gx[t] = (gx[t] * ACC_TO_OPERAND) * act.sp[(size_t)(act.spslot + t) * WG_THREADS];
+            gx[t] = (gx[t] * act.inv_w) * act.sp[(size_t)(act.spslot + t) * WG_THREADS];
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                gx[t][r] = gx[t][r] * fmaf((float)((m[(t * 4 + r) / 32] >> ((t * 4 + r) % 32)) & 1u), (1.0f - act.slope) * ACC_TO_OPERAND, act.slope * ACC_TO_OPERAND);
+                gx[t][r] = gx[t][r] * fmaf((float)((m[(t * 4 + r) / 32] >> ((t * 4 + r) % 32)) & 1u), (1.0f - act.slope) * act.inv_w, act.slope * act.inv_w);
         }
         if (t & 1) pack_blk<SINGLE>(gx[t - 1], gx[t], out[t / 2]);
     }
@@ -562,7 +563,11 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
     ap.slope = args.slope;
     ap.beta = args.beta;
     ap.sp = SP ? (f32x4*)(args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS) + tid : nullptr;
-    auto layer = [&](int spslot) { return SAct{args.slope, args.beta, ap.sp, spslot, (char*)(smem + LDS_F) + wave * (16 * FSTRIDE * 4), lane}; };
+    // 1 / weight scale of lin0..lin5 (powers of two chosen by the packer), uniform
+    float inv_w[6];
+#pragma unroll
+    for (int l = 0; l < 6; ++l) inv_w[l] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, args.bias[SCALE_OFF + l])));
+    auto layer = [&](int spslot, float inv) { return SAct{args.slope, args.beta, ap.sp, spslot, inv, (char*)(smem + LDS_F) + wave * (16 * FSTRIDE * 4), lane}; };
     const long long pose0 = (long long)blockIdx.x * WG_POSES;
     float* const lds_bias = (float*)(smem + LDS_BIAS);
     uint8_t* const lds_mask = (uint8_t*)(smem + LDS_MASK) + tid;
@@ -626,23 +631,23 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
                 tick<TIMING>(rc, 0);
                 f32x4 x2[32];
                 load_bias<32>(x2, lds_bias + BIAS_OFF[1], g);
-                PhaseSel<TERMS, SP, 4, 2, 8, 32, false>::type::run(b0, x2, ring, lds_bias + BIAS_OFF[0], lds_mask + MASK_BASE[0] * WG_THREADS, layer(SP_SLOT_CHUNK[0]), g);
+                PhaseSel<TERMS, SP, 4, 2, 8, 32, false>::type::run(b0, x2, ring, lds_bias + BIAS_OFF[0], lds_mask + MASK_BASE[0] * WG_THREADS, layer(SP_SLOT_CHUNK[0], inv_w[0]), g);
                 tick<TIMING>(rc, 1);
-                act_split_tiles<32, SG, SP>(x2, b2, m2, layer(SP_SLOT_X2));
+                act_split_tiles<32, SG, SP>(x2, b2, m2, layer(SP_SLOT_X2, inv_w[1]));
                 tick<TIMING>(rc, 2);
             }
             f32x4 x4[32];
             load_bias<32>(x4, lds_bias + BIAS_OFF[3], g);
-            PhaseSel<TERMS, SP, 16, 2, 32, 32, false>::type::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1]), g);
+            PhaseSel<TERMS, SP, 16, 2, 32, 32, false>::type::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], inv_w[2]), g);
             tick<TIMING>(rc, 3);
-            act_split_tiles<32, SG, SP>(x4, b4, m4, layer(SP_SLOT_X4));
+            act_split_tiles<32, SG, SP>(x4, b4, m4, layer(SP_SLOT_X4, inv_w[3]));
             tick<TIMING>(rc, 4);
         }
         load_bias<4>(x6, lds_bias + BIAS_OFF[5], g);
-        PhaseSel<TERMS, SP, 16, 4, 4, 4, false>::type::run(b4, x6, ring, lds_bias + BIAS_OFF[4], lds_mask + MASK_BASE[2] * WG_THREADS, layer(SP_SLOT_CHUNK[2]), g);
+        PhaseSel<TERMS, SP, 16, 4, 4, 4, false>::type::run(b4, x6, ring, lds_bias + BIAS_OFF[4], lds_mask + MASK_BASE[2] * WG_THREADS, layer(SP_SLOT_CHUNK[2], inv_w[4]), g);
         tick<TIMING>(rc, 5);
         Blk b6[2];
-        act_split_tiles<4, SG, SP>(x6, b6, m6, layer(SP_SLOT_X6));      // b6 unused forward; x6 (fp32) feeds lin6
+        act_split_tiles<4, SG, SP>(x6, b6, m6, layer(SP_SLOT_X6, inv_w[5]));      // b6 unused forward; x6 (fp32) feeds lin6
 
         // ---------------- lin6 (64 -> 1) + output ReLU, fp32 on the VALU
         f32x4 w6[4];
@@ -684,30 +689,30 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
                     {
                         f32x4 g6[4];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) g6[t] = w6[t] * (XB_SCALE * W_SCALE);     // dact multiplies by 1 / W_SCALE
+                        for (int t = 0; t < 4; ++t) g6[t] = w6[t] * XB_SCALE;                 // the seed: no accumulator scale to undo
                         Blk gb6[2];
-                        dact_split_tiles<4, SG, SP>(g6, gb6, m6, layer(SP_SLOT_X6));
+                        dact_split_tiles<4, SG, SP>(g6, gb6, m6, layer(SP_SLOT_X6, 1.0f));
                         tick<TIMING>(rc, 6);
                         f32x4 g4[32];
 #pragma unroll
                         for (int t = 0; t < 32; ++t) g4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        PhaseSel<TERMS, SP, 2, 4, 4, 32, true>::type::run(gb6, g4, ring, nullptr, lds_mask + MASK_BASE[2] * WG_THREADS, layer(SP_SLOT_CHUNK[2]), g);
-                        dact_split_tiles<32, SG, SP>(g4, gb4, m4, layer(SP_SLOT_X4));
+                        PhaseSel<TERMS, SP, 2, 4, 4, 32, true>::type::run(gb6, g4, ring, nullptr, lds_mask + MASK_BASE[2] * WG_THREADS, layer(SP_SLOT_CHUNK[2], inv_w[5]), g);
+                        dact_split_tiles<32, SG, SP>(g4, gb4, m4, layer(SP_SLOT_X4, inv_w[4]));
                         tick<TIMING>(rc, 7);
                     }
                     f32x4 g2[32];
 #pragma unroll
                     for (int t = 0; t < 32; ++t) g2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    PhaseSel<TERMS, SP, 16, 2, 32, 32, true>::type::run(gb4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1]), g);
-                    dact_split_tiles<32, SG, SP>(g2, gb2, m2, layer(SP_SLOT_X2));
+                    PhaseSel<TERMS, SP, 16, 2, 32, 32, true>::type::run(gb4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], inv_w[3]), g);
+                    dact_split_tiles<32, SG, SP>(g2, gb2, m2, layer(SP_SLOT_X2, inv_w[2]));
                     tick<TIMING>(rc, 8);
                 }
 #pragma unroll
                 for (int t = 0; t < 8; ++t) g0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                PhaseSel<TERMS, SP, 16, 2, 8, 8, true>::type::run(gb2, g0, ring, nullptr, lds_mask + MASK_BASE[0] * WG_THREADS, layer(SP_SLOT_CHUNK[0]), g);
+                PhaseSel<TERMS, SP, 16, 2, 8, 8, true>::type::run(gb2, g0, ring, nullptr, lds_mask + MASK_BASE[0] * WG_THREADS, layer(SP_SLOT_CHUNK[0], inv_w[1]), g);
             }
 #pragma unroll
-            for (int t = 0; t < 8; ++t) *(f32x4*)(my_f + 16 * t + 4 * g) = g0[t] * (1.0f / (W_SCALE * XB_SCALE));
+            for (int t = 0; t < 8; ++t) *(f32x4*)(my_f + 16 * t + 4 * g) = g0[t] * (inv_w[0] * (1.0f / XB_SCALE));
         }
         __syncthreads();
 

@@ -283,7 +283,7 @@ def _mm3(w, x, c):
     return c
 
 
-def run_phase_split(ph, xin, acc, st, bias_a, masks, slope, bwd):
+def run_phase_split(ph, xin, acc, st, bias_a, masks, slope, bwd, inv_a):
     """xin: list of (hi, lo) blocks; acc: list of fp32 tiles.  Stream order A(0) | A(c+1) B(c) ... (pndf_layout.h)."""
     KA, CT, NC, NB = PHASES[ph]
 
@@ -295,7 +295,7 @@ def run_phase_split(ph, xin, acc, st, bias_a, masks, slope, bwd):
         for kb in range(KA // 2):
             for ci in range(CT):
                 ch[ci] = _mm3(st.pair(), xin[kb], ch[ci])
-        ch = [t * np.float32(1.0 / W_SCALE) for t in ch]       # accumulator -> scaled operand (kernel: ACC_TO_OPERAND)
+        ch = [t * np.float32(inv_a) for t in ch]               # accumulator -> scaled operand (kernel: SAct::inv_w)
         if not bwd:
             m = [t > 0 for t in ch]
             masks[(ph, c)] = m
@@ -313,16 +313,19 @@ def run_phase_split(ph, xin, acc, st, bias_a, masks, slope, bwd):
         chb = nxt
 
 
-# exact power-of-two operand scaling of the split kernel (pndf_kernel_split.hip): 2^8 W in the stream, forward
-# activations as 2^4 x, backward gradients as 2^10 g, trunk biases as 2^12 b
-W_SCALE, XF_SCALE, XB_SCALE = 256.0, 16.0, 1024.0
+# exact power-of-two operand scaling of the split kernel (pndf_kernel_split.hip): s_l W in the stream (1 / s_l in the
+# bias block at SCALE_OFF + l), forward activations as 2^4 x, backward gradients as 2^10 g, trunk biases as s_l 2^4 b
+XF_SCALE, XB_SCALE = 16.0, 1024.0
+SCALE_OFF = ENCB_OFF + 21 * 32
 
 
-def _descale(tiles):
-    return [t * np.float32(1.0 / W_SCALE) for t in tiles]
+def _descale(tiles, inv):
+    return [t * np.float32(inv) for t in tiles]
 
 
 def trunk_wave_split(feat16, stream, bias, slope):
+    inv = [float(bias[SCALE_OFF + l]) for l in range(6)]
+    assert all(v > 0 and np.log2(v) == np.round(np.log2(v)) for v in inv), inv       # powers of two
     f = np.zeros((16, 128), np.float32)
     f[:, :126] = feat16
     x0 = []
@@ -334,16 +337,16 @@ def trunk_wave_split(feat16, stream, bias, slope):
     st, masks, stages = PairStream(stream, ENC_PAD), {}, {}
     true = np.float32(1.0 / XF_SCALE)
     x2 = load_bias(bias, BIAS_OFF[1], 32)
-    run_phase_split(0, pack_blocks(x0), x2, st, bias[BIAS_OFF[0]:], masks, slope, False)
-    x2, m2 = act_tiles(_descale(x2), slope)
+    run_phase_split(0, pack_blocks(x0), x2, st, bias[BIAS_OFF[0]:], masks, slope, False, inv[0])
+    x2, m2 = act_tiles(_descale(x2, inv[1]), slope)
     stages["x2"] = decode(x2) * true
     x4 = load_bias(bias, BIAS_OFF[3], 32)
-    run_phase_split(1, pack_blocks(x2), x4, st, bias[BIAS_OFF[2]:], masks, slope, False)
-    x4, m4 = act_tiles(_descale(x4), slope)
+    run_phase_split(1, pack_blocks(x2), x4, st, bias[BIAS_OFF[2]:], masks, slope, False, inv[2])
+    x4, m4 = act_tiles(_descale(x4, inv[3]), slope)
     stages["x4"] = decode(x4) * true
     x6 = load_bias(bias, BIAS_OFF[5], 4)
-    run_phase_split(2, pack_blocks(x4), x6, st, bias[BIAS_OFF[4]:], masks, slope, False)
-    x6, m6 = act_tiles(_descale(x6), slope)
+    run_phase_split(2, pack_blocks(x4), x6, st, bias[BIAS_OFF[4]:], masks, slope, False, inv[4])
+    x6, m6 = act_tiles(_descale(x6, inv[5]), slope)
     stages["x6"] = decode(x6) * true
     w6 = load_bias(bias, W6_OFF, 4)
     part = np.zeros(64, np.float32)
@@ -357,15 +360,15 @@ def trunk_wave_split(feat16, stream, bias, slope):
     d = np.maximum(z7, 0)
     gz7 = (z7 > 0).astype(np.float32)
     # unit seed (scaled), the output derivative multiplies the result
-    g6 = dact_tiles(_descale([w6[t] * np.float32(XB_SCALE * W_SCALE) for t in range(4)]), m6, slope)
+    g6 = dact_tiles([w6[t] * np.float32(XB_SCALE) for t in range(4)], m6, slope)
     g4 = [np.zeros((64, 4), np.float32) for _ in range(32)]
-    run_phase_split(3, pack_blocks(g6), g4, st, None, masks, slope, True)
-    g4 = dact_tiles(_descale(g4), m4, slope)
+    run_phase_split(3, pack_blocks(g6), g4, st, None, masks, slope, True, inv[5])
+    g4 = dact_tiles(_descale(g4, inv[4]), m4, slope)
     g2 = [np.zeros((64, 4), np.float32) for _ in range(32)]
-    run_phase_split(4, pack_blocks(g4), g2, st, None, masks, slope, True)
-    g2 = dact_tiles(_descale(g2), m2, slope)
+    run_phase_split(4, pack_blocks(g4), g2, st, None, masks, slope, True, inv[3])
+    g2 = dact_tiles(_descale(g2, inv[2]), m2, slope)
     g0 = [np.zeros((64, 4), np.float32) for _ in range(8)]
-    run_phase_split(5, pack_blocks(g2), g0, st, None, masks, slope, True)
+    run_phase_split(5, pack_blocks(g2), g0, st, None, masks, slope, True, inv[1])
     assert st.pos == st.t.shape[0] - ENC_PAD, (st.pos, st.t.shape)
-    g0 = [t * np.float32(1.0 / (W_SCALE * XB_SCALE)) * gz7[:, None] for t in g0]
+    g0 = [t * np.float32(inv[0] / XB_SCALE) * gz7[:, None] for t in g0]
     return d[:16], decode(g0), stages

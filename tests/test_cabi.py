@@ -81,21 +81,29 @@ def test_pack_host_rejects_bad_tables(lib):
         engine.pack_host(bad, lib)
 
 
-def test_split_packer_refuses_weights_outside_the_fp16_split_range(lib):
-    """The fp16 hi/lo split has an operating range (include/posendf_amd.h, PNDF_PREC_F16X3): a layer whose largest
-    |weight| is below 2^-14 (lo halves subnormal even after the 2^8 scaling) or above 200 (hi half overflows) is refused, not degraded."""
+def test_split_packer_scales_each_layer_and_refuses_the_unscalable(lib):
+    """The fp16 hi/lo split carries s_l W with a per-layer power of two s_l (largest |weight| -> [2^12, 2^13)), so any
+    weight magnitude packs; a layer without a finite non-zero weight cannot be scaled and is refused, not degraded."""
     from posendf_amd import engine, synth
+    from lane_model import SCALE_OFF
     sd = synth.make_weights(1)
-    engine.pack_host(sd, lib, split=True)                       # ordinary weights pack
-    tiny = dict(sd)
-    tiny["dfnet.lin2.weight"] = sd["dfnet.lin2.weight"] * 1e-4
-    engine.pack_host(tiny, lib)                                  # fine for the exact fp32 stream
+    _, bias = engine.pack_host(sd, lib, split=True)
+    for scale_by in (1e-6, 1e7):                                 # far outside any fixed scaling window
+        odd = dict(sd)
+        odd["dfnet.lin2.weight"] = sd["dfnet.lin2.weight"] * np.float32(scale_by)
+        stream, b2 = engine.pack_host(odd, lib, split=True)
+        trunk = stream.reshape(-1, 256)[48:48 + 10624].view(np.float16).astype(np.float32)     # between the encoder sections
+        assert np.isfinite(trunk).all() and np.abs(trunk).max() <= 2.0 ** 13            # hi = rne(scaled weight) may round up to 2^13
+        inv = b2[SCALE_OFF:SCALE_OFF + 6]
+        assert (np.log2(inv) == np.round(np.log2(inv))).all()
+        mx = np.abs(odd["dfnet.lin2.weight"]).max() / inv[2]
+        assert 2.0 ** 12 <= mx < 2.0 ** 13
+        assert (inv[[0, 1, 3, 4, 5]] == bias[SCALE_OFF:SCALE_OFF + 6][[0, 1, 3, 4, 5]]).all()
+    zero = dict(sd)
+    zero["dfnet.lin4.weight"] = np.zeros_like(sd["dfnet.lin4.weight"])
+    engine.pack_host(zero, lib)                                  # fine for the exact fp32 stream
     with pytest.raises(engine.PndfError):
-        engine.pack_host(tiny, lib, split=True)
-    huge = dict(sd)
-    huge["dfnet.lin4.weight"] = sd["dfnet.lin4.weight"] * 1e7
-    with pytest.raises(engine.PndfError):
-        engine.pack_host(huge, lib, split=True)
+        engine.pack_host(zero, lib, split=True)
     nan = dict(sd)
     w = sd["dfnet.lin0.weight"].copy()
     w[3, 5] = np.nan

@@ -362,14 +362,21 @@ def test_precision_auto_selects_by_weight_range(torch_cuda):
     d = net(q, train=False)["dist_pred"]
     assert net._engine_for(q.device).precision == "f16x3"
     tiny = {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
-    tiny["dfnet.lin3.weight"] *= 1e-5                              # lo halves would be subnormal
+    tiny["dfnet.lin3.weight"] *= 1e-5                              # any magnitude packs: the scale is per layer
+    net1 = PoseNDF(amass_config("lrelu", "cuda:0"))
+    net1.load_state_dict(tiny)
+    d1 = net1(q, train=False)["dist_pred"]
+    assert net1._engine_for(q.device).precision == "f16x3"
+    from oracle import posendf_np as onp
+    d_o1, _ = onp.forward_grad(q.cpu().numpy(), {k: v.numpy() for k, v in tiny.items()}, "lrelu", dtype=np.float64)
+    assert d_err(d1.detach().cpu().numpy().ravel(), d_o1.ravel()) < TOL
+    tiny["dfnet.lin3.weight"] *= 0.0                               # a layer that cannot be scaled at all
     net2 = PoseNDF(amass_config("lrelu", "cuda:0"))
     net2.load_state_dict(tiny)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         d2 = net2(q, train=False)["dist_pred"]
     assert net2._engine_for(q.device).precision == "fp32" and any("operating range" in str(x.message) for x in w)
-    from oracle import posendf_np as onp
     d_o, _ = onp.forward_grad(q.cpu().numpy(), {k: v.numpy() for k, v in tiny.items()}, "lrelu")
     assert d_err(d2.detach().cpu().numpy().ravel(), d_o.ravel()) < TOL
     assert torch.isfinite(d).all()

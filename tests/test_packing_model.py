@@ -37,7 +37,7 @@ def test_packed_blocks_layout():
     from posendf_amd import engine, synth
     sd = synth.make_weights(3)
     stream, bias = engine.pack_host(sd)
-    assert stream.size == 10720 * 256 and bias.size == 2692 + 21 * 32
+    assert stream.size == 10720 * 256 and bias.size == 2692 + 21 * 32 + 8
     # bias block
     assert np.array_equal(bias[0:256], sd["dfnet.lin0.bias"])
     assert np.array_equal(bias[2560:2624], sd["dfnet.lin5.bias"])
