@@ -54,9 +54,9 @@ typedef struct {
 /* PNDF_PREC_FP32 : exact fp32 MFMA (v_mfma_f32_16x16x4_f32), bit-comparable to an fmaf chain.
  * PNDF_PREC_F16X3: every fp32 operand split into fp16 hi + lo, three v_mfma_f32_16x16x32_f16 per product block,
  *                  fp32 accumulate: ~2^-22 relative product error (fp32-class), ~4x the throughput.
- *                  Operands must stay inside the fp16 range (|x| < 65504); pndf_load_weights refuses
- *                  (PNDF_ERR_UNSUPPORTED) a trunk layer whose largest |weight| is outside [2^-14, 200], where the lo
- *                  halves would be subnormal / the hi halves overflow.
+ *                  Weights are scaled per layer by a power of two (any magnitude packs); pndf_load_weights refuses
+ *                  (PNDF_ERR_UNSUPPORTED) only a trunk layer without a finite non-zero weight.  Activations must
+ *                  stay below 65504 / 16, gradients below 65504 / 1024 (both travel scaled by exact powers of two).
  * PNDF_PREC_F16  : plain fp16 operands (round to nearest), ONE MFMA per product block, fp32 accumulate.  A measured
  *                  comparison point (BASELINE.json configs[2] "fp32 vs bf16"): ~1e-3 relative, NOT within the 1e-4
  *                  parity bar of the two modes above; never selected implicitly; relu / lrelu only. */
