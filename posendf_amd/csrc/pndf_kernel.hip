@@ -292,7 +292,17 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
         for (int i = 0; i < TIMING_GROUPS; ++i) rc.grp[i] = 0;
         rc.last = __builtin_amdgcn_s_memtime();
     }
+    const int g_launch = g;
     for (int step = 0; step < nsteps; ++step) {
+        // softplus kernels: LICM hoists ~220 LDS addresses of the form constant + 16 g out of this loop and, under their
+        // higher register pressure, spills them -- and every spill reload is a VMEM load whose vmcnt(0) drains the
+        // ring's DMA.  An opaque copy of g per step keeps those one-instruction address computations inside the step.
+        // The same goes for the ~200 64-bit addresses of the derivative scratch slots (ap.sp + slot * 4 KiB).
+        int g = g_launch;
+        if constexpr (SP) {
+            asm volatile("" : "+v"(g));
+            asm volatile("" : "+v"(ap.sp));
+        }
         uint32_t eb[6];
         uint32_t m2[4], m4[4], m6[1];
         f32x4 x6[4];
