@@ -28,7 +28,7 @@ class PndfError(RuntimeError):
 
 
 def load_library(path: str | None = None) -> ctypes.CDLL:
-    path = path or _LIB_PATH
+    path = path or os.environ.get("PNDF_LIBRARY") or _LIB_PATH      # PNDF_LIBRARY: A/B runs of two builds on one box
     # PyTorch is the plumbing for device memory and streams, so the library must share PyTorch's HIP runtime:
     # import torch FIRST so that its bundled libamdhip64 is the one already mapped when the loader resolves
     # this library's dependency (the other order puts two HIP runtimes in the process and pndf_create then
