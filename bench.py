@@ -29,9 +29,22 @@ KERNELS = {"fp32": ("pndf_fused_relu_kernel", PEAK_FP32_MFMA_TFLOPS, "f32"),
                    "f16 (operands ROUNDED to fp16, fp32 accumulate; NOT within the 1e-4 parity bar)")}
 
 
-def cpu_baseline(act, sd, proj_steps, budget_s=20.0):
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(act, sd, proj_steps, budget_s=20.0, runs=3):
     """The reference's CPU PyTorch path (restated in oracle/posendf_torch.py) on this box's host cores, on a
-    bounded sample of the same workload: the full 100-step projection of as many poses as fit in ~budget_s."""
+    bounded sample of the same workload: the full 100-step projection of as many poses as fit in ~budget_s / runs,
+    `runs` times (median reported), plus BASELINE.json configs[0] (B = 256, forward only, median of 10)."""
+    import statistics
     import torch
     from oracle.posendf_torch import RefNet, project
     from posendf_amd import synth
@@ -44,17 +57,78 @@ def cpu_baseline(act, sd, proj_steps, budget_s=20.0):
     net = RefNet(act)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     q = torch.from_numpy(synth.make_poses(4096, seed=1234))
-    project(net, q[:256], 1)                                    # warm-up
+    for _ in range(3):
+        project(net, q[:256], 1)                                # warm-ups
     t0 = time.perf_counter()
     project(net, q[:512], 2)                                    # calibration: pose-steps per second
     rate = 512 * 2 / (time.perf_counter() - t0)
-    sample_b = int(min(4096, max(64, rate * budget_s / proj_steps)))
+    sample_b = int(min(4096, max(64, rate * budget_s / runs / proj_steps)))
+    times = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        project(net, q[:sample_b], proj_steps)
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    # configs[0]: batch = 256, PoseNDF.forward() distance only, PyTorch CPU
+    q0 = q[:256]
+    with torch.no_grad():
+        for _ in range(3):
+            net(q0)
+        f_t = []
+        for _ in range(10):
+            t0 = time.perf_counter()
+            net(q0)
+            f_t.append(time.perf_counter() - t0)
+    f_med = statistics.median(f_t)
+    return {"value": sample_b / dt, "unit": "projected poses/s", "cores": threads, "kind": "port", "cpu": _cpu_model(),
+            "runs_s": [round(t, 3) for t in times],
+            "sample": f"B={sample_b} poses x {proj_steps} steps, median of {runs} runs = {dt:.1f} s; PyTorch-CPU restatement "
+                      f"of the reference (oracle/posendf_torch.py), {threads} threads on {cores} visible cores of a "
+                      f"{_cpu_model()}",
+            "config0_forward_only": {"workload": "BASELINE.json configs[0]: batch=256, forward() distance only, PyTorch CPU",
+                                     "ms": f_med * 1e3, "poses_per_s": 256 / f_med, "runs": 10}}
+
+
+def gpu_torch_baseline(act, sd, B, proj_steps, dev, timed_steps=5):
+    """The comparator of north_star's '>= 10x the reference single-GPU PyTorch poses/sec': the same PyTorch restatement
+    of the reference run through stock PyTorch-ROCm on this GPU (fp32, same batch), timed over `timed_steps` projection
+    steps and extrapolated linearly to `proj_steps` (every step does identical work; the chained autograd graph of the
+    reference is detached between steps, which only saves memory)."""
+    import torch
+    from oracle.posendf_torch import RefNet, project
+    from posendf_amd import synth
+    net = RefNet(act).to(dev)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    q = torch.from_numpy(synth.make_poses(B, seed=1234)).to(dev)
+    project(net, q, 2)
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    project(net, q[:sample_b], proj_steps)
-    dt = time.perf_counter() - t0
-    return {"value": sample_b / dt, "unit": "projected poses/s", "cores": threads, "kind": "port",
-            "sample": f"B={sample_b} poses x {proj_steps} steps in {dt:.1f} s; PyTorch-CPU restatement of the "
-                      f"reference (oracle/posendf_torch.py), {threads} threads on {cores} visible cores"}
+    project(net, q, timed_steps)
+    torch.cuda.synchronize(dev)
+    per_step = (time.perf_counter() - t0) / timed_steps
+    del net, q
+    torch.cuda.empty_cache()
+    return {"what": "PyTorch-ROCm fp32 restatement of the reference (oracle/posendf_torch.py) on the same MI355X",
+            "batch": B, "timed_steps": timed_steps, "ms_per_step": per_step * 1e3,
+            "value": B / (per_step * proj_steps), "unit": f"projected poses/s (extrapolated to {proj_steps} steps)",
+            "achieved_tflops": B * FLOP_PER_POSE_STEP / per_step / 1e12, "torch": torch.__version__}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible; refusing to report a smaller job as N={args.gpus}")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -73,7 +147,10 @@ def main():
                     help="skip the short exact-fp32 and plain-f16 runs reported beside f16x3")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gpu-torch-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                       # does not return
 
     import numpy as np
     import torch
@@ -82,7 +159,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs; the engine has no CPU path")
@@ -99,8 +176,8 @@ def main():
     sd = synth.make_weights(0, 2.0, 0.1)                        # BASELINE.md section 3 "live regime"
     precision = "fp32" if (args.act == "softplus" and args.precision == "f16") else args.precision
 
-    def build(prec):
-        cfg = amass_config(args.act, f"cuda:{local}")
+    def build(prec, act=None):
+        cfg = amass_config(act or args.act, f"cuda:{local}")
         cfg["engine"] = {"precision": prec}
         m = PoseNDF(cfg)
         m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -112,11 +189,13 @@ def main():
     # shard `rank` of the global batch: reference input distribution (sample_poses.py:96-97), seeded
     q0 = torch.from_numpy(synth.make_poses(B, seed=1234, offset=rank)).to(dev)
     from posendf_amd.sharding import all_gather_blocks
+    # receive buffer of the final gather, allocated once: equal blocks go straight into it (all_gather_into_tensor)
+    gathered = torch.empty((B * world, 21, 4), device=dev, dtype=torch.float32) if use_dist else None
 
     def one_pass():
         qp, d = net.project(q0, steps=args.proj_steps)
         if use_dist:
-            all_gather_blocks(qp, B * world)                    # the only collective: final gather over xGMI
+            all_gather_blocks(qp, B * world, out=gathered)      # the only collective: final gather over xGMI
         return qp, d
 
     for _ in range(args.warmup):
@@ -131,7 +210,7 @@ def main():
         qp, d = net.project(q0, steps=args.proj_steps)          # the dominant kernel, bracketed by HIP events
         ev[k][1].record()
         if use_dist:
-            all_gather_blocks(qp, B * world)
+            all_gather_blocks(qp, B * world, out=gathered)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -147,8 +226,8 @@ def main():
 
     # the exact-fp32 and the plain-fp16 kernels beside the split-precision one (same inputs, short runs, outside the
     # timed region): the three points of BASELINE.json configs[2] "fp32 vs bf16"
-    def side_run(prec):
-        ref = build(prec)
+    def side_run(prec, act=None):
+        ref = build(prec, act)
         ref.project(q0, steps=args.proj_steps)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
@@ -180,20 +259,27 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / 5
 
+    side = world == 1 and not args.no_fp32_ref      # the side runs belong to the N = 1 line; scaling runs stay short
     fwd_grad = None
-    if not args.no_fp32_ref:
+    if side:
         ms1 = fwd_grad_ms(net)
         fwd_grad = {"workload": f"BASELINE.json configs[1]: one forward + d d/d q launch, batch={B}", "precision": precision,
                     "ms": ms1, "pose_steps_per_s": B / (ms1 * 1e-3),
                     "achieved_tflops": B * FLOP_PER_POSE_STEP / (ms1 * 1e-3) / 1e12}
 
-    fp32_ref = f16_ref = None
-    if precision == "f16x3" and not args.no_fp32_ref:
+    fp32_ref = f16_ref = sp_ref = None
+    if precision == "f16x3" and side and args.act != "softplus":
+        # the activation of the reference's published checkpoints (sample_poses.py:115, motion_denoise.py:162-163)
+        sp_ref = side_run("f16x3", "softplus")
+        sp_ref["kernel"] = "pndf_fused_split_softplus_kernel"
+        sp_ref["frac_of_fp16_mfma_peak"] = sp_ref["achieved_tflops"] / PEAK_F16_MFMA_TFLOPS
+        sp_ref.pop("median_rel_diff_of_projected_poses_vs_f16x3")     # another network: not comparable
+    if precision == "f16x3" and side:
         fp32_ref = side_run("fp32")
         fp32_ref["frac_of_fp32_mfma_peak"] = fp32_ref["achieved_tflops"] / PEAK_FP32_MFMA_TFLOPS
         if args.act == "softplus":
             fp32_ref["kernel"] = "pndf_fused_softplus_kernel"
-    if precision == "f16x3" and not args.no_fp32_ref and args.act != "softplus":
+    if precision == "f16x3" and side and args.act != "softplus":
         f16_ref = side_run("f16")
         f16_ref["frac_of_fp16_mfma_peak"] = f16_ref["achieved_tflops"] / PEAK_F16_MFMA_TFLOPS
         f16_ref["note"] = ("reduced precision: operands rounded to fp16, one MFMA per product block; outside the 1e-4 "
@@ -248,6 +334,14 @@ def main():
             out["fp32_exact"] = fp32_ref
         if f16_ref is not None:
             out["f16_single"] = f16_ref
+        if sp_ref is not None:
+            out["softplus"] = sp_ref
+        if world == 1 and not args.no_gpu_torch_baseline:
+            gt = gpu_torch_baseline(args.act, sd, B, args.proj_steps, dev)
+            gt["speedup_of_value"] = out["value"] / gt["value"]
+            if fp32_ref is not None:
+                gt["speedup_of_fp32_exact"] = fp32_ref["poses_per_s_per_gpu"] / gt["value"]
+            out["gpu_torch_baseline"] = gt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.act, sd, args.proj_steps, args.cpu_budget)
         print(json.dumps(out))

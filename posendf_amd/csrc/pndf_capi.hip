@@ -11,6 +11,7 @@
 
 #include "../../include/posendf_amd.h"
 #include "pndf_layout.h"
+#include "pndf_host.h"
 
 using namespace pndf;
 
@@ -29,7 +30,7 @@ struct PndfKernelArgs {
     float slope;
     float beta;
     float* scratch;
-    int dbg_nslots;
+    int reserved0;
     int noenc;
 };
 extern "C" __global__ void pndf_fused_relu_kernel(PndfKernelArgs args);
@@ -52,12 +53,20 @@ struct pndf_engine {
     pndf_config cfg;
     int device = 0;
     bool have_weights = false;
-    char* d_stream = nullptr;   // STEP_TILES KiB
+    char* d_stream = nullptr;   // STEP_TILES KiB + a replica of the first STREAM_PAD_SLOTS slots (the ring never wraps)
     float* d_bias = nullptr;
-    float* d_scratch = nullptr;     // softplus derivative scratch, grown on demand
-    int64_t scratch_wgs = 0;
+    // softplus: fp32 derivative scratch, one block per RESIDENT workgroup (= per CU: the kernels take a whole CU each
+    // and walk the 64-pose blocks with a grid-stride loop), allocated once in pndf_create.  Launches of one handle share
+    // it, so launches on different streams are ordered with an event (sp_done recorded after each softplus launch).
+    float* d_scratch = nullptr;
+    int resident_wgs = 0;
+    hipEvent_t sp_done = nullptr;
+    void* sp_stream = nullptr;
+    bool sp_pending = false;
     std::string err;
 };
+
+constexpr int STREAM_PAD_SLOTS = 4;           // RING_SLOTS - 1 of pndf_device.h: the ring's prefetch distance
 
 static thread_local std::string g_create_err;
 
@@ -120,12 +129,19 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
     HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return fail(nullptr, PNDF_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(nullptr, PNDF_ERR_HIP, "hipSetDevice failed");
     pndf_engine* h = new pndf_engine();
     h->cfg = *cfg;
     h->device = device;
-    HIP_TRY(nullptr, hipSetDevice(device));
-    hipError_t e = hipMalloc((void**)&h->d_stream, (size_t)STEP_TILES * TILE_BYTES);
+    h->resident_wgs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t e = hipMalloc((void**)&h->d_stream, (size_t)(STEP_TILES + STREAM_PAD_SLOTS * SLOT_TILES) * TILE_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias, BIAS_FLOATS * sizeof(float));
+    if (e == hipSuccess && cfg->act == PNDF_ACT_SOFTPLUS) {
+        e = hipMalloc((void**)&h->d_scratch,
+                      (size_t)h->resident_wgs * pndf_kernel_softplus_scratch_floats_per_wg() * sizeof(float));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->sp_done, hipEventDisableTiming);
+    }
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
@@ -155,7 +171,8 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
 
 extern "C" int pndf_destroy(pndf_handle h) {
     if (!h) return PNDF_OK;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
+    if (h->sp_done) (void)hipEventDestroy(h->sp_done);
     if (h->d_stream) (void)hipFree(h->d_stream);
     if (h->d_bias) (void)hipFree(h->d_bias);
     if (h->d_scratch) (void)hipFree(h->d_scratch);
@@ -365,9 +382,13 @@ extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, con
                                              "range of the fp16 hi/lo split -- use precision fp32 for this network");
     if (prc != PNDF_OK)
         return fail(h, PNDF_ERR_BAD_SHAPE, "internal: packed stream length mismatch");
-    HIP_TRY(h, hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(h, PNDF_ERR_HIP, "hipSetDevice failed");
     HIP_TRY(h, hipDeviceSynchronize());   // no launch may still be reading the old weights
     HIP_TRY(h, hipMemcpy(h->d_stream, stream.data(), stream.size() * sizeof(float), hipMemcpyHostToDevice));
+    // replica of the first slots behind the stream: the ring's fetch offset never wraps inside a step
+    HIP_TRY(h, hipMemcpy(h->d_stream + (size_t)STEP_TILES * TILE_BYTES, stream.data(),
+                         (size_t)STREAM_PAD_SLOTS * SLOT_TILES * TILE_BYTES, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
     h->have_weights = true;
     return PNDF_OK;
@@ -391,9 +412,10 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
     a.slope = (h->cfg.act == PNDF_ACT_LRELU) ? 0.01f : 0.0f;   // nn.LeakyReLU() default slope, net_modules.py:31
     a.beta = h->cfg.beta;
     a.scratch = nullptr;
-    a.dbg_nslots = 0;
+    a.reserved0 = 0;
     a.noenc = (h->cfg.dims[0] == NOENC_IN) ? 1 : 0;
-    if (const char* e = getenv("PNDF_DEBUG_NSLOTS")) a.dbg_nslots = atoi(e);   // timing experiments only
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return fail(h, PNDF_ERR_HIP, "hipSetDevice failed");
     const bool softplus = h->cfg.act == PNDF_ACT_SOFTPLUS;
     if (a.noenc && dbg && !timing) return fail(h, PNDF_ERR_UNSUPPORTED, "the stage-dump kernel expects the structure encoder");
     if (softplus && dbg) return fail(h, PNDF_ERR_UNSUPPORTED, "the debug dump exists for the relu-family kernel only");
@@ -403,25 +425,30 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
         if (d) HIP_TRY(h, hipMemsetAsync(d, 0, (size_t)B * sizeof(float), (hipStream_t)stream));
         return PNDF_OK;
     }
-    const dim3 grid((unsigned)((B + WG_POSES - 1) / WG_POSES)), block(WG_THREADS);
+    const int64_t nblocks = (B + WG_POSES - 1) / WG_POSES;
+    const dim3 grid((unsigned)nblocks), block(WG_THREADS);
     if (softplus) {
-        // derivative scratch: one block per workgroup; grown (synchronously) when a larger batch arrives
-        if ((int64_t)grid.x > h->scratch_wgs) {
-            HIP_TRY(h, hipSetDevice(h->device));
-            HIP_TRY(h, hipDeviceSynchronize());
-            if (h->d_scratch) HIP_TRY(h, hipFree(h->d_scratch));
-            h->d_scratch = nullptr;
-            h->scratch_wgs = 0;
-            HIP_TRY(h, hipMalloc((void**)&h->d_scratch,
-                                 (size_t)grid.x * pndf_kernel_softplus_scratch_floats_per_wg() * sizeof(float)));
-            h->scratch_wgs = grid.x;
-        }
+        // Persistent grid: at most one workgroup per CU (a workgroup takes a whole CU), each walking its blocks; the
+        // derivative scratch is indexed by workgroup and was allocated in pndf_create -- nothing is allocated, freed or
+        // synchronised here.  The scratch is shared by all launches of the handle: a launch on another stream than the
+        // previous one first waits (on the device) for that one's completion event.
+        const dim3 pgrid((unsigned)(nblocks < h->resident_wgs ? nblocks : h->resident_wgs));
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
+        const bool capturing = cap != hipStreamCaptureStatusNone;
+        if (h->sp_pending && h->sp_stream != stream && !capturing)
+            HIP_TRY(h, hipStreamWaitEvent((hipStream_t)stream, h->sp_done, 0));
         a.scratch = h->d_scratch;
         if (h->cfg.precision == PNDF_PREC_F16X3)
-            hipLaunchKernelGGL(pndf_fused_split_softplus_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+            hipLaunchKernelGGL(pndf_fused_split_softplus_kernel, pgrid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
         else
-            hipLaunchKernelGGL(pndf_fused_softplus_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+            hipLaunchKernelGGL(pndf_fused_softplus_kernel, pgrid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
         HIP_TRY(h, hipGetLastError());
+        if (!capturing) {
+            HIP_TRY(h, hipEventRecord(h->sp_done, (hipStream_t)stream));
+            h->sp_stream = stream;
+            h->sp_pending = true;
+        }
         return PNDF_OK;
     }
     const bool split = h->cfg.precision == PNDF_PREC_F16X3, half = h->cfg.precision == PNDF_PREC_F16;

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pndf_host.h"
+
 namespace {
 
 constexpr int NJ = 21, NJ_ALL = 23, TH = 69, NQ = 84;
@@ -148,6 +150,8 @@ extern "C" int pndf_aa2quat(const float* theta, float* q, int64_t N, void* strea
     if (N < 0 || (N > 0 && (!theta || !q))) return -1;
     if (((uintptr_t)q) & 15) return -1;
     if (N == 0) return 0;
+    DeviceGuard guard(pndf_pointer_device(q));
+    if (!guard.ok) return -3;
     const long long items = (long long)N * NJ;
     hipLaunchKernelGGL(pndf_aa2quat_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, theta, q,
                        (long long)N);
@@ -161,6 +165,8 @@ extern "C" int pndf_denoise_update(const float* theta_in, float* theta_out, cons
     if (S == 0 || T == 0) return 0;
     if (!theta_in || !theta_out || !theta0 || !d || !dq || !m || !v || !q_next || theta_in == theta_out) return -1;
     if ((((uintptr_t)dq) | ((uintptr_t)q_next)) & 15) return -1;
+    DeviceGuard guard(pndf_pointer_device(q_next));
+    if (!guard.ok) return -3;
     PndfDenoiseArgs a;
     a.theta_in = theta_in; a.theta_out = theta_out; a.theta0 = theta0; a.d = d; a.dq = dq; a.m = m; a.v = v;
     a.q_next = q_next; a.S = S; a.T = T; a.it = it; a.adam_step = adam_step;

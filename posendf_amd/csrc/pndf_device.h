@@ -49,13 +49,20 @@ enum {
 // boundary needs no synchronisation and tile prefetch runs straight through.  Depth matters for the
 // split-precision kernel, which consumes a slot in ~300 cycles: with 3 slots the latency budget of a DMA was
 // one slot time and every L2 miss of the weight stream (3 %, i.e. almost every slot) stalled all four waves.
+//
+// Bookkeeping is kept to what one wave per SIMD can afford (every SALU / VALU instruction is ~4 cycles of the critical
+// path): byte offsets instead of indices, and NO wrap test on the stream side -- the device copy of the stream is
+// followed by a replica of its first RING_SLOTS - 1 slots, the fetch offset just keeps growing through a step and is
+// pulled back by one step's length at the top of the next one (ring_next_step).  Per slot that is
+//   boundary : s_add, s_cmp, s_cselect (buffer offset with wrap) + one v_add (this lane's read pointer)
+//   mid slot : s_add (M0 = LDS destination) + one v_add (this lane's fetch offset)
 struct Ring {
-    const char* gstream;   // packed weight stream (global)
+    const char* gstream;   // packed weight stream (global), followed by a replica of its first 4 slots
     char* smem;
-    int nslots;            // slots per step (wrap point)
-    int next;              // next slot to DMA
-    int cur;               // buffer holding the slot being consumed
-    int wave;              // wave id (uniform)
+    uint32_t fetch_off;    // per lane: stream byte offset of this lane's 16 B of the slot fetched LAST
+    uint32_t cur_off;      // uniform: LDS byte offset (within the ring) of the buffer being consumed
+    uint32_t prev_off;     // uniform: buffer of the previous slot = the one the mid-slot fetch refills
+    uint32_t dst_base;     // uniform: LDS address of this wave's 4 KiB window of buffer 0
     int lane;
 };
 
@@ -63,7 +70,7 @@ struct Ring {
 // LDS destination = M0 + lane * 16).  Issued from inline asm on purpose: when hipcc sees the builtin it
 // degrades every `s_waitcnt lgkmcnt(N)` of the tile prefetch to lgkmcnt(0), which serialises ds_read and
 // MFMA.  Consequence (cdna_hip_programming.md 5.7): the compiler does not count these loads, so every
-// consumer-side barrier is preceded by an explicit `s_waitcnt vmcnt(0)`.
+// consumer-side barrier is preceded by an explicit `s_waitcnt vmcnt(N)`.
 // One 1-KiB piece (tile 4*wave + j of the slot).  Piece 0 points M0 at the wave's LDS window, pieces 1..3 reuse
 // it (the instruction offset moves both the global and the LDS address).
 // Addressing: SGPR base (the stream pointer) + one 32-bit VGPR byte offset -- measured 21 issue cycles per piece
@@ -73,9 +80,8 @@ struct DmaSrc {
     uint32_t off;          // per lane: slot * SLOT_BYTES + wave * 4 KiB + lane * 16
 };
 // M0 is declared clobbered and never restored: hipcc treats M0 as a reserved scratch register that it sets right
-// before each of its own uses (there is none in these kernels), so saving / restoring it only costs issue slots --
-// and with one wave per SIMD every SALU instruction is ~4 cycles of the critical path.  Pieces 1..3 rely on M0 still
-// holding piece 0's value: between them only MFMAs, ds_reads, VALU and waits are issued.
+// before each of its own uses (there is none in these kernels: the only M0 writes in the ISA are the ones below), so
+// saving / restoring it only costs issue slots.  Pieces 1..3 rely on M0 still holding piece 0's value.
 __device__ __forceinline__ void ring_dma_piece(const DmaSrc& src, uint32_t dst, int j) {
     if (j == 0)
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
@@ -88,19 +94,18 @@ __device__ __forceinline__ void ring_dma_piece(const DmaSrc& src, uint32_t dst, 
         asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(src.off), "s"(src.base) : "memory");
 }
 
-// source / destination of this wave's share of the next slot to fetch; advances r.next
-__device__ __forceinline__ void ring_dma_begin(Ring& r, int buf, DmaSrc& src, uint32_t& dst) {
+// source / destination of this wave's share of the next slot to fetch (into the buffer of the previous slot)
+__device__ __forceinline__ void ring_dma_begin(Ring& r, DmaSrc& src, uint32_t& dst) {
+    r.fetch_off += SLOT_BYTES;
     src.base = r.gstream;
-    src.off = (uint32_t)r.next * SLOT_BYTES + r.wave * (4 * TILE_BYTES) + r.lane * 16;
-    const uint32_t lds_base = (uint32_t)(size_t)(PNDF_LDS char*)(r.smem + LDS_RING);
-    dst = lds_base + buf * SLOT_BYTES + r.wave * (4 * TILE_BYTES);
-    r.next = (r.next + 1 == r.nslots) ? 0 : r.next + 1;
+    src.off = r.fetch_off;
+    dst = r.dst_base + r.prev_off;
 }
 
-__device__ __forceinline__ void ring_dma(Ring& r, int buf) {
+__device__ __forceinline__ void ring_dma(Ring& r) {
     DmaSrc src;
     uint32_t dst;
-    ring_dma_begin(r, buf, src, dst);
+    ring_dma_begin(r, src, dst);
 #pragma unroll
     for (int j = 0; j < 4; ++j) ring_dma_piece(src, dst, j);
 }
@@ -109,23 +114,33 @@ __device__ __forceinline__ void ring_wait_dma() { asm volatile("s_waitcnt vmcnt(
 // at most two slot fetches (4 pieces each) of this wave may still be in flight
 __device__ __forceinline__ void ring_wait_next_slot() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 
-__device__ __forceinline__ void ring_start(Ring& r) {
-    r.next = 0;
+// slots 0..3 into buffers 0..3; the caller waits vmcnt(0) + barrier.  The first slot boundary makes buffer 0 current
+// and buffer 4 "previous", so the first mid-slot fetch (slot 4) fills buffer 4.
+__device__ __forceinline__ void ring_start(Ring& r, int wave) {
+    r.dst_base = (uint32_t)(size_t)(PNDF_LDS char*)(r.smem + LDS_RING) + wave * (4 * TILE_BYTES);
+    r.fetch_off = wave * (4 * TILE_BYTES) + r.lane * 16 - SLOT_BYTES;
+    r.prev_off = 0;
 #pragma unroll
-    for (int b = 0; b < RING_SLOTS - 1; ++b) ring_dma(r, b);     // slots 0..3; the caller waits vmcnt(0) + barrier
-    r.cur = RING_SLOTS - 1;                                      // the first slot boundary makes it 0
+    for (int b = 0; b < RING_SLOTS - 1; ++b) {
+        ring_dma(r);
+        r.prev_off += SLOT_BYTES;
+    }
+    r.cur_off = (RING_SLOTS - 1) * SLOT_BYTES;
 }
 
-// buffer that takes the slot fetched at the mid-slot point of the current slot (= buffer of the previous slot)
-__device__ __forceinline__ int ring_fill_buffer(const Ring& r) { return (r.cur == 0) ? RING_SLOTS - 1 : r.cur - 1; }
+// top of projection step 1, 2, ...: the fetch pointer has run one step's length (into the replica of the first slots)
+__device__ __forceinline__ void ring_next_step(Ring& r) { r.fetch_off -= (uint32_t)STEP_SLOTS * SLOT_BYTES; }
 
 // tile 0 of a slot: switch buffers (no barrier needed, see above)
-__device__ __forceinline__ void ring_boundary(Ring& r) { r.cur = (r.cur == RING_SLOTS - 1) ? 0 : r.cur + 1; }
+__device__ __forceinline__ void ring_boundary(Ring& r) {
+    r.prev_off = r.cur_off;
+    r.cur_off = (r.cur_off == (RING_SLOTS - 1) * SLOT_BYTES) ? 0u : r.cur_off + SLOT_BYTES;
+}
 
-// tile 8 of a slot: one barrier, then prefetch two slots ahead into the buffer of the previous slot
+// tile 8 of a slot: one barrier, then prefetch four slots ahead into the buffer of the previous slot
 // A raw s_barrier, not __syncthreads(): the latter's fence adds `s_waitcnt lgkmcnt(0)`, i.e. it waits for the
 // tile prefetch issued a few instructions earlier.  What the barrier has to order is already ordered: every
-// wave's DMA share of the next slot has landed (its own vmcnt(0) above), and every read of the previous slot
+// wave's DMA share of the next slot has landed (its own counted vmcnt above), and every read of the previous slot
 // returned long ago (its data has been consumed by MFMAs issued before this point).
 __device__ __forceinline__ void ring_midslot_sync(Ring& r) {
     ring_wait_next_slot();
@@ -134,7 +149,7 @@ __device__ __forceinline__ void ring_midslot_sync(Ring& r) {
 }
 
 __device__ __forceinline__ f32x4 ring_tile(const Ring& r, int t_in_slot) {
-    return *(const f32x4*)(r.smem + LDS_RING + r.cur * SLOT_BYTES + t_in_slot * TILE_BYTES + r.lane * 16);
+    return *(const f32x4*)(r.smem + LDS_RING + r.cur_off + t_in_slot * TILE_BYTES + r.lane * 16);
 }
 
 // Lanes of ONE wave exchange data through LDS (lane group 0 stores, all lane groups load).  The hardware
@@ -287,7 +302,7 @@ __device__ __forceinline__ f32x4 enc_tile(Ring& ring) {
     if (t == 0) ring_boundary(ring);
     if (t == SLOT_TILES / 2) {
         ring_midslot_sync(ring);
-        ring_dma(ring, ring_fill_buffer(ring));
+        ring_dma(ring);
     }
     return ring_tile(ring, t);
 }
@@ -565,7 +580,7 @@ __device__ __forceinline__ void ring_skip_encoder_section(Ring& ring) {
     for (int s = 0; s < ENC_TILES_PADDED / SLOT_TILES; ++s) {
         ring_boundary(ring);
         ring_midslot_sync(ring);
-        ring_dma(ring, ring_fill_buffer(ring));
+        ring_dma(ring);
     }
 }
 __device__ __forceinline__ void noenc_forward(const float* my_q, float* my_f, int g) {
@@ -618,7 +633,7 @@ struct PndfKernelArgs {
     float slope;            // 0 = relu, 0.01 = lrelu
     float beta;             // softplus beta
     float* scratch;         // softplus: gridDim.x * SP_WG_FLOATS floats of derivative scratch, else null
-    int dbg_nslots;         // 0, or (timing experiments only, wrong results) wrap the weight stream after n slots
+    int reserved0;
     int noenc;              // 1 = model.StrEnc.use False: the trunk sees the normalised quaternions (in_dim 84)
 };
 

@@ -63,7 +63,7 @@ struct PhaseBody {
                         if constexpr (t == 0) ring_boundary(ring);
                         if constexpr (t == SLOT_TILES / 2) {
                             ring_midslot_sync(ring);
-                            ring_dma_begin(ring, ring_fill_buffer(ring), dsrc, ddst);
+                            ring_dma_begin(ring, dsrc, ddst);
                         }
                         nxt[P] = ring_tile(ring, t);
                     }
@@ -247,7 +247,6 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     ap.sp = SP ? (f32x4*)wg_scratch + tid : nullptr;
     ap.stage = (char*)(smem + LDS_F) + wave * (16 * FSTRIDE * 4);
     ap.lane = lane;
-    const long long pose0 = (long long)blockIdx.x * WG_POSES;
     float* const lds_bias = (float*)(smem + LDS_BIAS);
     uint8_t* const lds_mask = (uint8_t*)(smem + LDS_MASK) + tid;
     float* const lds_q = (float*)(smem + LDS_Q);
@@ -259,15 +258,19 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     Ring ring;
     ring.gstream = args.stream;
     ring.smem = smem;
-    ring.nslots = (args.mode == MODE_FORWARD) ? FWD_SLOTS : STEP_SLOTS;
-    if (args.dbg_nslots > 0) ring.nslots = args.dbg_nslots;
-    ring.wave = wave;
     ring.lane = lane;
-    ring_start(ring);   // slots 0 and 1 in flight; the __syncthreads() below makes them visible
-
-    // ---- stage biases and this workgroup's poses in LDS (coalesced)
+    // ---- stage the biases in LDS once (coalesced)
     for (int i = tid; i < BIAS_FLOATS / 4; i += WG_THREADS)
         ((f32x4*)lds_bias)[i] = ((const f32x4*)args.bias)[i];
+
+    // A workgroup owns the 64-pose blocks blockIdx.x, blockIdx.x + gridDim.x, ...: the relu-family kernels are launched
+    // with one workgroup per block, the softplus kernels with at most one workgroup per CU so that the derivative scratch
+    // is bounded by the resident workgroups (pndf_capi.hip).  Every block restarts the ring (the forward-only mode leaves
+    // it in the middle of the stream); the drain + barrier at the end of a block make that safe.
+    const long long nblocks = (args.B + WG_POSES - 1) / WG_POSES;
+    for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const long long pose0 = blk * WG_POSES;
+    ring_start(ring, wave);   // slots 0..3 in flight; the __syncthreads() below makes them visible
     {
         long long nvalid = args.B - pose0;
         if (nvalid > WG_POSES) nvalid = WG_POSES;
@@ -299,6 +302,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
         // ring's DMA.  An opaque copy of g per step keeps those one-instruction address computations inside the step.
         // The same goes for the ~200 64-bit addresses of the derivative scratch slots (ap.sp + slot * 4 KiB).
         int g = g_launch;
+        if (step) ring_next_step(ring);
         if constexpr (SP) {
             asm volatile("" : "+v"(g));
             asm volatile("" : "+v"(ap.sp));
@@ -491,6 +495,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     // drain the DMA prefetch that is still in flight before the workgroup's LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    }   // block loop
 }
 
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1)

@@ -118,24 +118,32 @@ struct DmaPieces {     // the slot fetch that follows a mid-slot barrier, issued
 };
 template <int T0>
 __device__ __forceinline__ void dma_begin(DmaPieces& d, Ring& ring, bool loaded) {
-    if (group_has_mid<8, T0>() && loaded) ring_dma_begin(ring, ring_fill_buffer(ring), d.src, d.dst);
+    if (group_has_mid<8, T0>() && loaded) ring_dma_begin(ring, d.src, d.dst);
 }
 // The four pieces of a slot fetch are spread over the two tile groups that follow the barrier: pieces 0, 1 in the
 // group that ran the mid-slot events (TN == 8), pieces 2, 3 in the next one (TN == 0, same phase by construction:
 // a phase starts on a slot boundary and fetches are only begun when a next group exists).  Each group sets M0 for
 // its first piece; the second one, two MFMAs later, reuses it (M0: see ring_dma_piece).
-template <int TN, bool SECOND>
+#ifndef PNDF_NT_MODE
+#define PNDF_NT_MODE 0      // cache-policy experiments: 1 = `nt` on the two big phases' slot fetches, 2 = on every slot fetch
+#endif
+#define PNDF_DMA_VARIANTS(POLICY)                                                                                        \
+    if constexpr (TN == SLOT_TILES / 2 && !SECOND)                                                                       \
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" POLICY                              \
+                     : : "v"(d.src.off), "s"(d.src.base), "s"(d.dst) : "memory", "m0");                                  \
+    else if constexpr (TN == SLOT_TILES / 2 && SECOND)                                                                   \
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" POLICY : : "v"(d.src.off), "s"(d.src.base) : "memory"); \
+    else if constexpr (TN == 0 && !SECOND)                                                                               \
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" POLICY : : "v"(d.src.off), "s"(d.src.base) : "memory"); \
+    else                                                                                                                 \
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" POLICY : : "v"(d.src.off), "s"(d.src.base) : "memory");
+template <int TN, bool SECOND, bool BIG = false>
 __device__ __forceinline__ void dma_step(const DmaPieces& d) {
-    if constexpr (TN == SLOT_TILES / 2 && !SECOND)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                     : : "v"(d.src.off), "s"(d.src.base), "s"(d.dst) : "memory", "m0");
-    else if constexpr (TN == SLOT_TILES / 2 && SECOND)
-        asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(d.src.off), "s"(d.src.base) : "memory");
-    else if constexpr (TN == 0 && !SECOND)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048"
-                     : : "v"(d.src.off), "s"(d.src.base), "s"(d.dst) : "memory", "m0");
-    else
-        asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(d.src.off), "s"(d.src.base) : "memory");
+    if constexpr (PNDF_NT_MODE == 2 || (PNDF_NT_MODE == 1 && BIG)) {
+        PNDF_DMA_VARIANTS(" nt")
+    } else {
+        PNDF_DMA_VARIANTS("")
+    }
 }
 
 // What follows MFMA J (0..11) of a group, for the group after it (first tile TN of its slot):
@@ -145,7 +153,7 @@ __device__ __forceinline__ void dma_step(const DmaPieces& d) {
 // One LDS read per MFMA instead of a burst of eight: right after the workgroup barrier all four waves used to issue
 // their bursts at once and sat in the LDS queue with an empty MFMA pipe (tools/ubench/split_rate.hip: barrier cost
 // 150 -> 33 cycles per slot).
-template <int TN, int J>
+template <int TN, int J, bool BIG = false>
 __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, bool loaded) {
     if constexpr (J == 0) {
         if (loaded) {
@@ -159,7 +167,7 @@ __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, 
     } else if constexpr (J < 8) {
         if (loaded) nxt[J - 4].l = __builtin_bit_cast(f16x8, ring_tile(ring, TN + 2 * (J - 4) + 1));
     } else if constexpr (J == 9 || J == 11) {
-        if (TN == 0 || loaded) dma_step<TN, J == 11>(dp);
+        if (TN == 0 || loaded) dma_step<TN, J == 11, BIG>(dp);
     }
 }
 
@@ -171,6 +179,7 @@ struct SplitPhase {
     static constexpr int AG = AP / 4, BG = BP / 4;    // groups of 4 pairs
     static constexpr int A_TILES = 2 * AP;
     static constexpr int PARTIALS = 1;                // accumulators per chunk tile (3 = one per term)
+    static constexpr bool BIG = (NC >= 32);           // the two 4 MiB phases (lin2,lin3) / (lin3^T,lin2^T)
     static_assert(AP % 4 == 0 && BP % 4 == 0 && A_TILES % SLOT_TILES == 0, "group / slot alignment");
     static_assert(!SP || PARTIALS == 1, "the softplus epilogue reads one accumulator per chunk tile");
 
@@ -187,7 +196,7 @@ struct SplitPhase {
             const f16x8 x = (term == 1) ? xin[kb].l : xin[kb].h;
             ch[PARTIALS == 3 ? term : 0][ci] = mf16(w, x, ch[PARTIALS == 3 ? term : 0][ci]);
             __builtin_amdgcn_sched_barrier(0);
-            feed<TN, M>(nxt, ring, dp, true);     // part B follows, so there is always a next group
+            feed<TN, M, BIG>(nxt, ring, dp, true);     // part B follows, so there is always a next group
             __builtin_amdgcn_sched_barrier(0);
             a_steps<GA, M + 1>(xin, ch, cur, nxt, ring, dp);
         }
@@ -289,7 +298,7 @@ struct SplitPhase {
             const f16x8 x = (term == 1) ? chb[b].l : chb[b].h;
             acc[nb] = mf16(w, x, acc[nb]);
             __builtin_amdgcn_sched_barrier(0);
-            feed<TN, M>(nxt, ring, dp, loaded);
+            feed<TN, M, BIG>(nxt, ring, dp, loaded);
             __builtin_amdgcn_sched_barrier(0);
             b_steps<GB, M + 1>(chb, acc, cur, nxt, ring, dp, loaded);
         }
@@ -318,8 +327,8 @@ struct SplitPhase {
                         acc[nb] = mf16(w, x, acc[nb]);
                         if (term == 2 && (i & 1) && (TN == 0 || loaded)) {
                             __builtin_amdgcn_sched_barrier(0);
-                            if (i == 1) dma_step<TN, false>(dp);
-                            else dma_step<TN, true>(dp);
+                            if (i == 1) dma_step<TN, false, BIG>(dp);
+                            else dma_step<TN, true, BIG>(dp);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -375,7 +384,7 @@ __device__ __forceinline__ void load_half(f16x8 (&a)[8], Ring& ring) {     // bu
     for (int i = 0; i < 8; ++i) {
         if (i == 4) {
             ring_midslot_sync(ring);
-            ring_dma(ring, ring_fill_buffer(ring));
+            ring_dma(ring);
         }
         a[i] = __builtin_bit_cast(f16x8, ring_tile(ring, 2 * i));
     }
@@ -386,7 +395,7 @@ __device__ __forceinline__ void feed_half(f16x8 (&nxt)[8], Ring& ring, DmaPieces
     if constexpr (J == 0) ring_boundary(ring);
     if constexpr (J == 4) {
         ring_midslot_sync(ring);
-        ring_dma_begin(ring, ring_fill_buffer(ring), dp.src, dp.dst);
+        ring_dma_begin(ring, dp.src, dp.dst);
     }
     nxt[J] = __builtin_bit_cast(f16x8, ring_tile(ring, 2 * J));
     if constexpr (J >= 4) ring_dma_piece(dp.src, dp.dst, J - 4);
@@ -568,7 +577,6 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
 #pragma unroll
     for (int l = 0; l < 6; ++l) inv_w[l] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, args.bias[SCALE_OFF + l])));
     auto layer = [&](int spslot, float inv) { return SAct{args.slope, args.beta, ap.sp, spslot, inv, (char*)(smem + LDS_F) + wave * (16 * FSTRIDE * 4), lane}; };
-    const long long pose0 = (long long)blockIdx.x * WG_POSES;
     float* const lds_bias = (float*)(smem + LDS_BIAS);
     uint8_t* const lds_mask = (uint8_t*)(smem + LDS_MASK) + tid;
     float* const lds_q = (float*)(smem + LDS_Q);
@@ -579,14 +587,19 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
     Ring ring;
     ring.gstream = args.stream;
     ring.smem = smem;
-    ring.nslots = (args.mode == MODE_FORWARD) ? FWD_SLOTS : STEP_SLOTS;
-    if (args.dbg_nslots > 0) ring.nslots = args.dbg_nslots;
-    ring.wave = wave;
     ring.lane = lane;
-    ring_start(ring);
-
+    // ---- stage the biases in LDS once (coalesced)
     for (int i = tid; i < BIAS_FLOATS / 4; i += WG_THREADS)
         ((f32x4*)lds_bias)[i] = ((const f32x4*)args.bias)[i];
+
+    // A workgroup owns the 64-pose blocks blockIdx.x, blockIdx.x + gridDim.x, ...: the relu-family kernels are launched
+    // with one workgroup per block, the softplus kernels with at most one workgroup per CU so that the derivative scratch
+    // is bounded by the resident workgroups (pndf_capi.hip).  Every block restarts the ring (the forward-only mode leaves
+    // it in the middle of the stream); the drain + barrier at the end of a block make that safe.
+    const long long nblocks = (args.B + WG_POSES - 1) / WG_POSES;
+    for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const long long pose0 = blk * WG_POSES;
+    ring_start(ring, wave);   // slots 0..3 in flight; the __syncthreads() below makes them visible
     {
         long long nvalid = args.B - pose0;
         if (nvalid > WG_POSES) nvalid = WG_POSES;
@@ -617,6 +630,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
         // ring's DMA.  An opaque copy of g per step keeps those one-instruction address computations inside the step.
         // The same goes for the ~200 64-bit addresses of the derivative scratch slots (ap.sp + slot * 4 KiB).
         int g = g_launch;
+        if (step) ring_next_step(ring);
         if constexpr (SP) {
             asm volatile("" : "+v"(g));
             asm volatile("" : "+v"(ap.sp));
@@ -791,6 +805,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    }   // block loop
 }
 
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_relu_kernel(PndfKernelArgs args) {

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pndf_host.h"
+
 namespace {
 constexpr int NJ = 21, WG = 256, MAX_K_OUT = 16;
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -92,9 +94,10 @@ extern "C" __global__ void __launch_bounds__(WG) pndf_quat_topk_kernel(PndfQuatD
         __syncthreads();
         if (tid == 0) {
             for (int w = 1; w < WG / 64; ++w) argmin_pair(v, i, pv[w], pi[w]);
-            a.vals[b * a.k + r] = v;
-            a.idx[b * a.k + r] = i;
-            dist[i] = __builtin_inff();
+            const bool found = i < K;                   // false when fewer than r + 1 distances compare (NaN inputs)
+            a.vals[b * a.k + r] = found ? v : __builtin_nanf("");
+            a.idx[b * a.k + r] = found ? i : -1;
+            if (found) dist[i] = __builtin_nanf("");   // taken: NaN never compares, a genuine +inf distance still can
         }
         __syncthreads();
     }
@@ -110,11 +113,16 @@ extern "C" int pndf_quat_topk(const float* noise, const float* valid, int64_t B,
     if ((((uintptr_t)noise) | ((uintptr_t)valid)) & 15) return -1;
     const size_t lds = ((size_t)K * NJ + ((K + 3) & ~3) + NJ * 4 + 24 + 8) * sizeof(float);
     if (lds > 160 * 1024) return -4;                  // K <= ~1,850 candidates per query
-    static bool attr_set = false;
-    if (!attr_set) {
+    DeviceGuard guard(pndf_pointer_device(valid));
+    if (!guard.ok) return -3;
+    // the dynamic-LDS limit is a per-device function attribute: remember which devices have it
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -3;
+    if (!attr_set[dev]) {
         if (hipFuncSetAttribute((const void*)pndf_quat_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return -3;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     PndfQuatDistArgs a;
     a.noise = noise; a.valid = valid; a.vals = vals; a.idx = idx; a.K = K; a.k = k; a.metric = metric;

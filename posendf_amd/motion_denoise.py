@@ -66,10 +66,13 @@ class MotionDenoise:
         v, j = self.body_model(body_pose.reshape(S * T, 69))
         return v.reshape(S, T, *v.shape[1:]), j.reshape(S, T, *j.shape[1:])
 
-    @staticmethod
-    def _mean_norm(x):
-        """mean over (t, point) of the Euclidean norm, per sequence (motion_denoise.py:89,94)."""
-        return torch.sqrt((x * x).sum(dim=-1) + 1e-20).mean(dim=(1, 2))
+    def _mean_norm(self, x):
+        """mean over (t, point) of the Euclidean norm, per sequence (motion_denoise.py:89,94).  With a body model this
+        is the reference's formula as written; the pose-space surrogate adds 1e-20 under the root, so that two frames
+        with an identical joint rotation have a zero instead of a NaN gradient (the reference skips its data term at
+        it = 0 for the same reason, :92 "for nans")."""
+        eps = 1e-20 if self.body_model is None else 0.0
+        return torch.sqrt((x * x).sum(dim=-1) + eps).mean(dim=(1, 2))
 
     def losses(self, body_pose, init_joints, it):
         loss = {"pose_pr": self.pose_prior_term(body_pose)}

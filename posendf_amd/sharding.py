@@ -14,23 +14,37 @@ def shard_bounds(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_blocks(x: torch.Tensor, total: int, group=None):
-    """Gather per-rank blocks (possibly ragged by one row) into the [total, ...] tensor, in rank order."""
+def all_gather_blocks(x: torch.Tensor, total: int, group=None, out: torch.Tensor | None = None):
+    """Gather per-rank blocks (possibly ragged by one row) into the [total, ...] tensor, in rank order.
+    Equal blocks (total % world == 0, the benchmark's case) are gathered with ONE all_gather_into_tensor straight into
+    `out` (allocated by the caller once, or here): no per-rank receive buffers, no concatenation.  Ragged blocks are
+    padded to the common size, gathered the same way and trimmed."""
     import torch.distributed as dist
     if not dist.is_initialized():
         return x
     world = dist.get_world_size(group)
-    rows = max(shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world))
+    x = x.contiguous()
+    if total % world == 0:
+        assert x.shape[0] == total // world, (x.shape, total, world)
+        if out is None:
+            out = x.new_empty((total,) + tuple(x.shape[1:]))
+        dist.all_gather_into_tensor(out, x, group=group)
+        return out
+    rows = -(-total // world)                  # the first total % world ranks hold `rows`, the others rows - 1
     pad = x
-    if x.shape[0] < rows:   # ragged tail: pad to the common block size, trimmed below
+    if x.shape[0] < rows:
         pad = torch.cat([x, x.new_zeros((rows - x.shape[0],) + tuple(x.shape[1:]))])
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad.contiguous(), group=group)
+    buf = x.new_empty((world * rows,) + tuple(x.shape[1:]))
+    dist.all_gather_into_tensor(buf, pad, group=group)
     parts = []
-    for r, b in enumerate(bufs):
+    for r in range(world):
         lo, hi = shard_bounds(total, r, world)
-        parts.append(b[: hi - lo])
-    return torch.cat(parts)
+        parts.append(buf[r * rows: r * rows + (hi - lo)])
+    res = torch.cat(parts)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 def project_sharded(project_fn, q_shard: torch.Tensor, steps: int, total: int, group=None):

@@ -11,6 +11,12 @@ if REPO not in sys.path:
 GOLDEN = os.path.join(REPO, "tests", "golden")
 ACTS = ("lrelu", "relu", "softplus")
 REGIMES = {"live": dict(seed=0, gain=2.0, out_bias=0.1), "mixed": dict(seed=0, gain=2.5, out_bias=0.05)}
+# further reference-generated weight sets (tests/golden/make_golden.py LITE: single step, autograd contract, 1/10 steps)
+LITE_REGIMES = {"s2g3": dict(seed=2, gain=3.0, out_bias=0.05), "s4g25": dict(seed=4, gain=2.5, out_bias=0.05),
+                "s1g1": dict(seed=1, gain=1.0, out_bias=0.2)}
+ALL_REGIMES = {**REGIMES, **LITE_REGIMES}
+# the weight sets of the robustness sweep (tools/gpu_sweep.py, tests/test_gpu_sweep.py): (seed, gain, lin6.bias)
+SWEEP_WEIGHTS = ((0, 2.0, 0.1), (0, 2.5, 0.05), (1, 1.0, 0.2), (2, 3.0, 0.05), (3, 0.5, 0.3), (4, 2.5, 0.05))
 
 
 def pytest_configure(config):
@@ -23,7 +29,7 @@ def load_golden(act, regime):
 
 def golden_weights(regime):
     from posendf_amd import synth
-    return synth.make_weights(**REGIMES[regime])
+    return synth.make_weights(**ALL_REGIMES[regime])
 
 
 def rel_err(a, b):
@@ -63,6 +69,49 @@ def d_err(a, b, floor_frac=0.05):
     return float((np.abs(a - b) / den).max())
 
 
+def d_rows(a, b, floor_frac=0.05):
+    """per-pose form of d_err"""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    return np.abs(a - b) / np.maximum(np.abs(b), floor_frac * max(np.abs(b).max(), 1e-30))
+
+
+def fp32_noise(q, sd, act, draws=8, extra_d=(), extra_g=(), seed=1):
+    """Per-pose fp32 sensitivity of the REFERENCE arithmetic: the largest error against the fp64 run that the fp32 oracle
+    makes over `draws` evaluations whose inputs are perturbed by one fp32 rounding (q (1 + e), |e| <= 2^-23), plus any
+    further reference-arithmetic samples (`extra_*`: per-pose error vectors, e.g. the reference's own fp32 run from the
+    golden file).  A well-conditioned pose gets ~1e-6; a pose whose d is the small difference of large terms, or a
+    softplus pose with exp(beta z) of a large cancelling z, gets what fp32 can actually deliver there.  Returns
+    (sigma_d [B], sigma_g [B], d64, g64) in the metrics of d_rows / rel_err_rows."""
+    from oracle import posendf_np as onp
+    q = np.asarray(q, dtype=np.float32)
+    d64, g64 = onp.forward_grad(q, sd, act, dtype=np.float64)
+    rng = np.random.default_rng(seed)
+    sig_d = [np.asarray(e, dtype=np.float64) for e in extra_d]
+    sig_g = [np.asarray(e, dtype=np.float64) for e in extra_g]
+    for _ in range(draws):
+        qk = (q * (1 + rng.uniform(-2.0 ** -23, 2.0 ** -23, q.shape))).astype(np.float32)
+        d32, g32 = onp.forward_grad(qk, sd, act, dtype=np.float32)
+        sig_d.append(d_rows(d32, d64))
+        sig_g.append(rel_err_rows(g32, g64))
+    return np.max(sig_d, axis=0), np.max(sig_g, axis=0), d64, g64
+
+
+def pose_gate(err, sigma, what="", factor=8.0, floor=8e-6, exempt=None, tol=1e-4):
+    """Every pose individually: error <= factor x the pose's fp32 sensitivity (fp32_noise) + floor.  Calibrated on
+    tools/gpu_sweep.py (6 weight sets x 3 activations x 2 pose distributions x 1,024 poses, both kernels): the largest
+    error / (sigma + 1e-6) observed is 6.3, the 99th percentile 2.7.  `exempt`: poses that are allowed to exceed it
+    (relu family: poses with a pre-activation within 1e-5 of a kink, where the derivative legitimately flips).
+    Also holds the batch to the headline bar where the reference arithmetic itself meets it: median <= tol / 10."""
+    err, sigma = np.asarray(err, dtype=np.float64), np.asarray(sigma, dtype=np.float64)
+    bad = err > factor * sigma + floor
+    if exempt is not None:
+        bad &= ~np.asarray(exempt)
+    assert not bad.any(), (what, int(bad.sum()), np.flatnonzero(bad)[:8].tolist(), err[bad][:8].tolist(),
+                           sigma[bad][:8].tolist())
+    assert np.median(err) <= max(tol / 10, factor * float(np.median(sigma))), (what, float(np.median(err)))
+
+
 def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0):
     """Gate for quantities that are DISCONTINUOUS in the input (d d/d q and everything derived from it):
     a pre-activation within rounding of a ReLU/LeakyReLU kink flips its derivative (1 vs slope), so any two
@@ -79,9 +128,12 @@ def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0):
     assert np.median(mine_rows) < tol / 10, (what, float(np.median(mine_rows)))
     frac, ref_frac = float((mine_rows > tol).mean()), float((ref_rows > tol).mean())
     assert frac <= ratio * ref_frac + slack, (what, frac, ref_frac, float(mine_rows.max()), float(ref_rows.max()))
+    # p95 inside the bar wherever the reference arithmetic's own p95 is
+    if np.percentile(ref_rows, 95) <= tol / 2:
+        assert np.percentile(mine_rows, 95) <= tol, (what, float(np.percentile(mine_rows, 95)))
 
 
-@pytest.fixture(params=[(a, r) for a in ACTS for r in REGIMES], ids=lambda p: f"{p[0]}-{p[1]}")
+@pytest.fixture(params=[(a, r) for a in ACTS for r in ALL_REGIMES], ids=lambda p: f"{p[0]}-{p[1]}")
 def golden_case(request):
     act, regime = request.param
     return act, regime, load_golden(act, regime), golden_weights(regime)

@@ -34,12 +34,27 @@ def test_bench_json_line_default_precision():
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
     cb = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
+    assert {"cpu", "runs_s", "config0_forward_only"} <= set(cb) and cb["config0_forward_only"]["poses_per_s"] > 0
     assert "fp32_exact" in d and "f16_single" in d and "forward_grad_single_launch" in d
+    assert d["softplus"]["kernel"] == "pndf_fused_split_softplus_kernel" and d["softplus"]["kernel_ms"] > 0
+    gt = d["gpu_torch_baseline"]                  # the denominator of north_star's ">= 10x", measured in the same run
+    assert gt["value"] > 0 and abs(gt["speedup_of_value"] - d["value"] / gt["value"]) < 1e-9
 
 
 @pytest.mark.gpu
 def test_bench_json_line_fp32_and_softplus():
-    d = run_bench("--precision", "fp32", "--no-cpu-baseline", "--no-fp32-ref")
+    d = run_bench("--precision", "fp32", "--no-cpu-baseline", "--no-fp32-ref", "--no-gpu-torch-baseline")
     assert d["dtype"] == "f32" and d["roofline"]["peak"] == 157.3 and "cpu_baseline" not in d
-    d = run_bench("--act", "softplus", "--no-cpu-baseline", "--no-fp32-ref")
+    d = run_bench("--act", "softplus", "--no-cpu-baseline", "--no-fp32-ref", "--no-gpu-torch-baseline")
     assert d["roofline"]["kernel"] == "pndf_fused_split_softplus_kernel"
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` launches its own N ranks (torch.distributed.run); with fewer visible devices it must
+    fail loudly instead of printing an n_gpus: 1 line for a job that was asked to be N = 8."""
+    import torch
+    n = torch.cuda.device_count() + 1 if torch.cuda.is_available() else 2
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=REPO,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert out.returncode != 0 and "visible" in out.stderr and not out.stdout.strip()

@@ -5,7 +5,8 @@ distance floor of conftest.d_err."""
 import numpy as np
 import pytest
 
-from conftest import REGIMES, d_err, golden_weights, load_golden, outlier_gate, rel_err, rel_err_rows
+from conftest import (ALL_REGIMES, LITE_REGIMES, REGIMES, d_err, d_rows, fp32_noise, golden_weights, load_golden, outlier_gate,
+                      pose_gate, rel_err, rel_err_rows)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -40,41 +41,75 @@ def make_net(torch, act, regime=None, sd=None, precision="fp32"):
 ALL_ACTS = ["lrelu", "relu", "softplus"]
 
 
+EDGE_POSES = {96: "zero component column (eps clamp of F.normalize)", 97: "tiny pose (scale invariance)",
+              98: "all joints equal", 99: "one zero quaternion"}      # tests/golden/make_golden.py:make_inputs
+
+
+def kink_exempt(q, sd, act):
+    """relu family: poses with a pre-activation within 1e-5 (relative) of a kink in the fp64 run may flip a derivative;
+    everything else -- and every softplus pose -- is held to the per-pose fp32 sensitivity (conftest.pose_gate)."""
+    from oracle import posendf_np as onp
+    return None if act == "softplus" else onp.kink_margin(q, sd, act) < 1e-5
+
+
 @pytest.mark.parametrize("act,precision", cases(ALL_ACTS))
-@pytest.mark.parametrize("regime", list(REGIMES))
+@pytest.mark.parametrize("regime", list(ALL_REGIMES))
 def test_golden_single_step(torch_cuda, act, regime, precision):
     torch = torch_cuda
     g = load_golden(act, regime)
+    sd = golden_weights(regime)
     net = make_net(torch, act, regime, precision=precision)
     q = torch.from_numpy(g["q"]).cuda().requires_grad_(True)
     d = net(q, train=False)["dist_pred"]
     assert d.shape == (len(g["q"]), 1)
     (dq,) = torch.autograd.grad(d, q, grad_outputs=torch.ones_like(d))
-    assert d_err(d.detach().cpu().numpy(), g["d_f32"]) < TOL
-    outlier_gate(rel_err_rows(dq.cpu().numpy(), g["dq_f64"]), rel_err_rows(g["dq_f32"], g["dq_f64"]), TOL, "dq")
+    d_np, dq_np = d.detach().cpu().numpy(), dq.cpu().numpy()
+    if regime in REGIMES:
+        assert d_err(d_np, g["d_f32"]) < TOL         # the headline bar against the reference's fp32 output
+    # every pose individually against the reference's fp64 run, within the fp32 sensitivity of the reference arithmetic
+    # at that pose (the reference's own fp32 output is one of the samples that define it)
+    sig_d, sig_g, _, _ = fp32_noise(g["q"], sd, act, extra_d=[d_rows(g["d_f32"], g["d_f64"])],
+                                    extra_g=[rel_err_rows(g["dq_f32"], g["dq_f64"])])
+    e_d, e_g = d_rows(d_np, g["d_f64"]), rel_err_rows(dq_np, g["dq_f64"])
+    ex = kink_exempt(g["q"], sd, act)
+    pose_gate(e_d, sig_d, "d")
+    pose_gate(e_g, sig_g, "dq", exempt=ex)
+    for i, name in EDGE_POSES.items():               # the edge poses, by name
+        assert e_d[i] <= 8 * sig_d[i] + 8e-6, (name, "d", e_d[i], sig_d[i])
+        assert e_g[i] <= 8 * sig_g[i] + 8e-6 or (ex is not None and ex[i]), (name, "dq", e_g[i], sig_g[i])
+        assert np.isfinite(d_np[i]).all() and np.isfinite(dq_np[i]).all(), name
+    outlier_gate(e_g, rel_err_rows(g["dq_f32"], g["dq_f64"]), TOL, "dq")
     # forward-only launch gives the same distances as the forward+grad launch
     with torch.no_grad():
         d2 = net(torch.from_numpy(g["q"]), train=False)["dist_pred"]      # CPU tensor is moved (posendf.py:64)
     assert torch.equal(d2, d.detach())
     if act != "softplus":
-        # clipped poses: exactly zero distance and exactly zero gradient
-        z = g["d_f32"][:, 0] == 0
-        assert np.array_equal(d.detach().cpu().numpy()[:, 0] == 0, z)
-        assert np.all(dq.cpu().numpy()[z] == 0)
+        # clipped poses: exactly zero distance and exactly zero gradient -- wherever the reference's fp32 AND fp64 runs
+        # agree that the pose is clipped (a pre-activation of lin6 within rounding of 0 may go either way)
+        z = (g["d_f32"][:, 0] == 0) & (g["d_f64"][:, 0] == 0)
+        nz = (g["d_f32"][:, 0] > 0) & (g["d_f64"][:, 0] > 0)
+        assert np.all(d_np[z, 0] == 0) and np.all(dq_np[z] == 0)
+        if regime in REGIMES:
+            assert np.all(d_np[nz, 0] > 0)
 
 
 @pytest.mark.parametrize("act,precision", cases(ALL_ACTS))
-def test_golden_autograd_contract(torch_cuda, act, precision):
+@pytest.mark.parametrize("regime", ["mixed", "s2g3", "s4g25", "s1g1"])
+def test_golden_autograd_contract(torch_cuda, act, precision, regime):
     """backward with an arbitrary upstream gradient (motion_denoise.py:82-83,97-98) and the pose-prior
     objective 1e7 c^2 / (1 + it) of motion_denoise.py:33."""
     torch = torch_cuda
-    g = load_golden(act, "mixed")
-    net = make_net(torch, act, "mixed", precision=precision)
+    g = load_golden(act, regime)
+    sd = golden_weights(regime)
+    net = make_net(torch, act, regime, precision=precision)
     q = torch.from_numpy(g["q"]).cuda().requires_grad_(True)
     (net(q, train=False)["dist_pred"] * torch.from_numpy(g["grad_out"]).cuda()).sum().backward()
     truth = g["dq_f64"] * g["grad_out"].reshape(-1, 1, 1)
-    outlier_gate(rel_err_rows(q.grad.cpu().numpy(), truth), rel_err_rows(g["grad_pose_f32"], truth), TOL, "grad_out")
-    for it in (0, 3):
+    ref_rows = rel_err_rows(g["grad_pose_f32"], truth)
+    outlier_gate(rel_err_rows(q.grad.cpu().numpy(), truth), ref_rows, TOL, "grad_out")
+    _, sig_g, _, _ = fp32_noise(g["q"], sd, act, extra_g=[ref_rows])
+    pose_gate(rel_err_rows(q.grad.cpu().numpy(), truth), sig_g, "grad_out", exempt=kink_exempt(g["q"], sd, act))
+    for it in (() if regime in LITE_REGIMES else (0, 3)):
         q = torch.from_numpy(g["q"]).cuda().requires_grad_(True)
         c = torch.mean(net(q, train=False)["dist_pred"])
         obj = 10.0 ** 7 * c * c / (1 + it)
@@ -87,7 +122,7 @@ def test_golden_autograd_contract(torch_cuda, act, precision):
 
 
 @pytest.mark.parametrize("act,precision", cases(ALL_ACTS))
-@pytest.mark.parametrize("regime", list(REGIMES))
+@pytest.mark.parametrize("regime", list(ALL_REGIMES))
 def test_golden_projection(torch_cuda, act, regime, precision):
     """1/10/100-step projection vs the reference.  Single step: 1e-4.  Free-running: measured against the
     reference's fp64 trajectory with the reference's own fp32 run as the envelope (LeakyReLU/ReLU kinks make
@@ -96,21 +131,23 @@ def test_golden_projection(torch_cuda, act, regime, precision):
     g = load_golden(act, regime)
     net = make_net(torch, act, regime, precision=precision)
     q0 = torch.from_numpy(g["q"]).cuda()
-    for steps in (1, 10, 100):
+    for steps in ((1, 10) if regime in LITE_REGIMES else (1, 10, 100)):
         qp, dl = net.project(q0, steps=steps)
         qp = qp.cpu().numpy()
         truth = g[f"q{steps}_f64"]
         mine = rel_err_rows(qp, truth)
         ref = rel_err_rows(g[f"q{steps}_f32"], truth)
-        outlier_gate(mine, ref, TOL, f"project{steps}")
-        assert np.percentile(mine, 90) < TOL
+        outlier_gate(mine, ref, TOL, f"project{steps}")       # includes BASELINE.md section 5's p95 gate
         # d_last is dist_pred of the last iteration (before its update); along a free-running trajectory it
         # is subject to the same kink divergence as q, so it gets the same outlier gate
         dref64 = g["dtrace_f64"][steps - 1]
         floor = 0.05 * np.abs(dref64).max()
         derr = lambda a: np.abs(np.asarray(a, np.float64) - dref64) / np.maximum(np.abs(dref64), floor)
-        if steps == 1:
+        if steps == 1 and regime in REGIMES:
             assert d_err(dl.cpu().numpy()[:, 0], g["dtrace_f32"][0]) < TOL
+        elif steps == 1:
+            sig_d, _, _, _ = fp32_noise(g["q"], golden_weights(regime), act, extra_d=[d_rows(g["dtrace_f32"][0], dref64)])
+            pose_gate(d_rows(dl.cpu().numpy()[:, 0], dref64), sig_d, "d_last1")
         else:
             outlier_gate(derr(dl.cpu().numpy()[:, 0]), derr(g["dtrace_f32"][steps - 1]), 20 * TOL, f"d_last{steps}")
 

@@ -132,3 +132,132 @@ def test_aa2quat_kernel_matches_restatement():
     assert lib.pndf_aa2quat(theta.data_ptr(), q.data_ptr(), 257, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
     want = axis_angle_to_quaternion(theta.reshape(257, 23, 3)[:, :21])
     assert torch.allclose(q, want, atol=2e-7, rtol=1e-6)
+
+
+# ---------------------------------------------------------------- round 2: independent oracle, cfg-5 size, body model
+def _gold():
+    import os
+    from conftest import GOLDEN
+    return dict(np.load(os.path.join(GOLDEN, "denoise_live.npz")))
+
+
+def _engine_net(act, precision, sd=None):
+    from posendf_amd import PoseNDF, amass_config
+    cfg = amass_config(act, "cuda:0")
+    cfg["engine"] = {"precision": precision}
+    net = PoseNDF(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in (sd or golden_weights("live")).items()})
+    return net.eval()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "autograd"])
+@pytest.mark.parametrize("act,precision", [("lrelu", "fp32"), ("lrelu", "f16x3"), ("softplus", "f16x3")])
+def test_denoise_matches_reference_loop(act, precision, fused):
+    """Both product loops -- the fused HIP step (pndf_aa2quat + pndf_forward_grad + pndf_denoise_update) and the autograd
+    driver -- against the trajectory that the imported reference network produced inside the reference's optimisation
+    loop (tests/golden/make_golden_denoise.py: torch autograd + torch.optim.Adam, fp64), and against the numpy oracle of
+    the step (oracle/denoise_np.py, pinned on the same vectors)."""
+    from oracle import denoise_np as dn
+    from posendf_amd.motion_denoise import MotionDenoise
+    g = _gold()
+    md = MotionDenoise(_engine_net(act, precision), device="cuda:0")
+    theta0 = torch.from_numpy(g["theta0"])
+    # first step: Adam's bias-corrected first update is lr * g / (|g| + eps), i.e. -+lr for every element with a gradient
+    one, _ = md.optimize(theta0, iterations=1, steps_per_iter=1, fused=fused, record=False)
+    want1 = g[f"{act}_theta_f64"][0]
+    assert np.abs(one.cpu().numpy() - want1).max() < 1e-5
+    out, _ = md.optimize(theta0, iterations=2, steps_per_iter=4, fused=fused, record=False)
+    want = g[f"{act}_theta_f64"][-1]
+    err = np.abs(out.cpu().numpy() - want)
+    ref_err = np.abs(g[f"{act}_theta_f32"][-1] - want)            # the reference loop's own fp32 run
+    moved = np.abs(want - g["theta0"]).max()
+    print(f"{act} {precision} fused={fused}: max err {err.max():.2e} median {np.median(err):.2e} | reference fp32 loop "
+          f"{ref_err.max():.2e} | moved {moved:.3f}")
+    assert np.median(err) < 1e-6 and err.max() < max(5e-4, 4 * ref_err.max())
+    assert np.array_equal(out.cpu().numpy()[:, 63:], g["theta0"][:, 63:])        # hand joints: no term, never move
+    # the numpy oracle of the loop in fp32 lands in the same envelope
+    o32 = dn.optimize(g["theta0"], golden_weights("live"), iterations=2, steps_per_iter=4, act=act, dtype=np.float32)
+    assert np.abs(o32 - want).max() < max(5e-4, 4 * ref_err.max())
+
+
+@pytest.mark.gpu
+def test_denoise_config5_size():
+    """BASELINE.json configs[4]: 512 sequences x 300 frames (one GPU holds all of them here; 8 GPUs shard whole
+    sequences).  A few Adam steps of the fused loop at full size: finite, sequences independent (a permuted batch gives
+    the permuted result bit for bit), agreement with the autograd driver, and one sequence against the numpy oracle."""
+    from oracle import denoise_np as dn
+    from posendf_amd.motion_denoise import MotionDenoise
+    S, T, steps = 512, 300, 3
+    sd = golden_weights("live")
+    md = MotionDenoise(_engine_net("lrelu", "f16x3", sd), device="cuda:0")
+    noisy = _noisy_sequences(S, T, seed=7)
+    out, _ = md.optimize(noisy, iterations=1, steps_per_iter=steps, fused=True)
+    assert out.shape == (S, T, 69) and torch.isfinite(out).all()
+    perm = torch.randperm(S, generator=torch.Generator().manual_seed(1))
+    out_p, _ = md.optimize(noisy[perm], iterations=1, steps_per_iter=steps, fused=True)
+    assert torch.equal(out[perm.cuda()], out_p)
+    auto, _ = md.optimize(noisy[:16], iterations=1, steps_per_iter=steps, fused=False, record=False)
+    diff = (auto - out[:16]).abs()
+    assert diff.median().item() < 1e-6 and (diff > 1e-3).float().mean().item() < 0.01
+    s = 37
+    want = dn.optimize(noisy[s].numpy().astype(np.float64), sd, iterations=1, steps_per_iter=steps)
+    err = np.abs(out[s].cpu().numpy() - want)
+    assert np.median(err) < 1e-6 and (err > 1e-3).mean() < 0.01, (np.median(err), err.max())
+    # second outer iteration switches the data term on (:92) and changes the weights
+    out2, _ = md.optimize(noisy[:64], iterations=2, steps_per_iter=2, fused=True)
+    want2 = dn.optimize(noisy[5].numpy().astype(np.float64), sd, iterations=2, steps_per_iter=2)
+    err2 = np.abs(out2[5].cpu().numpy() - want2)
+    assert np.median(err2) < 1e-6 and (err2 > 1e-3).mean() < 0.01
+
+
+class _LinearBlendBody:
+    """A small differentiable stand-in for the SMPL body model of experiments/body_model.py:11-53 (third-party code +
+    licensed model files, not available offline): 40 "vertices" and 24 "joints" as fixed random linear blends of the
+    joint rotation matrices' first columns -- enough to exercise the body-model terms of the objective
+    (motion_denoise.py:86-94: vertex temporal term, joint data term) end to end."""
+
+    def __init__(self, device, dtype=torch.float32, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.wv = (torch.randn(63, 40 * 3, generator=g) / 8).to(device, dtype)
+        self.wj = (torch.randn(63, 24 * 3, generator=g) / 8).to(device, dtype)
+
+    def __call__(self, pose_body):                       # [N,69] -> (vertices [N,40,3], joints [N,24,3])
+        x = torch.sin(pose_body[:, :63])
+        return (x @ self.wv).reshape(-1, 40, 3), (x @ self.wj).reshape(-1, 24, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_body_model_terms_are_pluggable(precision):
+    """a user-supplied differentiable body model drives the temporal / data terms; the pose prior still
+    comes from the HIP engine through its autograd contract.  Checked against the same loop around the PyTorch-CPU
+    oracle network (reference arithmetic), and against the loop WITHOUT the body model (the terms must matter)."""
+    from posendf_amd.motion_denoise import MotionDenoise
+    sd = golden_weights("live")
+    net = _engine_net("lrelu", precision, sd)
+    noisy = _noisy_sequences(2, 10, seed=11)
+    got, h = MotionDenoise(net, body_model=_LinearBlendBody("cuda:0"), device="cuda:0").optimize(
+        noisy, iterations=2, steps_per_iter=5)
+    ref, h_ref = MotionDenoise(_OraclePrior("lrelu", sd), body_model=_LinearBlendBody("cpu"), device="cpu").optimize(
+        noisy, iterations=2, steps_per_iter=5)
+    assert "temp" in h[0] and "data" in h[-1] and abs(h[0]["temp"] - h_ref[0]["temp"]) < 1e-5 * abs(h_ref[0]["temp"])
+    err = (got.cpu() - ref).abs()
+    assert err.median().item() < 1e-5 and err.max().item() < 5e-3, (err.median().item(), err.max().item())
+    plain, _ = MotionDenoise(net, device="cuda:0").optimize(noisy, iterations=2, steps_per_iter=5, record=False)
+    assert (plain.cpu() - got.cpu()).abs().max().item() > 1e-2          # the body-model terms changed the solution
+    with pytest.raises(ValueError):
+        MotionDenoise(net, body_model=_LinearBlendBody("cuda:0"), device="cuda:0").optimize(noisy, fused=True)
+
+
+def test_body_model_hook_cpu():
+    """The body-model plumbing itself, without a GPU: gradients of the vertex / joint terms reach the poses."""
+    from posendf_amd.motion_denoise import MotionDenoise
+    md = MotionDenoise(_OraclePrior("lrelu", golden_weights("live")), body_model=_LinearBlendBody("cpu"), device="cpu")
+    pose = _noisy_sequences(1, 6, seed=2).requires_grad_(True)
+    with torch.no_grad():
+        _, init_j = md._geometry(pose)
+    loss = md.losses(pose, init_j + 0.01, it=1)
+    assert set(loss) == {"pose_pr", "temp", "data"}
+    (loss["temp"].sum() + loss["data"].sum()).backward()
+    assert pose.grad[..., :63].abs().min().item() > 0 and torch.all(pose.grad[..., 63:] == 0)

@@ -4,8 +4,13 @@
 import numpy as np
 import pytest
 
-from conftest import d_err, rel_err
+from conftest import LITE_REGIMES, d_err, d_rows, fp32_noise, pose_gate, rel_err, rel_err_rows
 from oracle import posendf_np as onp
+
+
+def kink_exempt(g, sd, act):
+    """relu family: poses with a pre-activation within 1e-5 (relative) of a kink may flip a derivative"""
+    return None if act == "softplus" else onp.kink_margin(g["q"], sd, act) < 1e-5
 
 
 def test_single_step_fp32(golden_case):
@@ -14,9 +19,20 @@ def test_single_step_fp32(golden_case):
     d, dq = onp.forward_grad(g["q"], sd, act, debug=dbg)
     assert rel_err(dbg["n"], g["n_f32"]) < 1e-5
     assert rel_err(dbg["feat"], g["feat_f32"]) < 1e-5
-    assert d_err(d, g["d_f32"]) < 2e-5
-    assert rel_err(dq, g["dq_f32"]) < 5e-5
-    assert d_err(onp.forward(g["q"], sd, act), g["d_f32"]) < 2e-5
+    if regime in LITE_REGIMES:
+        # ill-conditioned weight sets: two fp32 evaluations (numpy here, torch in the fixture) legitimately differ by more
+        # than 2e-5 on the poses whose d is a small difference of large terms -- each is held, pose by pose, to the fp32
+        # sensitivity of the arithmetic (conftest.fp32_noise), both against the reference's fp64 run
+        sig_d, sig_g, _, _ = fp32_noise(g["q"], sd, act)
+        pose_gate(d_rows(d, g["d_f64"]), sig_d, "oracle d")
+        pose_gate(d_rows(g["d_f32"], g["d_f64"]), sig_d, "reference d")
+        ex = kink_exempt(g, sd, act)
+        pose_gate(rel_err_rows(dq, g["dq_f64"]), sig_g, "oracle dq", exempt=ex)
+        pose_gate(rel_err_rows(g["dq_f32"], g["dq_f64"]), sig_g, "reference dq", exempt=ex)
+    else:
+        assert d_err(d, g["d_f32"]) < 2e-5
+        assert rel_err(dq, g["dq_f32"]) < 5e-5
+        assert d_err(onp.forward(g["q"], sd, act), g["d_f32"]) < 2e-5
     # clipped poses are clipped on both sides, and their gradient is exactly zero
     if act != "softplus":
         z = g["d_f32"][:, 0] == 0
@@ -34,11 +50,20 @@ def test_single_step_fp64(golden_case):
 def test_autograd_contract(golden_case):
     act, regime, g, sd = golden_case
     _, gp = onp.forward_grad(g["q"], sd, act, grad_out=g["grad_out"])
-    assert rel_err(gp, g["grad_pose_f32"]) < 5e-5
+    if regime in LITE_REGIMES:
+        truth = g["dq_f64"] * g["grad_out"].reshape(-1, 1, 1)
+        _, sig_g, _, _ = fp32_noise(g["q"], sd, act)
+        ex = kink_exempt(g, sd, act)
+        pose_gate(rel_err_rows(gp, truth), sig_g, "oracle grad_pose", exempt=ex)
+        pose_gate(rel_err_rows(g["grad_pose_f32"], truth), sig_g, "reference grad_pose", exempt=ex)
+    else:
+        assert rel_err(gp, g["grad_pose_f32"]) < 5e-5
 
 
 def test_pose_prior_objective(golden_case):
     act, regime, g, sd = golden_case
+    if regime in LITE_REGIMES:
+        pytest.skip("lite fixture: no pose-prior vectors")
     for it in (0, 3):
         obj, grad = onp.pose_prior_objective(g["q"], sd, it, act)
         assert abs(obj - g[f"prior_obj_it{it}"]) <= 2e-5 * abs(g[f"prior_obj_it{it}"])
@@ -48,8 +73,9 @@ def test_pose_prior_objective(golden_case):
 def test_projection_fp64(golden_case):
     """fp64 trajectories agree to ~1e-9 unless a ReLU/LeakyReLU kink is crossed within rounding."""
     act, regime, g, sd = golden_case
-    q, d, tr = onp.project(g["q"], sd, steps=100, act=act, dtype=np.float64, trace=True)
-    e = np.abs(q - g["q100_f64"]).reshape(len(q), -1).max(1) / np.abs(g["q100_f64"]).max()
+    last = 10 if regime in LITE_REGIMES else 100
+    q, d, tr = onp.project(g["q"], sd, steps=last, act=act, dtype=np.float64, trace=True)
+    e = np.abs(q - g[f"q{last}_f64"]).reshape(len(q), -1).max(1) / np.abs(g[f"q{last}_f64"]).max()
     assert np.median(e) < 1e-9
     assert (e > 1e-6).mean() <= 0.03
     assert rel_err(tr[0], g["dtrace_f64"][0]) < 1e-9
@@ -59,7 +85,7 @@ def test_projection_fp32_envelope(golden_case):
     """Free-running fp32 vs the reference's fp64 truth: the reference's own fp32 run sets the envelope
     (SURVEY.md section 7 'hard parts'); the oracle must be no worse than 2x + slack."""
     act, regime, g, sd = golden_case
-    for steps in (1, 10, 100):
+    for steps in ((1, 10) if regime in LITE_REGIMES else (1, 10, 100)):
         q, _ = onp.project(g["q"], sd, steps=steps, act=act)
         truth = g[f"q{steps}_f64"]
         scale = np.abs(truth).max()
