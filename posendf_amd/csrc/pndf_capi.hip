@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <string>
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -298,12 +299,12 @@ extern "C" int pndf_pack_host(const float* const* tensors, const int64_t* numel,
 }
 
 // ---- split-precision stream
-// Exact power-of-two operand scaling (pndf_kernel_split.hip, "operand scaling"): the weights of layer l travel as
-// s_l W with s_l = the power of two that brings the layer's largest |weight| into [2^12, 2^13) -- the hi halves cannot
-// overflow and the lo halves of all weights down to 2^-14 of the largest stay in fp16's normal range -- and the trunk
-// biases as s_l 2^4 b (weight scale x forward activation scale).  1 / s_l goes to the bias block (SCALE_OFF + l).
+// Exact power-of-two scaling (pndf_kernel_split.hip, "operand scaling"): the weights of layer l travel as s_l W with
+// s_l = the power of two that brings the layer's largest |weight| into [2^12, 2^13) -- the hi halves cannot overflow and
+// the lo halves of all weights down to 2^-14 of the largest stay in fp16's normal range; 1 / s_l goes to the bias block
+// (SCALE_OFF + l).  Biases stay unscaled: activations and gradients are scaled PER POSE on the chip, and the packer only
+// supplies the norms (NORM_OFF) from which the kernel derives guaranteed bounds for the layers it cannot measure.
 namespace {
-constexpr float SPLIT_XF_SCALE = 16.0f;
 inline void split_f16(float w, _Float16& hi, _Float16& lo) {
     hi = (_Float16)w;                       // round to nearest even
     lo = (_Float16)(w - (float)hi);
@@ -343,7 +344,29 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
         (void)std::frexp(mx, &e);                       // mx = f * 2^e, f in [0.5, 1)
         wscale[l] = std::ldexp(1.0f, 13 - e);           // s_l * mx in [2^12, 2^13)
         bias[SCALE_OFF + l] = 1.0f / wscale[l];
-        for (int i = BIAS_OFF[l]; i < BIAS_OFF[l] + DIMS[l + 1]; ++i) bias[i] *= wscale[l] * SPLIT_XF_SCALE;
+    }
+    // norms for the a-priori bounds of the chunked layers, rounded UP (they must stay upper bounds in fp32)
+    auto up = [](double v) { return std::nextafter((float)v, INFINITY); };
+    for (int k = 0; k < 3; ++k) {
+        const int lf = 2 * k, lb = 5 - 2 * k;           // forward chunk layers 0, 2, 4; backward chunk layers 5, 3, 1
+        const int inf = lin_in(lf, enc), outf = DIMS[lf + 1];
+        double rowmax = 0.0, bmax = 0.0;
+        for (int o = 0; o < outf; ++o) {
+            double sum = 0.0;
+            for (int i = 0; i < inf; ++i) sum += std::fabs((double)lin[2 * lf][(size_t)o * inf + i]);
+            rowmax = std::max(rowmax, sum);
+            bmax = std::max(bmax, std::fabs((double)lin[2 * lf + 1][o]));
+        }
+        const int inb = lin_in(lb, enc), outb = DIMS[lb + 1];
+        double colmax = 0.0;
+        for (int i = 0; i < inb; ++i) {
+            double sum = 0.0;
+            for (int o = 0; o < outb; ++o) sum += std::fabs((double)lin[2 * lb][(size_t)o * inb + i]);
+            colmax = std::max(colmax, sum);
+        }
+        bias[NORM_OFF + k] = up(rowmax);
+        bias[NORM_OFF + 3 + k] = up(bmax);
+        bias[NORM_OFF + 6 + k] = up(colmax);
     }
     float* dst = stream + (size_t)ENC_TILES_PADDED * TILE_FLOATS;
     for (int ph = 0; ph < 6; ++ph) {

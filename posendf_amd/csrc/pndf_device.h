@@ -600,6 +600,16 @@ __device__ __forceinline__ void noenc_forward(const float* my_q, float* my_f, in
     wave_lds_fence();      // written by one lane group each, read by all (x0)
 }
 
+// q <- q - d * grad exactly as the reference evaluates it (experiments/sample_poses.py:74: the product is rounded to
+// fp32, then subtracted).  hipcc's default -ffp-contract=fast would fuse the two into one fma (and __fmul_rn is a plain
+// `*` in this toolchain); an opaque multiply keeps the two roundings, so that project() equals the reference's loop
+// around forward + gradient bit for bit (tests/test_reference_callers.py).
+__device__ __forceinline__ float project_update(float q, float d, float dq) {
+    float prod;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(prod) : "v"(d), "v"(dq));
+    return q - prod;
+}
+
 template <int NT>
 __device__ __forceinline__ void load_bias(f32x4 (&acc)[NT], const float* bias, int g) {
 #pragma unroll

@@ -460,7 +460,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
                     const float dq = gv[c] / denom[c] - qv[c] * kk[c];
                     if (DBG && dbg && step == 0) dbg[(size_t)(DBG_DQ + 4 * j + c) * WG_THREADS + tid] = dq;
                     // q <- q - d * grad  (experiments/sample_poses.py:74: product rounded, then subtracted)
-                    o[c] = (args.mode == MODE_PROJECT) ? __fsub_rn(qv[c], __fmul_rn(dval, dq)) : dq;
+                    o[c] = (args.mode == MODE_PROJECT) ? project_update(qv[c], dval, dq) : dq;
                 }
                 *(f32x4*)(my_q + 4 * j) = o;
             }

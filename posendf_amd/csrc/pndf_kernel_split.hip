@@ -65,25 +65,61 @@ __device__ __forceinline__ float lrelu_bit(float z, float slope, uint32_t& m) {
     return y;
 }
 
-// activation parameters of one layer: relu family (slope) or softplus (beta + this thread's column of the derivative
-// scratch, first slot of the layer; see ActP / SP_SLOT_* in pndf_device.h)
+// Activation parameters of one layer: relu family (slope) or softplus (beta + this thread's column of the derivative
+// scratch, first slot of the layer; see ActP / SP_SLOT_* in pndf_device.h), and the PER-POSE operand scaling.
+//
+// Operand scaling (exact: every factor is a power of two).  An fp16 lo half is ~2^-11 of its value and turns SUBNORMAL
+// below 2^-14, an fp16 hi half overflows at 65504 -- so operands must sit high in the fp16 range without ever leaving
+// it, whatever the magnitudes of the network at hand (gradients of a small-gain network are 1e-6, activations of a
+// large-gain one 1e+3).  Weights: the stream carries s_l W, s_l = the per-layer power of two that brings the largest
+// |weight| into [2^12, 2^13) (chosen by the packer).  Activations and gradients: every pose carries its own power of
+// two sigma(p) per operand tensor, chosen on the chip from a BOUND b(p) >= max_i |x_i(p)| such that
+// b sigma in [2^13, 2^14): the hi halves cannot overflow by construction, for any finite weights and poses.
+//   accumulator layers (x2, x4, g4, g2, and x0 / the seed g6): the bound is MEASURED -- max |value| over the pose's
+//       register-resident tiles (+ two cross-lane steps: a pose's rows live in four lane groups);
+//   chunked layers (x1, x3, x5, g5, g3, g1), produced and consumed a chunk at a time so that all chunks must share one
+//       scale chosen before the first: |W x + b|_inf <= ||W||_inf |x|_inf + |b|_inf (forward; + ln 2 / beta for softplus)
+//       and |W^T g|_inf <= ||W^T||_inf |g|_inf (backward; |act'| <= 1), with the norms supplied by the packer (NORM_OFF).
+//       Such a bound is loose by ~2^6 (sqrt(K) x crest factor), i.e. typical operands sit at 2^7 and every value down to
+//       2^-10 of the typical one still has a NORMAL lo half.
+// The fp32 accumulators of a layer then hold s_l sigma_in x the true value; one multiply per value in the epilogue
+// (`to_true * oscale`, per lane) turns that into the next operand, and forward accumulators start from b s_l sigma_in.
 struct SAct {
     float slope, beta;
     f32x4* sp;
     int spslot;
-    float inv_w;      // 1 / (weight scale of the layer whose accumulators this activation consumes), a power of two
+    float to_true;    // per lane: 1 / (s_l sigma_in): accumulator -> true pre-activation / gradient
+    float oscale;     // per lane: sigma of the operand this layer produces
+    float bscale;     // per lane: s_l sigma_in (forward chunk layers: accumulators start from bias * bscale)
     char* stage;      // softplus backward: this wave's LDS staging window for derivative tiles (1 KiB per tile)
     int lane;
 };
 
-// Power-of-two operand scaling (exact).  An fp16 lo half is ~2^-11 of its value and turns SUBNORMAL below 2^-14: with
-// weights of a few 1e-2 and gradients of 1e-3..1e-1 most lo halves would keep only a few bits.  So the stream carries
-// s_l W (s_l: the per-layer power of two that brings the largest |weight| into [2^12, 2^13), chosen by the packer),
-// forward activations travel as 2^4 x and backward gradients as 2^10 g; the fp32 accumulators then hold s_l 2^4
-// (forward, the packed biases are scaled to match) or s_l 2^10 (backward) times the true value, and ONE multiply by
-// 1 / s_l (SAct::inv_w, from the bias block) in the epilogue turns either into the next layer's scaled operand
-// (LeakyReLU commutes with positive scales).
-constexpr float XF_SCALE = 16.0f, XB_SCALE = 1024.0f;
+// |x| <= bound  ->  power of two sigma with bound * sigma in [2^13, 2^14), clamped to 2^-40 .. 2^40 (a zero or
+// denormal-sized bound must not turn into an inf factor; beyond 2^53 nothing finite is left to protect)
+__device__ __forceinline__ float pose_scale(float bound) {
+    uint32_t e = (__builtin_bit_cast(uint32_t, bound) >> 23) & 0xffu;
+    e = e < 100u ? 100u : (e > 180u ? 180u : e);
+    return __builtin_bit_cast(float, (267u - e) << 23);
+}
+// exact reciprocal of a power of two
+__device__ __forceinline__ float pow2_rcp(float p) { return __builtin_bit_cast(float, 0x7F000000u - __builtin_bit_cast(uint32_t, p)); }
+// a pose's rows live in the four lane groups (lane = 16 g + p): maximum over them
+__device__ __forceinline__ float pose_max(float m) {
+    m = fmaxf(m, __shfl_xor(m, 16));
+    return fmaxf(m, __shfl_xor(m, 32));
+}
+template <int NT>
+__device__ __forceinline__ float tiles_absmax(const f32x4 (&x)[NT]) {
+    float m[4] = {0.f, 0.f, 0.f, 0.f};      // four independent chains: a single one is 2 NT dependent v_max3
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[t & 3] = fmaxf(m[t & 3], fabsf(x[t][r]));
+    }
+    return fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3]));
+}
+constexpr float SOFTPLUS_MAX_OFFSET = 0.6931472f;      // softplus(z) <= max(z, 0) + ln 2 / beta
 
 // two activated fp32 C/D tiles -> the B operand of the k-block they form (8 halfs = 4 dwords, hi and lo)
 template <bool SINGLE = false>
@@ -215,55 +251,105 @@ struct SplitPhase {
         }
     }
 
-    // ---- chunk epilogue: sum the three partials, (forward) bias is already in ch[0], activation or mask, split
-    static __device__ __forceinline__ void epilogue(f32x4 (&ch)[3][CT], Blk (&out)[CB], uint8_t* mask, int c, const SAct& act) {
-        f32x4 y[CT];
-        const float slope = act.slope;
-        if constexpr (SP) {
-            // softplus: fp32 derivatives parked in the per-workgroup scratch, one float4 per lane per chunk tile
+    // ---- chunk epilogue: (forward) bias, activation or derivative, hi/lo split -- as a sequence of NS micro-steps.
+    // One wave per SIMD cannot overlap its own VALU work with its own MFMAs unless the two are interleaved in program
+    // order: an MFMA occupies the pipe for 16 cycles but only 4 of issue, so ~3 other instructions fit behind each one.
+    // The epilogue of chunk c + 1 (its part A has just been issued) is therefore cut into micro-steps of a few VALU
+    // instructions and dealt out over the 24 MFMA slots of the first two groups of part B of chunk c (`slot<J>`, pinned
+    // with sched_barriers by the caller); as one block behind the last MFMA of a group (round 1) its ~75 (CT = 2) /
+    // ~160 (CT = 4) instructions ran with an idle MFMA pipe, 300 - 650 cycles per chunk.
+    //   step 0              forward: bias tiles (x operand scale);  backward: derivative bits
+    //   steps 1 .. NV       one value each (NV = 4 CT): accumulator -> scaled operand value
+    //   step NV + 1         forward: park the derivative bits
+    //   steps NV + 2 ..     one hi/lo split of two values each (2 CT of them), the last one assembles the B operands
+    static constexpr int NV = 4 * CT, NS = NV + 2 + 2 * CT, EPI_SLOTS = 24;
+    static_assert(BG >= 2, "the epilogue is dealt out over two groups of part B");
+    struct Epi {
+        f32x4 (&ch)[3][CT];
+        Blk (&out)[CB];
+        uint8_t* mask;
+        int c;
+        const SAct& act;
+        const float* biasA;
+        int g;
+        f32x4 y[CT], bt[CT];
+        uint32_t bits;
+        unsigned hw[2 * CT], lw[2 * CT];
+        float cf, k1, k0;
+
+        template <int S>
+        __device__ __forceinline__ void step() {
+            if constexpr (S == 0) {
+                cf = act.to_true * act.oscale;
+                if constexpr (SP && BWD) {
+                    wait_staged_derivatives<STAGE_YOUNGER>();
+                } else if constexpr (!BWD) {
 #pragma unroll
-            for (int ci = 0; ci < CT; ++ci) {
-                f32x4* slot = act.sp + (size_t)(act.spslot + c * CT + ci) * WG_THREADS;
-                if (!BWD) {
-                    f32x4 dv;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float dr;
-                        y[ci][r] = act_softplus(ch[0][ci][r] * (act.inv_w * (1.0f / XF_SCALE)), act.beta, dr) * XF_SCALE;
-                        dv[r] = dr;
+                    for (int ci = 0; ci < CT; ++ci) {
+                        bt[ci] = *(const f32x4*)(biasA + 16 * (c * CT + ci) + 4 * g);
+                        if constexpr (!SP) bt[ci] = bt[ci] * act.oscale;
                     }
-                    *slot = dv;
+                    bits = 0;
                 } else {
-                    if (ci == 0) wait_staged_derivatives<STAGE_YOUNGER>();
-                    y[ci] = (ch[0][ci] * act.inv_w) * *(const f32x4*)(act.stage + ci * 1024 + act.lane * 16);
+                    bits = load_chunk_bits<CT>(mask, c);
+                    k1 = (1.0f - act.slope) * cf;
+                    k0 = act.slope * cf;
                 }
-            }
-        } else if (!BWD) {
-            uint32_t bits = 0;
-#pragma unroll
-            for (int ci = CT - 1; ci >= 0; --ci) {
-#pragma unroll
-                for (int r = 3; r >= 0; --r) {
-                    const float z = ((PARTIALS == 3) ? (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r] : ch[0][ci][r]) * act.inv_w;
-                    y[ci][r] = lrelu_bit(z, slope, bits);
+            } else if constexpr (S <= NV) {
+                // forward relu family: from the HIGHEST value down, so that value k ends at bit k (lrelu_bit)
+                constexpr int k = (!SP && !BWD) ? NV - S : S - 1, ci = k / 4, r = k % 4;
+                const float a = (PARTIALS == 3) ? (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r] : ch[0][ci][r];
+                if constexpr (SP && !BWD) {
+                    // softplus: fp32 derivatives parked in the per-workgroup scratch, one float4 per lane per chunk tile
+                    float dr;
+                    y[ci][r] = act_softplus(fmaf(a, act.to_true, bt[ci][r]), act.beta, dr) * act.oscale;
+                    bt[ci][r] = dr;                                  // the bias value is dead: its slot carries the derivative
+                    if constexpr (r == 3) act.sp[(size_t)(act.spslot + c * CT + ci) * WG_THREADS] = bt[ci];
+                } else if constexpr (SP && BWD) {
+                    if constexpr (r == 0) bt[ci] = *(const f32x4*)(act.stage + ci * 1024 + act.lane * 16);
+                    y[ci][r] = (a * cf) * bt[ci][r];
+                } else if constexpr (!BWD) {
+                    y[ci][r] = lrelu_bit(fmaf(a, cf, bt[ci][r]), act.slope, bits);
+                } else {
+                    // derivative factor with the accumulator -> operand scale folded in (exact powers of two apart)
+                    y[ci][r] = a * fmaf((float)((bits >> k) & 1u), k1, k0);
                 }
-            }
-            asm volatile("" : "+v"(bits));      // pin the chain here (see pndf_kernel.hip act_tiles)
-            store_chunk_bits<CT>(mask, c, bits);
-        } else {
-            const uint32_t bits = load_chunk_bits<CT>(mask, c);
+            } else if constexpr (S == NV + 1) {
+                if constexpr (!SP && !BWD) {
+                    asm volatile("" : "+v"(bits));      // pin the chain here (see pndf_kernel.hip act_tiles)
+                    store_chunk_bits<CT>(mask, c, bits);
+                }
+            } else {
+                constexpr int j = S - NV - 2, t = j / 2, h = j % 2;
+                split2<SINGLE>(y[t][2 * h], y[t][2 * h + 1], hw[j], lw[j]);
+                if constexpr (S == NS - 1) {
 #pragma unroll
-            for (int ci = 0; ci < CT; ++ci) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float z = (PARTIALS == 3) ? (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r] : ch[0][ci][r];
-                    // derivative factor with the accumulator -> operand scale folded in (both exact powers of two apart)
-                    y[ci][r] = z * fmaf((float)((bits >> (ci * 4 + r)) & 1u), (1.0f - slope) * act.inv_w, slope * act.inv_w);
+                    for (int b = 0; b < CB; ++b) {
+                        out[b].h = __builtin_bit_cast(f16x8, u32x4{hw[4 * b], hw[4 * b + 1], hw[4 * b + 2], hw[4 * b + 3]});
+                        out[b].l = __builtin_bit_cast(f16x8, u32x4{lw[4 * b], lw[4 * b + 1], lw[4 * b + 2], lw[4 * b + 3]});
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int b = 0; b < CB; ++b) pack_blk<SINGLE>(y[2 * b], y[2 * b + 1], out[b]);
+        template <int S0, int S1>
+        __device__ __forceinline__ void steps() {
+            if constexpr (S0 < S1) {
+                step<S0>();
+                steps<S0 + 1, S1>();
+            }
+        }
+        // the micro-steps dealt to MFMA slot J (0 .. EPI_SLOTS - 1): step S lives in slot S * EPI_SLOTS / NS
+        template <int J>
+        __device__ __forceinline__ void slot() {
+            constexpr int first = (J * NS + EPI_SLOTS - 1) / EPI_SLOTS, last = ((J + 1) * NS + EPI_SLOTS - 1) / EPI_SLOTS;
+            steps<first, last>();
+        }
+    };
+    // the whole epilogue at once (chunk 0 of a phase: there is no MFMA to hide behind; the single-term comparison mode)
+    static __device__ __forceinline__ void epilogue(f32x4 (&ch)[3][CT], Blk (&out)[CB], uint8_t* mask, int c, const SAct& act,
+                                                    const float* biasA, int g) {
+        Epi e{ch, out, mask, c, act, biasA, g};
+        e.template steps<0, NS>();
     }
 
     // Backward softplus: the chunk's parked derivatives are fetched HERE, a whole part A (thousands of cycles) before the
@@ -274,75 +360,48 @@ struct SplitPhase {
     static __device__ __forceinline__ void init_chunk(f32x4 (&ch)[3][CT], const float* biasA, int c, int g, const SAct& act) {
 #pragma unroll
         for (int ci = 0; ci < CT; ++ci) {
-            ch[0][ci] = BWD ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(biasA + 16 * (c * CT + ci) + 4 * g);
+            ch[0][ci] = f32x4{0.f, 0.f, 0.f, 0.f};      // forward: the bias joins in the epilogue (scaled like the result)
             if constexpr (SP && BWD) stage_derivative_tile(act.sp + (size_t)(act.spslot + c * CT + ci) * WG_THREADS, act.stage + ci * 1024);
             ch[1][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
             ch[2][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 
-    // ---- part B: every output tile gets the chunk's contribution.  In group 0 the epilogue of the NEXT chunk
-    // (its part A has just been issued) is placed in the same scheduling region, so its VALU work is
-    // interleaved with these MFMAs by the compiler instead of stalling the pipe (that group keeps the burst prefetch).
-    template <int GB, int M>
+    // ---- part B: every output tile gets the chunk's contribution; behind every MFMA one tile read of the next group
+    // (feed) and, in the first two groups, the micro-steps of the NEXT chunk's epilogue (MORE: there is a next chunk;
+    // the last chunk of a phase is a separate instantiation, so nothing in the loop body is conditional).
+    template <bool MORE, int GB, int M>
     static __device__ __forceinline__ void b_steps(const Blk (&chb)[CB], f32x4 (&acc)[NB], const Pair (&cur)[4],
-                                                   Pair (&nxt)[4], Ring& ring, DmaPieces& dp, bool loaded) {
+                                                   Pair (&nxt)[4], Ring& ring, DmaPieces& dp, Epi& epi) {
         if constexpr (M < 12) {
             constexpr int term = M / 4, i = M % 4, pi = 4 * GB + i, nb = pi / CB, b = pi % CB;
             constexpr int TN = (A_TILES + 8 * (GB + 1)) % SLOT_TILES;
+            constexpr bool LOADED = MORE || (GB + 1 < BG);
             if constexpr (M == 8) {
-                if (loaded) __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8)
-                else __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+                if constexpr (LOADED) __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8)
+                else __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0)
             }
             const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
             const f16x8 x = (term == 1) ? chb[b].l : chb[b].h;
             acc[nb] = mf16(w, x, acc[nb]);
             __builtin_amdgcn_sched_barrier(0);
-            feed<TN, M, BIG>(nxt, ring, dp, loaded);
+            feed<TN, M, BIG>(nxt, ring, dp, LOADED);
+            if constexpr (MORE && 12 * GB + M < EPI_SLOTS) epi.template slot<12 * GB + M>();
             __builtin_amdgcn_sched_barrier(0);
-            b_steps<GB, M + 1>(chb, acc, cur, nxt, ring, dp, loaded);
+            b_steps<MORE, GB, M + 1>(chb, acc, cur, nxt, ring, dp, epi);
         }
     }
-    template <int GB>
+    template <bool MORE, int GB>
     static __device__ __forceinline__ void part_b(const Blk (&chb)[CB], f32x4 (&acc)[NB], Pair (&cur)[4], Ring& ring,
-                                                  DmaPieces& dp, bool more, f32x4 (&chn)[3][CT], Blk (&nextb)[CB],
-                                                  uint8_t* mask, int c, const SAct& act) {
+                                                  DmaPieces& dp, Epi& epi) {
         if constexpr (GB < BG) {
             Pair nxt[4];
-            constexpr int TN = (A_TILES + 8 * (GB + 1)) % SLOT_TILES;
-            const bool loaded = (GB + 1 < BG) || more;
-            if constexpr (GB == 0) {
-                if (loaded) load_pairs<TN>(nxt, ring);
-                dma_begin<TN>(dp, ring, loaded);
-                if (loaded) __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8)
-                else __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int term = 0; term < 3; ++term) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int pi = i, nb = pi / CB, b = pi % CB;
-                        const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
-                        const f16x8 x = (term == 1) ? chb[b].l : chb[b].h;
-                        acc[nb] = mf16(w, x, acc[nb]);
-                        if (term == 2 && (i & 1) && (TN == 0 || loaded)) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (i == 1) dma_step<TN, false, BIG>(dp);
-                            else dma_step<TN, true, BIG>(dp);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                }
-                if (more) epilogue(chn, nextb, mask, c + 1, act);
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-                if (loaded) __builtin_amdgcn_s_waitcnt(0xC47F);   // lgkmcnt(4): hi tiles of this group
-                __builtin_amdgcn_sched_barrier(0);
-                b_steps<GB, 0>(chb, acc, cur, nxt, ring, dp, loaded);
-            }
+            if constexpr (MORE || GB + 1 < BG || true) __builtin_amdgcn_s_waitcnt(0xC47F);   // lgkmcnt(4): hi tiles of this group
+            __builtin_amdgcn_sched_barrier(0);
+            b_steps<MORE, GB, 0>(chb, acc, cur, nxt, ring, dp, epi);
 #pragma unroll
             for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
-            part_b<GB + 1>(chb, acc, cur, ring, dp, more, chn, nextb, mask, c, act);
+            part_b<MORE, GB + 1>(chb, acc, cur, ring, dp, epi);
         }
     }
 
@@ -357,17 +416,20 @@ struct SplitPhase {
         Blk chb[CB];
         init_chunk(ch, biasA, 0, g, act);
         part_a<0>(xin, ch, cur, ring, dp);
-        epilogue(ch, chb, mask, 0, act);
-        for (int c = 0; c < NC; ++c) {
-            const bool more = c + 1 < NC;
+        epilogue(ch, chb, mask, 0, act, biasA, g);
+        for (int c = 0; c + 1 < NC; ++c) {
             Blk nextb[CB];
-            if (more) {
-                init_chunk(ch, biasA, c + 1, g, act);
-                part_a<0>(xin, ch, cur, ring, dp);
-            }
-            part_b<0>(chb, acc, cur, ring, dp, more, ch, nextb, mask, c, act);
+            init_chunk(ch, biasA, c + 1, g, act);
+            part_a<0>(xin, ch, cur, ring, dp);
+            Epi epi{ch, nextb, mask, c + 1, act, biasA, g};
+            part_b<true, 0>(chb, acc, cur, ring, dp, epi);
 #pragma unroll
             for (int b = 0; b < CB; ++b) chb[b] = nextb[b];
+        }
+        {
+            Blk unused[CB];
+            Epi epi{ch, unused, mask, NC, act, biasA, g};      // no next chunk: no micro-step is ever taken from it
+            part_b<false, 0>(chb, acc, cur, ring, dp, epi);
         }
     }
 };
@@ -448,7 +510,7 @@ struct HalfPhase {
     template <int GB>
     static __device__ __forceinline__ void part_b(const Blk (&chb)[CB], f32x4 (&acc)[NB], f16x8 (&cur)[8], Ring& ring,
                                                   DmaPieces& dp, bool more, f32x4 (&chn)[3][CT], Blk (&nextb)[CB],
-                                                  uint8_t* mask, int c, const SAct& act) {
+                                                  uint8_t* mask, int c, const SAct& act, const float* biasA, int g) {
         if constexpr (GB < BG) {
             f16x8 nxt[8];
             const bool loaded = (GB + 1 < BG) || more;
@@ -461,14 +523,14 @@ struct HalfPhase {
                     const int nb = i / CB, b = i % CB;
                     acc[nb] = mf16(cur[i], chb[b].h, acc[nb]);
                 }
-                if (more) Base::epilogue(chn, nextb, mask, c + 1, act);
+                if (more) Base::epilogue(chn, nextb, mask, c + 1, act, biasA, g);
                 __builtin_amdgcn_sched_barrier(0);
             } else {
                 b_steps<GB, 0>(chb, acc, cur, nxt, ring, dp, loaded);
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
-            part_b<GB + 1>(chb, acc, cur, ring, dp, more, chn, nextb, mask, c, act);
+            part_b<GB + 1>(chb, acc, cur, ring, dp, more, chn, nextb, mask, c, act, biasA, g);
         }
     }
 
@@ -483,7 +545,7 @@ struct HalfPhase {
         Blk chb[CB];
         Base::init_chunk(ch, biasA, 0, g, act);
         part_a<0>(xin, ch, cur, ring, dp);
-        Base::epilogue(ch, chb, mask, 0, act);
+        Base::epilogue(ch, chb, mask, 0, act, biasA, g);
         for (int c = 0; c < NC; ++c) {
             const bool more = c + 1 < NC;
             Blk nextb[CB];
@@ -491,7 +553,7 @@ struct HalfPhase {
                 Base::init_chunk(ch, biasA, c + 1, g, act);
                 part_a<0>(xin, ch, cur, ring, dp);
             }
-            part_b<0>(chb, acc, cur, ring, dp, more, ch, nextb, mask, c, act);
+            part_b<0>(chb, acc, cur, ring, dp, more, ch, nextb, mask, c, act, biasA, g);
 #pragma unroll
             for (int b = 0; b < CB; ++b) chb[b] = nextb[b];
         }
@@ -503,11 +565,18 @@ struct PhaseSel { using type = SplitPhase<KA2, CT, NC, NB, BWD, false, SP>; };
 template <int KA2, int CT, int NC, int NB, bool BWD>
 struct PhaseSel<1, false, KA2, CT, NC, NB, BWD> { using type = HalfPhase<KA2, CT, NC, NB, BWD>; };
 
-// activation of an accumulator layer + split into the next phase's B operands; relu family: sign bits in registers,
-// softplus: fp32 derivatives to the scratch (slot act.spslot + tile)
+// Activation of an accumulator layer + split into the next phase's B operands; relu family: sign bits in registers,
+// softplus: fp32 derivatives to the scratch (slot act.spslot + tile).  The accumulators hold act.to_true^-1 x the true
+// pre-activation; the operand scale of the result is MEASURED here (see SAct) unless the caller fixes it (`fixed` > 0:
+// the last layer keeps true values for lin6).  Returns the bound of the produced values (true scale) in `bound` and
+// their operand scale in `oscale`.
 template <int NT, bool SINGLE = false, bool SP = false>
-__device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 2], uint32_t (&m)[(NT * 4 + 31) / 32], const SAct& act) {
+__device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 2], uint32_t (&m)[(NT * 4 + 31) / 32], const SAct& act,
+                                                float fixed, float& bound, float& oscale) {
     constexpr int NW = (NT * 4 + 31) / 32;
+    bound = pose_max(tiles_absmax<NT>(x)) * act.to_true;          // |act(z)| <= |z| (+ ln 2 / beta for softplus)
+    if constexpr (SP) bound += SOFTPLUS_MAX_OFFSET / act.beta;
+    oscale = fixed > 0.f ? fixed : pose_scale(bound);
     if constexpr (SP) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -515,7 +584,7 @@ __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float dr;
-                x[t][r] = act_softplus(x[t][r] * (act.inv_w * (1.0f / XF_SCALE)), act.beta, dr) * XF_SCALE;
+                x[t][r] = act_softplus(x[t][r] * act.to_true, act.beta, dr) * oscale;
                 dv[r] = dr;
             }
             act.sp[(size_t)(act.spslot + t) * WG_THREADS] = dv;
@@ -523,6 +592,7 @@ __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 
 #pragma unroll
         for (int w = 0; w < NW; ++w) m[w] = 0;
     } else {
+        const float cf = act.to_true * oscale;
 #pragma unroll
         for (int w = NW - 1; w >= 0; --w) {
             uint32_t bits = 0;
@@ -530,7 +600,7 @@ __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 
 #pragma unroll
             for (int k = top; k >= 32 * w; --k) {
                 const int t = k / 4, r = k % 4;
-                x[t][r] = lrelu_bit(x[t][r] * act.inv_w, act.slope, bits);
+                x[t][r] = lrelu_bit(x[t][r] * cf, act.slope, bits);
             }
             m[w] = bits;
             asm volatile("" : "+v"(m[w]));      // pin the packing here (see pndf_kernel.hip act_tiles)
@@ -540,16 +610,21 @@ __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 
     for (int t = 1; t < NT; t += 2) pack_blk<SINGLE>(x[t - 1], x[t], out[t / 2]);
 }
 
+// Backward counterpart: gradient accumulators x act' -> B operands, scale measured (|act'| <= 1).
 template <int NT, bool SINGLE = false, bool SP = false>
-__device__ __forceinline__ void dact_split_tiles(f32x4 (&gx)[NT], Blk (&out)[NT / 2], const uint32_t (&m)[(NT * 4 + 31) / 32], const SAct& act) {
+__device__ __forceinline__ void dact_split_tiles(f32x4 (&gx)[NT], Blk (&out)[NT / 2], const uint32_t (&m)[(NT * 4 + 31) / 32], const SAct& act,
+                                                 float& bound, float& oscale) {
+    bound = pose_max(tiles_absmax<NT>(gx)) * act.to_true;
+    oscale = pose_scale(bound);
+    const float cf = act.to_true * oscale, k1 = (1.0f - act.slope) * cf, k0 = act.slope * cf;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if constexpr (SP) {
-            gx[t] = (gx[t] * act.inv_w) * act.sp[(size_t)(act.spslot + t) * WG_THREADS];
+            gx[t] = (gx[t] * cf) * act.sp[(size_t)(act.spslot + t) * WG_THREADS];
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                gx[t][r] = gx[t][r] * fmaf((float)((m[(t * 4 + r) / 32] >> ((t * 4 + r) % 32)) & 1u), (1.0f - act.slope) * act.inv_w, act.slope * act.inv_w);
+                gx[t][r] = gx[t][r] * fmaf((float)((m[(t * 4 + r) / 32] >> ((t * 4 + r) % 32)) & 1u), k1, k0);
         }
         if (t & 1) pack_blk<SINGLE>(gx[t - 1], gx[t], out[t / 2]);
     }
@@ -572,11 +647,21 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
     ap.slope = args.slope;
     ap.beta = args.beta;
     ap.sp = SP ? (f32x4*)(args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS) + tid : nullptr;
-    // 1 / weight scale of lin0..lin5 (powers of two chosen by the packer), uniform
-    float inv_w[6];
+    // uniform constants of the packer: 1 / weight scale of lin0..lin5 (powers of two) and the norms behind the a-priori
+    // bounds of the chunked layers (pndf_layout.h NORM_OFF)
+    auto uni = [&](int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, args.bias[i]))); };
+    float inv_w[6], nrm[9];
 #pragma unroll
-    for (int l = 0; l < 6; ++l) inv_w[l] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, args.bias[SCALE_OFF + l])));
-    auto layer = [&](int spslot, float inv) { return SAct{args.slope, args.beta, ap.sp, spslot, inv, (char*)(smem + LDS_F) + wave * (16 * FSTRIDE * 4), lane}; };
+    for (int l = 0; l < 6; ++l) inv_w[l] = uni(SCALE_OFF + l);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nrm[i] = uni(NORM_OFF + i);
+    const float sp_off = SP ? SOFTPLUS_MAX_OFFSET / args.beta : 0.f;
+    // layer l, operand of scale sigma_in coming in (per lane), operand of scale sigma_out going out (see SAct)
+    auto layer = [&](int spslot, int l, float sigma_in, float sigma_out) {
+        const float to_true = inv_w[l] * pow2_rcp(sigma_in);
+        return SAct{args.slope, args.beta, ap.sp, spslot, to_true, sigma_out, pow2_rcp(to_true),
+                    (char*)(smem + LDS_F) + wave * (16 * FSTRIDE * 4), lane};
+    };
     float* const lds_bias = (float*)(smem + LDS_BIAS);
     uint8_t* const lds_mask = (uint8_t*)(smem + LDS_MASK) + tid;
     float* const lds_q = (float*)(smem + LDS_Q);
@@ -639,6 +724,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
         uint32_t m2[4], m4[4], m6[1];
         f32x4 x6[4];
         Blk b4[16];
+        float fwd_bound, fwd_sigma;      // per pose: bound (true scale) and operand scale of the last accumulator layer
         {
             Blk b2[16];
             {
@@ -648,30 +734,59 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
                 } else {
                     encoder_forward<SP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ap, g);
                 }
+                // x0: the pose's 128 feature rows, bound measured, scaled per pose (see SAct)
+                f32x4 f0[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) f0[t] = *(const f32x4*)(my_f + 16 * t + 4 * g);
+                float bnd = pose_max(tiles_absmax<8>(f0));
+                float sg_in = pose_scale(bnd);
                 Blk b0[4];
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-                    pack_blk<SG>(*(const f32x4*)(my_f + 32 * kb + 4 * g) * XF_SCALE, *(const f32x4*)(my_f + 32 * kb + 16 + 4 * g) * XF_SCALE, b0[kb]);
+                for (int kb = 0; kb < 4; ++kb) pack_blk<SG>(f0[2 * kb] * sg_in, f0[2 * kb + 1] * sg_in, b0[kb]);
                 tick<TIMING>(rc, 0);
+                float sg_ch = pose_scale(fmaf(nrm[0], bnd, nrm[3] + sp_off));        // x1: |W0 x0 + b0| <= ||W0|| |x0| + |b0|
                 f32x4 x2[32];
                 load_bias<32>(x2, lds_bias + BIAS_OFF[1], g);
-                PhaseSel<TERMS, SP, 4, 2, 8, 32, false>::type::run(b0, x2, ring, lds_bias + BIAS_OFF[0], lds_mask + MASK_BASE[0] * WG_THREADS, layer(SP_SLOT_CHUNK[0], inv_w[0]), g);
+                {
+                    const float bs = pow2_rcp(inv_w[1]) * sg_ch;                      // x2 accumulates s_1 sigma_x1 (W1 x1 + b1)
+#pragma unroll
+                    for (int t = 0; t < 32; ++t) x2[t] = x2[t] * bs;
+                }
+                PhaseSel<TERMS, SP, 4, 2, 8, 32, false>::type::run(b0, x2, ring, lds_bias + BIAS_OFF[0], lds_mask + MASK_BASE[0] * WG_THREADS, layer(SP_SLOT_CHUNK[0], 0, sg_in, sg_ch), g);
                 tick<TIMING>(rc, 1);
-                act_split_tiles<32, SG, SP>(x2, b2, m2, layer(SP_SLOT_X2, inv_w[1]));
+                act_split_tiles<32, SG, SP>(x2, b2, m2, layer(SP_SLOT_X2, 1, sg_ch, 0.f), 0.f, bnd, sg_in);
                 tick<TIMING>(rc, 2);
+                fwd_bound = bnd;
+                fwd_sigma = sg_in;
             }
+            float bnd = fwd_bound, sg_in = fwd_sigma;
+            float sg_ch = pose_scale(fmaf(nrm[1], bnd, nrm[4] + sp_off));            // x3
             f32x4 x4[32];
             load_bias<32>(x4, lds_bias + BIAS_OFF[3], g);
-            PhaseSel<TERMS, SP, 16, 2, 32, 32, false>::type::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], inv_w[2]), g);
+            {
+                const float bs = pow2_rcp(inv_w[3]) * sg_ch;
+#pragma unroll
+                for (int t = 0; t < 32; ++t) x4[t] = x4[t] * bs;
+            }
+            PhaseSel<TERMS, SP, 16, 2, 32, 32, false>::type::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], 2, sg_in, sg_ch), g);
             tick<TIMING>(rc, 3);
-            act_split_tiles<32, SG, SP>(x4, b4, m4, layer(SP_SLOT_X4, inv_w[3]));
+            act_split_tiles<32, SG, SP>(x4, b4, m4, layer(SP_SLOT_X4, 3, sg_ch, 0.f), 0.f, bnd, sg_in);
             tick<TIMING>(rc, 4);
+            fwd_bound = bnd;
+            fwd_sigma = sg_in;
         }
-        load_bias<4>(x6, lds_bias + BIAS_OFF[5], g);
-        PhaseSel<TERMS, SP, 16, 4, 4, 4, false>::type::run(b4, x6, ring, lds_bias + BIAS_OFF[4], lds_mask + MASK_BASE[2] * WG_THREADS, layer(SP_SLOT_CHUNK[2], inv_w[4]), g);
-        tick<TIMING>(rc, 5);
-        Blk b6[2];
-        act_split_tiles<4, SG, SP>(x6, b6, m6, layer(SP_SLOT_X6, inv_w[5]));      // b6 unused forward; x6 (fp32) feeds lin6
+        {
+            const float sg_ch = pose_scale(fmaf(nrm[2], fwd_bound, nrm[5] + sp_off));    // x5
+            load_bias<4>(x6, lds_bias + BIAS_OFF[5], g);
+            const float bs = pow2_rcp(inv_w[5]) * sg_ch;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x6[t] = x6[t] * bs;
+            PhaseSel<TERMS, SP, 16, 4, 4, 4, false>::type::run(b4, x6, ring, lds_bias + BIAS_OFF[4], lds_mask + MASK_BASE[2] * WG_THREADS, layer(SP_SLOT_CHUNK[2], 4, fwd_sigma, sg_ch), g);
+            tick<TIMING>(rc, 5);
+            Blk b6[2];
+            float bnd6, sg6;
+            act_split_tiles<4, SG, SP>(x6, b6, m6, layer(SP_SLOT_X6, 5, sg_ch, 0.f), 1.0f, bnd6, sg6);   // b6 unused; x6 keeps TRUE values for lin6
+        }
 
         // ---------------- lin6 (64 -> 1) + output ReLU, fp32 on the VALU
         f32x4 w6[4];
@@ -684,7 +799,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
         }
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);
-        const float z7 = part * (1.0f / XF_SCALE) + lds_bias[BIAS_OFF[6]];      // x6 travels as 2^4 x
+        const float z7 = part + lds_bias[BIAS_OFF[6]];
         float gz7;
         if constexpr (SP) {
             dval = act_softplus(z7, ap.beta, gz7);      // output Softplus, net_modules.py:39-41,69
@@ -695,7 +810,8 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
         if (args.mode == MODE_FORWARD) break;
         // grad_outputs and the output activation's derivative (softplus: anything in (0, 1]) scale the RESULT, not the
         // seed of the backward pass: the pass is linear in the seed, and a seed of 1e-7 (or 1e+6: motion_denoise.py's
-        // 1e7 * c^2 weight) would leave the fp16 range of the operands.  The seed is XB_SCALE, undone in g0 below.
+        // 1e7 * c^2 weight) would leave the fp16 range of the operands.  The seed is w6 itself, scaled per pose like every
+        // other operand.
         float gscale = gz7;
         if (args.mode == MODE_FORWARD_GRAD && args.grad_out) {
             long long pidx = pose0 + wp;
@@ -706,6 +822,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
         // ---------------- trunk backward
         {
             f32x4 g0[8];
+            float bwd_bound, bwd_sigma, g0_true;
             {
                 Blk gb2[16];
                 {
@@ -713,30 +830,37 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
                     {
                         f32x4 g6[4];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) g6[t] = w6[t] * XB_SCALE;                 // the seed: no accumulator scale to undo
+                        for (int t = 0; t < 4; ++t) g6[t] = w6[t];                            // the seed d z7 / d x6
                         Blk gb6[2];
-                        dact_split_tiles<4, SG, SP>(g6, gb6, m6, layer(SP_SLOT_X6, 1.0f));
+                        SAct seed = layer(SP_SLOT_X6, 5, 1.0f, 0.f);
+                        seed.to_true = 1.0f;                                                  // no accumulator scale to undo
+                        float bnd, sg_in;
+                        dact_split_tiles<4, SG, SP>(g6, gb6, m6, seed, bnd, sg_in);
                         tick<TIMING>(rc, 6);
+                        const float sg_ch = pose_scale(nrm[6] * bnd);                         // g5: |W5^T g6| <= ||W5^T|| |g6|
                         f32x4 g4[32];
 #pragma unroll
                         for (int t = 0; t < 32; ++t) g4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        PhaseSel<TERMS, SP, 2, 4, 4, 32, true>::type::run(gb6, g4, ring, nullptr, lds_mask + MASK_BASE[2] * WG_THREADS, layer(SP_SLOT_CHUNK[2], inv_w[5]), g);
-                        dact_split_tiles<32, SG, SP>(g4, gb4, m4, layer(SP_SLOT_X4, inv_w[4]));
+                        PhaseSel<TERMS, SP, 2, 4, 4, 32, true>::type::run(gb6, g4, ring, nullptr, lds_mask + MASK_BASE[2] * WG_THREADS, layer(SP_SLOT_CHUNK[2], 5, sg_in, sg_ch), g);
+                        dact_split_tiles<32, SG, SP>(g4, gb4, m4, layer(SP_SLOT_X4, 4, sg_ch, 0.f), bwd_bound, bwd_sigma);
                         tick<TIMING>(rc, 7);
                     }
+                    const float sg_ch = pose_scale(nrm[7] * bwd_bound);                       // g3
                     f32x4 g2[32];
 #pragma unroll
                     for (int t = 0; t < 32; ++t) g2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    PhaseSel<TERMS, SP, 16, 2, 32, 32, true>::type::run(gb4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], inv_w[3]), g);
-                    dact_split_tiles<32, SG, SP>(g2, gb2, m2, layer(SP_SLOT_X2, inv_w[2]));
+                    PhaseSel<TERMS, SP, 16, 2, 32, 32, true>::type::run(gb4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], 3, bwd_sigma, sg_ch), g);
+                    dact_split_tiles<32, SG, SP>(g2, gb2, m2, layer(SP_SLOT_X2, 2, sg_ch, 0.f), bwd_bound, bwd_sigma);
                     tick<TIMING>(rc, 8);
                 }
+                const float sg_ch = pose_scale(nrm[8] * bwd_bound);                           // g1
 #pragma unroll
                 for (int t = 0; t < 8; ++t) g0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                PhaseSel<TERMS, SP, 16, 2, 8, 8, true>::type::run(gb2, g0, ring, nullptr, lds_mask + MASK_BASE[0] * WG_THREADS, layer(SP_SLOT_CHUNK[0], inv_w[1]), g);
+                PhaseSel<TERMS, SP, 16, 2, 8, 8, true>::type::run(gb2, g0, ring, nullptr, lds_mask + MASK_BASE[0] * WG_THREADS, layer(SP_SLOT_CHUNK[0], 1, bwd_sigma, sg_ch), g);
+                g0_true = inv_w[0] * pow2_rcp(sg_ch);                                         // g0 accumulated s_0 sigma_g1 x the true gradient
             }
 #pragma unroll
-            for (int t = 0; t < 8; ++t) *(f32x4*)(my_f + 16 * t + 4 * g) = g0[t] * (inv_w[0] * (1.0f / XB_SCALE));
+            for (int t = 0; t < 8; ++t) *(f32x4*)(my_f + 16 * t + 4 * g) = g0[t] * g0_true;
         }
         __syncthreads();
 
@@ -773,7 +897,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
                 for (int c = 0; c < 4; ++c) {
                     const float dq = gv[c] / denom[c] - qv[c] * kk[c];
                     const float dqs = dq * gscale;
-                    o[c] = (args.mode == MODE_PROJECT) ? __fsub_rn(qv[c], __fmul_rn(dval, dqs)) : dqs;
+                    o[c] = (args.mode == MODE_PROJECT) ? project_update(qv[c], dval, dqs) : dqs;
                 }
                 *(f32x4*)(my_q + 4 * j) = o;
             }

@@ -98,7 +98,11 @@ constexpr int W6_OFF = 2624;
 constexpr int NOENC_IN = 84;        // DFNet in_dim without the structure encoder (model.StrEnc.use = False): 21 x 4
 constexpr int ENCB_OFF = 2692;      // encoder biases: per joint b1 padded to 16, then b2 on rows 4..9 of 16
 constexpr int SCALE_OFF = ENCB_OFF + 21 * 32;   // split stream: 1 / (weight scale) of lin0..lin5 (8 floats; 1.0 in the fp32 block)
-constexpr int BIAS_FLOATS = SCALE_OFF + 8;
+// split stream: norms for the a-priori operand bounds of the chunked layers (pndf_kernel_split.hip "operand scaling")
+//   [0..2] ||W_l||_inf (largest absolute row sum), l = 0, 2, 4      [3..5] max |b_l|, l = 0, 2, 4
+//   [6..8] ||W_l^T||_inf (largest absolute column sum), l = 5, 3, 1 [9..11] unused
+constexpr int NORM_OFF = SCALE_OFF + 8;
+constexpr int BIAS_FLOATS = NORM_OFF + 12;
 
 constexpr int PARENT[NJ] = {-1, -1, -1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19};
 constexpr int enc_in(int j) { return PARENT[j] < 0 ? 4 : 10; }

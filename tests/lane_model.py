@@ -283,19 +283,21 @@ def _mm3(w, x, c):
     return c
 
 
-def run_phase_split(ph, xin, acc, st, bias_a, masks, slope, bwd, inv_a):
-    """xin: list of (hi, lo) blocks; acc: list of fp32 tiles.  Stream order A(0) | A(c+1) B(c) ... (pndf_layout.h)."""
+def run_phase_split(ph, xin, acc, st, bias_a, masks, slope, bwd, to_true, oscale, bscale):
+    """xin: list of (hi, lo) blocks; acc: list of fp32 tiles.  Stream order A(0) | A(c+1) B(c) ... (pndf_layout.h).
+    to_true / oscale / bscale: the per-lane factors of SAct (pndf_kernel_split.hip "operand scaling"), [64] each."""
     KA, CT, NC, NB = PHASES[ph]
+    cf = (to_true * oscale).astype(np.float32)[:, None]
 
     def part_a(c):
         ch = [np.zeros((64, 4), np.float32) for _ in range(CT)]
         if not bwd:
             for ci in range(CT):
-                ch[ci] = _tile_bias(bias_a, 16 * (c * CT + ci))
+                ch[ci] = _tile_bias(bias_a, 16 * (c * CT + ci)) * bscale.astype(np.float32)[:, None]
         for kb in range(KA // 2):
             for ci in range(CT):
                 ch[ci] = _mm3(st.pair(), xin[kb], ch[ci])
-        ch = [t * np.float32(inv_a) for t in ch]               # accumulator -> scaled operand (kernel: SAct::inv_w)
+        ch = [t * cf for t in ch]                               # accumulator -> scaled operand (LeakyReLU commutes)
         if not bwd:
             m = [t > 0 for t in ch]
             masks[(ph, c)] = m
@@ -313,18 +315,27 @@ def run_phase_split(ph, xin, acc, st, bias_a, masks, slope, bwd, inv_a):
         chb = nxt
 
 
-# exact power-of-two operand scaling of the split kernel (pndf_kernel_split.hip): s_l W in the stream (1 / s_l in the
-# bias block at SCALE_OFF + l), forward activations as 2^4 x, backward gradients as 2^10 g, trunk biases as s_l 2^4 b
-XF_SCALE, XB_SCALE = 16.0, 1024.0
+# Per-pose power-of-two operand scaling of the split kernel (pndf_kernel_split.hip): weights as s_l W (1 / s_l in the
+# bias block at SCALE_OFF + l), every operand tensor as sigma(p) x with sigma chosen from a measured or a-priori bound
 SCALE_OFF = ENCB_OFF + 21 * 32
+NORM_OFF = SCALE_OFF + 8
 
 
-def _descale(tiles, inv):
-    return [t * np.float32(inv) for t in tiles]
+def pose_scale(bound):
+    e = (np.asarray(bound, np.float32).view(np.uint32) >> 23) & 0xff
+    e = np.clip(e, 100, 180).astype(np.uint32)
+    return ((np.uint32(267) - e) << np.uint32(23)).view(np.float32)
+
+
+def pose_max(tiles):
+    """max |value| per lane, then over the four lane groups of the pose -> [64]"""
+    m = np.max([np.abs(t).max(axis=1) for t in tiles], axis=0)
+    return np.array([m[[(l & 15) + 16 * g for g in range(4)]].max() for l in range(64)], np.float32)
 
 
 def trunk_wave_split(feat16, stream, bias, slope):
-    inv = [float(bias[SCALE_OFF + l]) for l in range(6)]
+    inv = [np.float32(bias[SCALE_OFF + l]) for l in range(6)]
+    nrm = [np.float32(bias[NORM_OFF + i]) for i in range(9)]
     assert all(v > 0 and np.log2(v) == np.round(np.log2(v)) for v in inv), inv       # powers of two
     f = np.zeros((16, 128), np.float32)
     f[:, :126] = feat16
@@ -332,22 +343,31 @@ def trunk_wave_split(feat16, stream, bias, slope):
     for kt in range(8):
         x = np.zeros((64, 4), np.float32)
         for s in range(4):
-            x[:, s] = f[P, 16 * kt + 4 * G + s] * np.float32(XF_SCALE)
+            x[:, s] = f[P, 16 * kt + 4 * G + s]
         x0.append(x)
     st, masks, stages = PairStream(stream, ENC_PAD), {}, {}
-    true = np.float32(1.0 / XF_SCALE)
-    x2 = load_bias(bias, BIAS_OFF[1], 32)
-    run_phase_split(0, pack_blocks(x0), x2, st, bias[BIAS_OFF[0]:], masks, slope, False, inv[0])
-    x2, m2 = act_tiles(_descale(x2, inv[1]), slope)
-    stages["x2"] = decode(x2) * true
-    x4 = load_bias(bias, BIAS_OFF[3], 32)
-    run_phase_split(1, pack_blocks(x2), x4, st, bias[BIAS_OFF[2]:], masks, slope, False, inv[2])
-    x4, m4 = act_tiles(_descale(x4, inv[3]), slope)
-    stages["x4"] = decode(x4) * true
-    x6 = load_bias(bias, BIAS_OFF[5], 4)
-    run_phase_split(2, pack_blocks(x4), x6, st, bias[BIAS_OFF[4]:], masks, slope, False, inv[4])
-    x6, m6 = act_tiles(_descale(x6, inv[5]), slope)
-    stages["x6"] = decode(x6) * true
+    one = np.ones(64, np.float32)
+
+    def fwd_pair(ph, la, lb, xin, bnd, sg_in, nt_out, nrm_w, nrm_b):
+        sg_ch = pose_scale(nrm_w * bnd + nrm_b)
+        acc = [t * (sg_ch / inv[lb])[:, None] for t in load_bias(bias, BIAS_OFF[lb], nt_out)]
+        to_true = inv[la] / sg_in
+        run_phase_split(ph, pack_blocks([t * sg_in[:, None] for t in xin]), acc, st, bias[BIAS_OFF[la]:], masks, slope, False,
+                        to_true, sg_ch, one / to_true)
+        tt = inv[lb] / sg_ch
+        z = [t * tt[:, None] for t in acc]
+        return z, pose_max(acc) * tt
+
+    bnd = pose_max(x0)
+    z2, bnd2 = fwd_pair(0, 0, 1, x0, bnd, pose_scale(bnd), 32, nrm[0], nrm[3])
+    x2, m2 = act_tiles(z2, slope)
+    stages["x2"] = decode(x2)
+    z4, bnd4 = fwd_pair(1, 2, 3, x2, bnd2, pose_scale(bnd2), 32, nrm[1], nrm[4])
+    x4, m4 = act_tiles(z4, slope)
+    stages["x4"] = decode(x4)
+    z6, _ = fwd_pair(2, 4, 5, x4, bnd4, pose_scale(bnd4), 4, nrm[2], nrm[5])
+    x6, m6 = act_tiles(z6, slope)
+    stages["x6"] = decode(x6)
     w6 = load_bias(bias, W6_OFF, 4)
     part = np.zeros(64, np.float32)
     for t in range(4):
@@ -356,19 +376,26 @@ def trunk_wave_split(feat16, stream, bias, slope):
     tot = np.zeros(64, np.float32)
     for l in range(64):
         tot[l] = part[[(l & 15) + 16 * g for g in range(4)]].sum()
-    z7 = tot * true + bias[BIAS_OFF[6]]
+    z7 = tot + bias[BIAS_OFF[6]]
     d = np.maximum(z7, 0)
     gz7 = (z7 > 0).astype(np.float32)
-    # unit seed (scaled), the output derivative multiplies the result
-    g6 = dact_tiles([w6[t] * np.float32(XB_SCALE) for t in range(4)], m6, slope)
-    g4 = [np.zeros((64, 4), np.float32) for _ in range(32)]
-    run_phase_split(3, pack_blocks(g6), g4, st, None, masks, slope, True, inv[5])
-    g4 = dact_tiles(_descale(g4, inv[4]), m4, slope)
-    g2 = [np.zeros((64, 4), np.float32) for _ in range(32)]
-    run_phase_split(4, pack_blocks(g4), g2, st, None, masks, slope, True, inv[3])
-    g2 = dact_tiles(_descale(g2, inv[2]), m2, slope)
-    g0 = [np.zeros((64, 4), np.float32) for _ in range(8)]
-    run_phase_split(5, pack_blocks(g2), g0, st, None, masks, slope, True, inv[1])
+
+    def bwd_pair(ph, la, lb, gin, bnd, sg_in, nt_out, nrm_w):
+        sg_ch = pose_scale(nrm_w * bnd)
+        acc = [np.zeros((64, 4), np.float32) for _ in range(nt_out)]
+        run_phase_split(ph, pack_blocks([t * sg_in[:, None] for t in gin]), acc, st, None, masks, slope, True,
+                        inv[la] / sg_in, sg_ch, one)
+        tt = inv[lb] / sg_ch
+        return [t * tt[:, None] for t in acc], pose_max(acc) * tt
+
+    # unit seed; the output derivative multiplies the result
+    g6 = dact_tiles([w6[t].copy() for t in range(4)], m6, slope)
+    bg = pose_max(w6)
+    g4, bg4 = bwd_pair(3, 5, 4, g6, bg, pose_scale(bg), 32, nrm[6])
+    g4 = dact_tiles(g4, m4, slope)
+    g2, bg2 = bwd_pair(4, 3, 2, g4, bg4, pose_scale(bg4), 32, nrm[7])
+    g2 = dact_tiles(g2, m2, slope)
+    g0, _ = bwd_pair(5, 1, 0, g2, bg2, pose_scale(bg2), 8, nrm[8])
     assert st.pos == st.t.shape[0] - ENC_PAD, (st.pos, st.t.shape)
-    g0 = [t * np.float32(inv[0] / XB_SCALE) * gz7[:, None] for t in g0]
+    g0 = [t * gz7[:, None] for t in g0]
     return d[:16], decode(g0), stages

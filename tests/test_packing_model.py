@@ -37,7 +37,7 @@ def test_packed_blocks_layout():
     from posendf_amd import engine, synth
     sd = synth.make_weights(3)
     stream, bias = engine.pack_host(sd)
-    assert stream.size == 10720 * 256 and bias.size == 2692 + 21 * 32 + 8
+    assert stream.size == 10720 * 256 and bias.size == 2692 + 21 * 32 + 8 + 12      # + weight scales + chunk-layer norms
     # bias block
     assert np.array_equal(bias[0:256], sd["dfnet.lin0.bias"])
     assert np.array_equal(bias[2560:2624], sd["dfnet.lin5.bias"])
@@ -74,24 +74,38 @@ def test_packed_blocks_layout():
     assert abs(float((stream.astype(np.float64) ** 2).sum()) - 2 * tot) < 1e-6 * tot
 
 
-def test_split_precision_lane_model():
+@pytest.mark.parametrize("weights", ["mixed", (3, 0.5, 0.3), (2, 3.0, 0.05), "huge-lin3", "tiny-lin1"], ids=str)
+def test_split_precision_lane_model(weights):
     """f16 x 3 trunk (pndf_kernel_split.hip) modelled at lane level with the real split packer: checks the block
-    permutation, the software-pipelined stream order and -- the point of the scheme -- that three fp16 MFMAs
-    per product block keep fp32-class accuracy (vs the fp64 oracle, next to the fp32 oracle's own error)."""
+    permutation, the software-pipelined stream order, the per-pose operand scaling and -- the point of the scheme -- that
+    three fp16 MFMAs per product block keep fp32-class accuracy (vs the fp64 oracle, next to the fp32 oracle's own
+    error) whatever the magnitudes: a small-gain net (gradients ~1e-6: the fixed 2^10 gradient scale of round 1 lost the
+    lo halves there), a large-gain one, and layers scaled by 1e+4 / 1e-4 (nothing may overflow or flush)."""
     from posendf_amd import engine, synth
     import lane_model as lm
-    sd = golden_weights("mixed")
+    if isinstance(weights, tuple):
+        sd = synth.make_weights(*weights)
+    else:
+        sd = dict(golden_weights("mixed"))
+        if weights == "huge-lin3":
+            sd["dfnet.lin3.weight"] = sd["dfnet.lin3.weight"] * np.float32(1e4)
+            sd["dfnet.lin4.weight"] = sd["dfnet.lin4.weight"] * np.float32(1e-4)
+        if weights == "tiny-lin1":
+            sd["dfnet.lin1.weight"] = sd["dfnet.lin1.weight"] * np.float32(1e-4)
+            sd["dfnet.lin1.bias"] = sd["dfnet.lin1.bias"] * np.float32(1e-4)
+            sd["dfnet.lin2.weight"] = sd["dfnet.lin2.weight"] * np.float32(1e4)
     stream, bias = engine.pack_host(sd, split=True)
     q = synth.make_poses(16, seed=7, signed=True)
     dbg, dbg64 = {}, {}
     d32, _ = onp.forward_grad(q, sd, "lrelu", debug=dbg)
     d64, _ = onp.forward_grad(q, sd, "lrelu", dtype=np.float64, debug=dbg64)
     d_m, gx0_m, stages = lm.trunk_wave_split(dbg["feat"], stream, bias, 0.01)
+    assert np.isfinite(d_m).all() and np.isfinite(gx0_m).all()
     assert rel_err(stages["x4"], onp._act(dbg64["zs"][3], "lrelu", 100.0)) < 2e-5
     e_split = d_err(d_m, d64[:, 0])
     e_fp32 = d_err(d32[:, 0], d64[:, 0])
-    assert e_split < 5e-5, (e_split, e_fp32)
     g_split = rel_err(gx0_m[:, :126], dbg64["gx"][0])
     g_fp32 = rel_err(dbg["gx"][0], dbg64["gx"][0])
-    assert g_split < 5e-5, (g_split, g_fp32)
-    print("split vs fp64: d", e_split, "gx0", g_split, "| fp32 oracle vs fp64: d", e_fp32, "gx0", g_fp32)
+    print(weights, "split vs fp64: d", e_split, "gx0", g_split, "| fp32 oracle vs fp64: d", e_fp32, "gx0", g_fp32)
+    assert e_split < max(5e-5, 3 * e_fp32), (e_split, e_fp32)
+    assert g_split < max(5e-6, 3 * g_fp32), (g_split, g_fp32)

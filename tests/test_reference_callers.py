@@ -138,7 +138,7 @@ def test_forward_grad_full_size_with_grad_out():
         torch.cuda.synchronize()
         assert torch.equal(d2, d.detach()[:, 0])
         rows = rel_err_rows(dq2.cpu().numpy(), gq.cpu().numpy())
-        assert np.median(rows) < 1e-6 and np.percentile(rows, 99.9) < 1e-5
+        assert np.median(rows) < 5e-6 and np.percentile(rows, 99.9) < 5e-5     # fp32 kernel: grad_out enters at the seed
         # per-pose independence at full size: a permuted batch gives the permuted result bit for bit
         perm = torch.randperm(B, device="cuda", generator=torch.Generator("cuda").manual_seed(0))
         dq3 = torch.empty_like(dq2)
