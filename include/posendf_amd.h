@@ -9,9 +9,14 @@
  * Conventions
  *   - all tensors are contiguous fp32; poses are [B, 21, 4] = [B, 84] row-major (model/posendf.py:64),
  *     distances are [B] (the reference's [B, 1]); device pointers must be 16-byte aligned;
- *   - every call enqueues work on the caller's HIP stream (`stream` is a hipStream_t passed as void*;
- *     NULL = the default stream) and returns without synchronising;
- *   - the caller owns every buffer; the engine owns only its packed copy of the weights;
+ *   - every compute call enqueues work on the caller's HIP stream (`stream` is a hipStream_t passed as void*;
+ *     NULL = the default stream) and returns without synchronising, allocating or freeing anything (safe under
+ *     stream capture); pndf_create and pndf_load_weights allocate / synchronise;
+ *   - every entry point runs on the device of its handle (stateless helpers: of their buffers) and restores the
+ *     caller's current device before it returns;
+ *   - the caller owns every buffer; the engine owns its packed copy of the weights and, for softplus, one derivative
+ *     scratch (843 KB per compute unit, allocated by pndf_create).  Softplus launches of one handle share that scratch:
+ *     a launch on another stream than the previous one first waits (on the device) for the previous one's completion;
  *   - return value: 0 on success, a negative pndf_status otherwise; pndf_last_error() has the text;
  *   - a handle belongs to one device and must not be used from two threads at once.
  */
@@ -53,10 +58,12 @@ typedef struct {
 
 /* PNDF_PREC_FP32 : exact fp32 MFMA (v_mfma_f32_16x16x4_f32), bit-comparable to an fmaf chain.
  * PNDF_PREC_F16X3: every fp32 operand split into fp16 hi + lo, three v_mfma_f32_16x16x32_f16 per product block,
- *                  fp32 accumulate: ~2^-22 relative product error (fp32-class), ~4x the throughput.
- *                  Weights are scaled per layer by a power of two (any magnitude packs); pndf_load_weights refuses
- *                  (PNDF_ERR_UNSUPPORTED) only a trunk layer without a finite non-zero weight.  Activations must
- *                  stay below 65504 / 16, gradients below 65504 / 1024 (both travel scaled by exact powers of two).
+ *                  fp32 accumulate: ~2^-22 relative product error (fp32-class), ~3x the throughput.
+ *                  All scaling is by exact powers of two: weights per layer (any magnitude packs; pndf_load_weights
+ *                  refuses -- PNDF_ERR_UNSUPPORTED -- only a trunk layer without a finite non-zero weight), activations
+ *                  and gradients PER POSE from bounds measured on the chip or derived from the layers' norms, so that
+ *                  no operand can overflow fp16 for any finite weights and poses and none is flushed for poses whose
+ *                  gradients are tiny (small-gain networks).
  * PNDF_PREC_F16  : plain fp16 operands (round to nearest), ONE MFMA per product block, fp32 accumulate.  A measured
  *                  comparison point (BASELINE.json configs[2] "fp32 vs bf16"): ~1e-3 relative, NOT within the 1e-4
  *                  parity bar of the two modes above; never selected implicitly; relu / lrelu only. */

@@ -223,10 +223,19 @@ __device__ __forceinline__ float act_softplus(float z, float beta, float& deriv)
 // Activation parameters + where derivatives are parked between the forward and the backward pass.
 //   relu family : sign bits (chunk layers: one u16 per lane per chunk in LDS; accumulator layers: registers)
 //   softplus    : fp32 derivatives in a per-workgroup global scratch, one float4 per lane per tile ("slot")
+// The derivative scratch of a workgroup ([slot][256 lanes] float4) is addressed as ONE uniform 64-bit base (an SGPR pair)
+// + a 32-bit per-lane byte offset: `global_load/store v_off, .., s[base:base+1]`.  As per-lane 64-bit pointers (round 1)
+// the ~200 slot addresses were computed ahead, hoisted and spilled -- and every spill reload is a VMEM load whose
+// vmcnt(0) drains the ring's DMA.
+struct SpRef {
+    const char* base;   // uniform: this workgroup's block of the scratch
+    uint32_t off;       // per lane: tid * 16
+    __device__ __forceinline__ f32x4* slot(int s) const { return (f32x4*)(const_cast<char*>(base) + (uint32_t)(off + (uint32_t)s * (WG_THREADS * 16u))); }
+};
 struct ActP {
     float slope;        // relu family
     float beta;         // softplus
-    f32x4* sp;          // softplus: this thread's column of the scratch ([slot][256] float4), else null
+    SpRef sp;           // softplus: this thread's column of the scratch, else {null, 0}
     char* stage;        // softplus backward: this wave's LDS staging window for derivative tiles (its own F rows,
     int lane;           //   free between the forward trunk and the end of the backward trunk); lane id
 };
@@ -235,10 +244,11 @@ struct ActP {
 // layers' derivatives must not come in as ordinary global loads: those share the in-order vmcnt queue with the ring's
 // inline-asm DMA, which hipcc cannot see, so its own `s_waitcnt vmcnt(0)` at the point of use would drain every DMA
 // piece in flight.  The consumer waits with `vmcnt(N)`, N = number of ring pieces certainly issued in between.
-__device__ __forceinline__ void stage_derivative_tile(const f32x4* src, char* stage_tile) {
+__device__ __forceinline__ void stage_derivative_tile(const SpRef& sp, int slot, char* stage_tile) {
     // wave-uniform by construction (the wave's window); readfirstlane keeps it in an SGPR whatever hipcc infers
     const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(PNDF_LDS char*)stage_tile);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory", "m0");
+    const uint32_t off = sp.off + (uint32_t)slot * (WG_THREADS * 16u);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(sp.base), "s"(dst) : "memory", "m0");
 }
 template <int YOUNGER>
 __device__ __forceinline__ void wait_staged_derivatives() {
@@ -330,7 +340,7 @@ __device__ __forceinline__ float enc_act(f32x4& z, const ActP& ap, int spslot) {
             z[r] = act_softplus(z[r], ap.beta, dr);
             dv[r] = dr;
         }
-        ap.sp[(size_t)spslot * WG_THREADS] = dv;
+        *ap.sp.slot(spslot) = dv;
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -563,7 +573,7 @@ __device__ __forceinline__ void encoder_backward(float* my_f, float* my_gn, cons
     f32x4 D[SP ? 2 * NJ : 1];
     if constexpr (SP) {
 #pragma unroll
-        for (int i = 0; i < 2 * NJ; ++i) D[i] = ap.sp[(size_t)(SP_SLOT_ENC + i) * WG_THREADS];
+        for (int i = 0; i < 2 * NJ; ++i) D[i] = *ap.sp.slot(SP_SLOT_ENC + i);
     }
     f32x4 t[4];
     enc_tiles<0, enc_bwd_pairable(NJ - 1) ? 4 : 2>(t, ring);

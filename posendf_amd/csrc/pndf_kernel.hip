@@ -85,7 +85,7 @@ struct PhaseBody {
                     if constexpr (SP) {
 #pragma unroll
                         for (int ci = 0; ci < CT; ++ci) {
-                            f32x4* slot = ap.sp + (size_t)(spslot + c * CT + ci) * WG_THREADS;
+                            f32x4* slot = ap.sp.slot(spslot + c * CT + ci);
                             if (!BWD) {
                                 f32x4 dv;
 #pragma unroll
@@ -168,7 +168,7 @@ __device__ __forceinline__ void run_phase(const f32x4 (&xin)[KA], f32x4 (&acc)[N
 #pragma unroll
         for (int ci = 0; ci < CT; ++ci) {
             dpre[ci] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (SP && BWD) stage_derivative_tile(ap.sp + (size_t)(spslot + c * CT + ci) * WG_THREADS, ap.stage + ci * 1024);
+            if constexpr (SP && BWD) stage_derivative_tile(ap.sp, spslot + c * CT + ci, ap.stage + ci * 1024);
         }
         if constexpr (GTIME) rc->last = __builtin_amdgcn_s_memtime();
         Body::template groups<0>(xin, acc, ch, cur, ring, mask, ap, spslot, c, rc, dpre);
@@ -187,7 +187,7 @@ __device__ __forceinline__ void act_tiles(f32x4 (&x)[NT], uint32_t (&m)[(NT * 4 
                 x[t][r] = act_softplus(x[t][r], ap.beta, dr);
                 dv[r] = dr;
             }
-            ap.sp[(size_t)(spslot + t) * WG_THREADS] = dv;
+            *ap.sp.slot(spslot + t) = dv;
         }
     } else {
         constexpr int NW = (NT * 4 + 31) / 32;
@@ -220,7 +220,7 @@ __device__ __forceinline__ void dact_tiles(f32x4 (&gx)[NT], const uint32_t (&m)[
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if constexpr (SP) {
-            gx[t] = gx[t] * ap.sp[(size_t)(spslot + t) * WG_THREADS];
+            gx[t] = gx[t] * *ap.sp.slot(spslot + t);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -243,8 +243,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     ActP ap;
     ap.slope = args.slope;
     ap.beta = args.beta;
-    float* const wg_scratch = SP ? args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS : nullptr;
-    ap.sp = SP ? (f32x4*)wg_scratch + tid : nullptr;
+    ap.sp = SpRef{SP ? (const char*)(args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS) : nullptr, (uint32_t)tid * 16u};
     ap.stage = (char*)(smem + LDS_F) + wave * (16 * FSTRIDE * 4);
     ap.lane = lane;
     float* const lds_bias = (float*)(smem + LDS_BIAS);
@@ -305,7 +304,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
         if (step) ring_next_step(ring);
         if constexpr (SP) {
             asm volatile("" : "+v"(g));
-            asm volatile("" : "+v"(ap.sp));
+            asm volatile("" : "+v"(ap.sp.off));
         }
         uint32_t eb[6];
         uint32_t m2[4], m4[4], m6[1];

@@ -86,7 +86,7 @@ __device__ __forceinline__ float lrelu_bit(float z, float slope, uint32_t& m) {
 // (`to_true * oscale`, per lane) turns that into the next operand, and forward accumulators start from b s_l sigma_in.
 struct SAct {
     float slope, beta;
-    f32x4* sp;
+    SpRef sp;
     int spslot;
     float to_true;    // per lane: 1 / (s_l sigma_in): accumulator -> true pre-activation / gradient
     float oscale;     // per lane: sigma of the operand this layer produces
@@ -304,7 +304,7 @@ struct SplitPhase {
                     float dr;
                     y[ci][r] = act_softplus(fmaf(a, act.to_true, bt[ci][r]), act.beta, dr) * act.oscale;
                     bt[ci][r] = dr;                                  // the bias value is dead: its slot carries the derivative
-                    if constexpr (r == 3) act.sp[(size_t)(act.spslot + c * CT + ci) * WG_THREADS] = bt[ci];
+                    if constexpr (r == 3) *act.sp.slot(act.spslot + c * CT + ci) = bt[ci];
                 } else if constexpr (SP && BWD) {
                     if constexpr (r == 0) bt[ci] = *(const f32x4*)(act.stage + ci * 1024 + act.lane * 16);
                     y[ci][r] = (a * cf) * bt[ci][r];
@@ -361,7 +361,7 @@ struct SplitPhase {
 #pragma unroll
         for (int ci = 0; ci < CT; ++ci) {
             ch[0][ci] = f32x4{0.f, 0.f, 0.f, 0.f};      // forward: the bias joins in the epilogue (scaled like the result)
-            if constexpr (SP && BWD) stage_derivative_tile(act.sp + (size_t)(act.spslot + c * CT + ci) * WG_THREADS, act.stage + ci * 1024);
+            if constexpr (SP && BWD) stage_derivative_tile(act.sp, act.spslot + c * CT + ci, act.stage + ci * 1024);
             ch[1][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
             ch[2][ci] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -587,7 +587,7 @@ __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 
                 x[t][r] = act_softplus(x[t][r] * act.to_true, act.beta, dr) * oscale;
                 dv[r] = dr;
             }
-            act.sp[(size_t)(act.spslot + t) * WG_THREADS] = dv;
+            *act.sp.slot(act.spslot + t) = dv;
         }
 #pragma unroll
         for (int w = 0; w < NW; ++w) m[w] = 0;
@@ -620,7 +620,7 @@ __device__ __forceinline__ void dact_split_tiles(f32x4 (&gx)[NT], Blk (&out)[NT 
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if constexpr (SP) {
-            gx[t] = (gx[t] * cf) * act.sp[(size_t)(act.spslot + t) * WG_THREADS];
+            gx[t] = (gx[t] * cf) * *act.sp.slot(act.spslot + t);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -646,7 +646,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
     ActP ap;
     ap.slope = args.slope;
     ap.beta = args.beta;
-    ap.sp = SP ? (f32x4*)(args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS) + tid : nullptr;
+    ap.sp = SpRef{SP ? (const char*)(args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS) : nullptr, (uint32_t)tid * 16u};
     // uniform constants of the packer: 1 / weight scale of lin0..lin5 (powers of two) and the norms behind the a-priori
     // bounds of the chunked layers (pndf_layout.h NORM_OFF)
     auto uni = [&](int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, args.bias[i]))); };
@@ -718,7 +718,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
         if (step) ring_next_step(ring);
         if constexpr (SP) {
             asm volatile("" : "+v"(g));
-            asm volatile("" : "+v"(ap.sp));
+            asm volatile("" : "+v"(ap.sp.off));
         }
         uint32_t eb[6];
         uint32_t m2[4], m4[4], m6[1];

@@ -195,14 +195,15 @@ def test_teacher_forced_steps(torch_cuda, precision):
         q = nxt.astype(np.float32)
 
 
-@pytest.mark.parametrize("precision", PRECISIONS)
-def test_full_size_properties(torch_cuda, precision):
-    """BASELINE.json configs 2-3 size (B = 65,536): size-independent properties instead of an oracle run."""
+@pytest.mark.parametrize("act,precision", cases(["lrelu", "softplus"]))
+def test_full_size_properties(torch_cuda, act, precision):
+    """BASELINE.json configs 2-3 size (B = 65,536): size-independent properties instead of an oracle run.  Softplus runs
+    as a persistent grid (one workgroup per CU walks four 64-pose blocks and re-uses its derivative scratch)."""
     torch = torch_cuda
     from oracle import posendf_np as onp
     from posendf_amd import synth
     sd = golden_weights("live")
-    net = make_net(torch, "lrelu", sd=sd, precision=precision)
+    net = make_net(torch, act, sd=sd, precision=precision)
     B = 65536
     qn = synth.make_poses(B, seed=1234)
     q = torch.from_numpy(qn).cuda()
@@ -225,8 +226,8 @@ def test_full_size_properties(torch_cuda, precision):
     assert torch.equal(q46, q10)
     # (4) a random sample of the full-size result against the oracle
     idx = np.random.default_rng(0).choice(B, 256, replace=False)
-    q64, _ = onp.project(qn[idx], sd, steps=10, dtype=np.float64)
-    q32, _ = onp.project(qn[idx], sd, steps=10)
+    q64, _ = onp.project(qn[idx], sd, steps=10, act=act, dtype=np.float64)
+    q32, _ = onp.project(qn[idx], sd, steps=10, act=act)
     outlier_gate(rel_err_rows(q10[idx].cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project10")
     # (5) the projection decreases the predicted distance on average (it is a descent on d^2 / 2)
     d0 = net(q, train=False)["dist_pred"]
@@ -275,13 +276,13 @@ def test_debug_stages(torch_cuda):
     assert "MISMATCH" not in r.stdout and r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("precision", PRECISIONS)
-def test_side_stream_and_graph_capture(torch_cuda, precision):
+@pytest.mark.parametrize("act,precision", cases(["lrelu", "softplus"]))
+def test_side_stream_and_graph_capture(torch_cuda, act, precision):
     """The C ABI enqueues on the caller's stream and allocates nothing per call (include/posendf_amd.h conventions):
     a launch on a side stream and a hipGraph capture + replay give the same bits as the default-stream call."""
     torch = torch_cuda
     from posendf_amd import synth
-    net = make_net(torch, "lrelu", "live", precision=precision)
+    net = make_net(torch, act, "live", precision=precision)      # softplus: the derivative scratch is allocated at create
     q = torch.from_numpy(synth.make_poses(300, seed=9)).cuda()
     ref_q, ref_d = net.project(q, steps=7)
     torch.cuda.synchronize()
