@@ -39,6 +39,7 @@ extern "C" __global__ void pndf_fused_softplus_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_split_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_split_relu_kernel_timing(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_split_softplus_kernel(PndfKernelArgs args);
+extern "C" __global__ void pndf_fused_split_softplus_kernel_timing(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_half_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_half_relu_kernel_timing(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_relu_kernel_timing(PndfKernelArgs args);
@@ -151,6 +152,8 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
         e = hipFuncSetAttribute((const void*)pndf_fused_split_relu_kernel_timing, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_split_softplus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)pndf_fused_split_softplus_kernel_timing, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_half_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
@@ -441,7 +444,8 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
     if (!guard.ok) return fail(h, PNDF_ERR_HIP, "hipSetDevice failed");
     const bool softplus = h->cfg.act == PNDF_ACT_SOFTPLUS;
     if (a.noenc && dbg && !timing) return fail(h, PNDF_ERR_UNSUPPORTED, "the stage-dump kernel expects the structure encoder");
-    if (softplus && dbg) return fail(h, PNDF_ERR_UNSUPPORTED, "the debug dump exists for the relu-family kernel only");
+    if (softplus && dbg && !(timing && h->cfg.precision == PNDF_PREC_F16X3))
+        return fail(h, PNDF_ERR_UNSUPPORTED, "the debug dump exists for the relu-family kernel only");
     if (mode == MODE_PROJECT && steps == 0) {
         // zero iterations: the loop body never runs (sample_poses.py:70); poses pass through
         if (qo != q) HIP_TRY(h, hipMemcpyAsync(qo, q, (size_t)B * NQ * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -462,7 +466,9 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
         if (h->sp_pending && h->sp_stream != stream && !capturing)
             HIP_TRY(h, hipStreamWaitEvent((hipStream_t)stream, h->sp_done, 0));
         a.scratch = h->d_scratch;
-        if (h->cfg.precision == PNDF_PREC_F16X3)
+        if (timing)     // instrumented: one workgroup per block like the relu timing kernel needs B <= 64 * resident_wgs
+            hipLaunchKernelGGL(pndf_fused_split_softplus_kernel_timing, pgrid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+        else if (h->cfg.precision == PNDF_PREC_F16X3)
             hipLaunchKernelGGL(pndf_fused_split_softplus_kernel, pgrid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
         else
             hipLaunchKernelGGL(pndf_fused_softplus_kernel, pgrid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
@@ -515,6 +521,7 @@ extern "C" int pndf_debug_timing_regions(void) { return pndf_kernel_timing_regio
 extern "C" int pndf_debug_project_timing(pndf_handle h, const float* q_in, float* q_out, int64_t B, int steps,
                                          unsigned long long* cycles, void* stream) {
     if (!cycles) return fail(h, PNDF_ERR_BAD_ARG, "cycles is null");
-    if (h && h->cfg.act == PNDF_ACT_SOFTPLUS) return fail(h, PNDF_ERR_UNSUPPORTED, "timing kernel is relu-family only");
+    if (h && h->cfg.act == PNDF_ACT_SOFTPLUS && (h->cfg.precision != PNDF_PREC_F16X3 || B > (int64_t)WG_POSES * h->resident_wgs))
+        return fail(h, PNDF_ERR_UNSUPPORTED, "softplus timing kernel: f16x3 only, at most one 64-pose block per compute unit");
     return launch(h, MODE_PROJECT, q_in, nullptr, q_out, nullptr, B, steps, (float*)cycles, stream, true);
 }

@@ -82,7 +82,11 @@ struct DmaSrc {
 // M0 is declared clobbered and never restored: hipcc treats M0 as a reserved scratch register that it sets right
 // before each of its own uses (there is none in these kernels: the only M0 writes in the ISA are the ones below), so
 // saving / restoring it only costs issue slots.  Pieces 1..3 rely on M0 still holding piece 0's value.
+#ifndef PNDF_ABLATE
+#define PNDF_ABLATE 0     // timing experiments ONLY (wrong results): 1 = no mid-slot barrier, 2 = no slot fetches after the
+#endif                    // first four, 4 = no counted vmcnt wait -- what each ring event costs (profiles/r02/ablation.txt)
 __device__ __forceinline__ void ring_dma_piece(const DmaSrc& src, uint32_t dst, int j) {
+    if (PNDF_ABLATE & 2) return;
     if (j == 0)
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      : : "v"(src.off), "s"(src.base), "s"(dst) : "memory", "m0");
@@ -122,7 +126,7 @@ __device__ __forceinline__ void ring_start(Ring& r, int wave) {
     r.prev_off = 0;
 #pragma unroll
     for (int b = 0; b < RING_SLOTS - 1; ++b) {
-        ring_dma(r);
+        ring_dma(r);          // (PNDF_ABLATE & 2: the ring then keeps whatever it held -- timing only)
         r.prev_off += SLOT_BYTES;
     }
     r.cur_off = (RING_SLOTS - 1) * SLOT_BYTES;
@@ -143,8 +147,8 @@ __device__ __forceinline__ void ring_boundary(Ring& r) {
 // wave's DMA share of the next slot has landed (its own counted vmcnt above), and every read of the previous slot
 // returned long ago (its data has been consumed by MFMAs issued before this point).
 __device__ __forceinline__ void ring_midslot_sync(Ring& r) {
-    ring_wait_next_slot();
-    __builtin_amdgcn_s_barrier();
+    if (!(PNDF_ABLATE & 4)) ring_wait_next_slot();
+    if (!(PNDF_ABLATE & 1)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
 

@@ -39,7 +39,9 @@ struct PhaseBody {
 
     // groups GI .. NG-1 of one chunk; `cur` holds group GI's tiles on entry and the next chunk's group 0
     // (or garbage after the very last group) on exit.
-    template <int GI>
+    // MORE: another chunk follows (the last chunk of a phase is a separate instantiation, so that `loaded` is a
+    // compile-time constant: as a run-time condition it put a branch behind every MFMA of the chunk's last group)
+    template <int GI, bool MORE>
     static __device__ __forceinline__ void groups(const f32x4 (&xin)[KA], f32x4 (&acc)[NB], f32x4 (&ch)[CT],
                                                   f32x4 (&cur)[GT], Ring& ring, uint8_t* mask, const ActP& ap,
                                                   int spslot, int c, RegionClock* rc, const f32x4 (&dpre)[CT]) {
@@ -47,7 +49,7 @@ struct PhaseBody {
             f32x4 nxt[GT];
             constexpr int TNEXT = ((GI + 1) * GT) % CHUNK_TILES;
             constexpr bool MID = group_has_mid<GT, TNEXT>();
-            const bool loaded = (GI + 1 < NG || c + 1 < NC);
+            constexpr bool loaded = (GI + 1 < NG) || MORE;
             // The next group's tiles are read ONE PER MFMA STEP of this group (not as a burst: right after the
             // workgroup barrier all four waves would queue their reads at once with an empty MFMA pipe), the ring
             // events ride on the read they belong to (always read 0 of the group), and the slot fetch that follows
@@ -143,7 +145,7 @@ struct PhaseBody {
                 rc->grp[GI] += now - rc->last;
                 rc->last = now;
             }
-            groups<GI + 1>(xin, acc, ch, cur, ring, mask, ap, spslot, c, rc, dpre);
+            groups<GI + 1, MORE>(xin, acc, ch, cur, ring, mask, ap, spslot, c, rc, dpre);
         }
     }
 };
@@ -155,7 +157,7 @@ __device__ __forceinline__ void run_phase(const f32x4 (&xin)[KA], f32x4 (&acc)[N
     using Body = PhaseBody<KA, CT, NC, NB, BWD, SP, GTIME>;
     f32x4 cur[Body::GT];
     load_group<Body::GT, 0>(cur, ring);
-    for (int c = 0; c < NC; ++c) {
+    auto chunk = [&](int c, auto more) {
         f32x4 ch[CT];
 #pragma unroll
         for (int ci = 0; ci < CT; ++ci) {
@@ -171,8 +173,10 @@ __device__ __forceinline__ void run_phase(const f32x4 (&xin)[KA], f32x4 (&acc)[N
             if constexpr (SP && BWD) stage_derivative_tile(ap.sp, spslot + c * CT + ci, ap.stage + ci * 1024);
         }
         if constexpr (GTIME) rc->last = __builtin_amdgcn_s_memtime();
-        Body::template groups<0>(xin, acc, ch, cur, ring, mask, ap, spslot, c, rc, dpre);
-    }
+        Body::template groups<0, decltype(more)::value>(xin, acc, ch, cur, ring, mask, ap, spslot, c, rc, dpre);
+    };
+    for (int c = 0; c + 1 < NC; ++c) chunk(c, std::true_type{});
+    chunk(NC - 1, std::false_type{});
 }
 
 template <int NT, bool SP>

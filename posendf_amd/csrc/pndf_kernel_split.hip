@@ -160,6 +160,10 @@ __device__ __forceinline__ void dma_begin(DmaPieces& d, Ring& ring, bool loaded)
 // group that ran the mid-slot events (TN == 8), pieces 2, 3 in the next one (TN == 0, same phase by construction:
 // a phase starts on a slot boundary and fetches are only begun when a next group exists).  Each group sets M0 for
 // its first piece; the second one, two MFMAs later, reuses it (M0: see ring_dma_piece).
+#ifndef PNDF_GROUP_STAMPS
+#define PNDF_GROUP_STAMPS 0   // 1: the instrumented kernel also stamps every group of the (lin2,lin3) loop.  s_memtime returns
+#endif                        // through lgkmcnt, so every stamp drains the tile prefetch: the groups then take ~1,100 cycles
+                              // instead of ~270 (profiles/r02/group_stamps.txt) -- kept only as a documented dead end
 #ifndef PNDF_NT_MODE
 #define PNDF_NT_MODE 0      // cache-policy experiments: 1 = `nt` on the two big phases' slot fetches, 2 = on every slot fetch
 #endif
@@ -175,6 +179,7 @@ __device__ __forceinline__ void dma_begin(DmaPieces& d, Ring& ring, bool loaded)
         asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" POLICY : : "v"(d.src.off), "s"(d.src.base) : "memory");
 template <int TN, bool SECOND, bool BIG = false>
 __device__ __forceinline__ void dma_step(const DmaPieces& d) {
+    if (PNDF_ABLATE & 2) return;
     if constexpr (PNDF_NT_MODE == 2 || (PNDF_NT_MODE == 1 && BIG)) {
         PNDF_DMA_VARIANTS(" nt")
     } else {
@@ -208,8 +213,18 @@ __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, 
 }
 
 // ------------------------------------------------------------------ one fused layer pair, split precision
-template <int KA2, int CT, int NC, int NB, bool BWD, bool SINGLE = false, bool SP = false>
+template <int KA2, int CT, int NC, int NB, bool BWD, bool SINGLE = false, bool SP = false, bool GTIME = false>
 struct SplitPhase {
+    // GTIME (instrumented kernel only): s_memtime stamp per group of the chunk loop, accumulated in rc->grp[group]
+    static __device__ __forceinline__ void gstamp(RegionClock* rc, int group) {
+        if constexpr (GTIME) {
+            if (rc) {
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                rc->grp[group] += now - rc->last;
+                rc->last = now;
+            }
+        }
+    }
     static constexpr int CB = CT / 2;                 // k-blocks of part B per chunk
     static constexpr int AP = KA2 * CT, BP = NB * CB; // pairs per chunk
     static constexpr int AG = AP / 4, BG = BP / 4;    // groups of 4 pairs
@@ -239,7 +254,7 @@ struct SplitPhase {
     }
     template <int GA>
     static __device__ __forceinline__ void part_a(const Blk (&xin)[KA2], f32x4 (&ch)[3][CT], Pair (&cur)[4], Ring& ring,
-                                                  DmaPieces& dp) {
+                                                  DmaPieces& dp, RegionClock* rc = nullptr) {
         if constexpr (GA < AG) {
             Pair nxt[4];
             __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt(4): this group's hi tiles
@@ -247,7 +262,8 @@ struct SplitPhase {
             a_steps<GA, 0>(xin, ch, cur, nxt, ring, dp);
 #pragma unroll
             for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
-            part_a<GA + 1>(xin, ch, cur, ring, dp);
+            gstamp(rc, GA);
+            part_a<GA + 1>(xin, ch, cur, ring, dp, rc);
         }
     }
 
@@ -262,8 +278,14 @@ struct SplitPhase {
     //   steps 1 .. NV       one value each (NV = 4 CT): accumulator -> scaled operand value
     //   step NV + 1         forward: park the derivative bits
     //   steps NV + 2 ..     one hi/lo split of two values each (2 CT of them), the last one assembles the B operands
-    static constexpr int NV = 4 * CT, NS = NV + 2 + 2 * CT, EPI_SLOTS = 24;
-    static_assert(BG >= 2, "the epilogue is dealt out over two groups of part B");
+    // Slots: the MFMAs of up to eight groups of part B (softplus needs them all: ~100 cycles of quarter-rate
+    // transcendentals per value; the relu family's ~6 instructions per step just get spread thinner).
+    // Forward softplus: a value is ~16 instructions, three of them quarter-rate transcendentals (16 cycles each) -- as
+    // one block behind an MFMA it stalls the pipe for ~120 cycles, so it is cut into SUB = 8 stages of at most one
+    // transcendental or three plain instructions.
+    static constexpr int SUB = (SP && !BWD) ? 8 : 1;
+    static constexpr int NV = 4 * CT, NS = NV * SUB + 2 + 2 * CT, EPI_SLOTS = 12 * (BG < 8 ? BG : 8);
+    static_assert(BG >= 2, "the epilogue is dealt out over at least two groups of part B");
     struct Epi {
         f32x4 (&ch)[3][CT];
         Blk (&out)[CB];
@@ -276,6 +298,7 @@ struct SplitPhase {
         uint32_t bits;
         unsigned hw[2 * CT], lw[2 * CT];
         float cf, k1, k0;
+        float sz, sbz, se, su, st2, sru, slg, sd;      // forward softplus: the value in flight (act_softplus, staged)
 
         template <int S>
         __device__ __forceinline__ void step() {
@@ -295,16 +318,38 @@ struct SplitPhase {
                     k1 = (1.0f - act.slope) * cf;
                     k0 = act.slope * cf;
                 }
-            } else if constexpr (S <= NV) {
+            } else if constexpr (S <= NV * SUB) {
                 // forward relu family: from the HIGHEST value down, so that value k ends at bit k (lrelu_bit)
-                constexpr int k = (!SP && !BWD) ? NV - S : S - 1, ci = k / 4, r = k % 4;
+                constexpr int v = (S - 1) / SUB, sub = (S - 1) % SUB;
+                constexpr int k = (!SP && !BWD) ? NV - 1 - v : v, ci = k / 4, r = k % 4;
                 const float a = (PARTIALS == 3) ? (ch[0][ci][r] + ch[1][ci][r]) + ch[2][ci][r] : ch[0][ci][r];
                 if constexpr (SP && !BWD) {
-                    // softplus: fp32 derivatives parked in the per-workgroup scratch, one float4 per lane per chunk tile
-                    float dr;
-                    y[ci][r] = act_softplus(fmaf(a, act.to_true, bt[ci][r]), act.beta, dr) * act.oscale;
-                    bt[ci][r] = dr;                                  // the bias value is dead: its slot carries the derivative
-                    if constexpr (r == 3) *act.sp.slot(act.spslot + c * CT + ci) = bt[ci];
+                    // softplus = act_softplus (pndf_device.h), one stage per MFMA slot; the fp32 derivative is parked in
+                    // the per-workgroup scratch, one float4 per lane per chunk tile
+                    if constexpr (sub == 0) {
+                        sz = fmaf(a, act.to_true, bt[ci][r]);
+                        sbz = sz * act.beta;
+                    } else if constexpr (sub == 1) {
+                        se = __builtin_amdgcn_exp2f(fminf(sbz, 20.0f) * 1.44269504088896341f);
+                    } else if constexpr (sub == 2) {
+                        su = 1.0f + se;
+                        st2 = se - (su - 1.0f);
+                    } else if constexpr (sub == 3) {
+                        sru = __builtin_amdgcn_rcpf(su);
+                    } else if constexpr (sub == 4) {
+                        slg = __builtin_amdgcn_logf(su) * 0.693147180559945309f;
+                    } else if constexpr (sub == 5) {
+                        slg = fmaf(st2, sru, slg);
+                        sd = se * sru;
+                    } else if constexpr (sub == 6) {
+                        const bool lin = sbz > 20.0f;
+                        sd = lin ? 1.0f : sd;
+                        sz = lin ? sz : slg * __builtin_amdgcn_rcpf(act.beta);      // beta is uniform: hoisted
+                    } else {
+                        y[ci][r] = sz * act.oscale;
+                        bt[ci][r] = sd;                              // the bias value is dead: its slot carries the derivative
+                        if constexpr (r == 3) *act.sp.slot(act.spslot + c * CT + ci) = bt[ci];
+                    }
                 } else if constexpr (SP && BWD) {
                     if constexpr (r == 0) bt[ci] = *(const f32x4*)(act.stage + ci * 1024 + act.lane * 16);
                     y[ci][r] = (a * cf) * bt[ci][r];
@@ -314,13 +359,13 @@ struct SplitPhase {
                     // derivative factor with the accumulator -> operand scale folded in (exact powers of two apart)
                     y[ci][r] = a * fmaf((float)((bits >> k) & 1u), k1, k0);
                 }
-            } else if constexpr (S == NV + 1) {
+            } else if constexpr (S == NV * SUB + 1) {
                 if constexpr (!SP && !BWD) {
                     asm volatile("" : "+v"(bits));      // pin the chain here (see pndf_kernel.hip act_tiles)
                     store_chunk_bits<CT>(mask, c, bits);
                 }
             } else {
-                constexpr int j = S - NV - 2, t = j / 2, h = j % 2;
+                constexpr int j = S - NV * SUB - 2, t = j / 2, h = j % 2;
                 split2<SINGLE>(y[t][2 * h], y[t][2 * h + 1], hw[j], lw[j]);
                 if constexpr (S == NS - 1) {
 #pragma unroll
@@ -393,20 +438,21 @@ struct SplitPhase {
     }
     template <bool MORE, int GB>
     static __device__ __forceinline__ void part_b(const Blk (&chb)[CB], f32x4 (&acc)[NB], Pair (&cur)[4], Ring& ring,
-                                                  DmaPieces& dp, Epi& epi) {
+                                                  DmaPieces& dp, Epi& epi, RegionClock* rc = nullptr) {
         if constexpr (GB < BG) {
             Pair nxt[4];
-            if constexpr (MORE || GB + 1 < BG || true) __builtin_amdgcn_s_waitcnt(0xC47F);   // lgkmcnt(4): hi tiles of this group
+            __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt(4): hi tiles of this group
             __builtin_amdgcn_sched_barrier(0);
             b_steps<MORE, GB, 0>(chb, acc, cur, nxt, ring, dp, epi);
 #pragma unroll
             for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
-            part_b<MORE, GB + 1>(chb, acc, cur, ring, dp, epi);
+            if constexpr (MORE) gstamp(rc, AG + GB);
+            part_b<MORE, GB + 1>(chb, acc, cur, ring, dp, epi, rc);
         }
     }
 
     static __device__ __forceinline__ void run(const Blk (&xin)[KA2], f32x4 (&acc)[NB], Ring& ring, const float* biasA,
-                                               uint8_t* mask, const SAct& act, int g) {
+                                               uint8_t* mask, const SAct& act, int g, RegionClock* rc = nullptr) {
         Pair cur[4];
         load_pairs<0>(cur, ring);
         DmaPieces dp;
@@ -420,9 +466,10 @@ struct SplitPhase {
         for (int c = 0; c + 1 < NC; ++c) {
             Blk nextb[CB];
             init_chunk(ch, biasA, c + 1, g, act);
-            part_a<0>(xin, ch, cur, ring, dp);
+            if constexpr (GTIME) rc->last = __builtin_amdgcn_s_memtime();
+            part_a<0>(xin, ch, cur, ring, dp, rc);
             Epi epi{ch, nextb, mask, c + 1, act, biasA, g};
-            part_b<true, 0>(chb, acc, cur, ring, dp, epi);
+            part_b<true, 0>(chb, acc, cur, ring, dp, epi, rc);
 #pragma unroll
             for (int b = 0; b < CB; ++b) chb[b] = nextb[b];
         }
@@ -535,7 +582,7 @@ struct HalfPhase {
     }
 
     static __device__ __forceinline__ void run(const Blk (&xin)[KA2], f32x4 (&acc)[NB], Ring& ring, const float* biasA,
-                                               uint8_t* mask, const SAct& act, int g) {
+                                               uint8_t* mask, const SAct& act, int g, RegionClock* = nullptr) {
         f16x8 cur[8];
         load_half(cur, ring);
         DmaPieces dp;
@@ -560,10 +607,10 @@ struct HalfPhase {
     }
 };
 
-template <int TERMS, bool SP, int KA2, int CT, int NC, int NB, bool BWD>
-struct PhaseSel { using type = SplitPhase<KA2, CT, NC, NB, BWD, false, SP>; };
-template <int KA2, int CT, int NC, int NB, bool BWD>
-struct PhaseSel<1, false, KA2, CT, NC, NB, BWD> { using type = HalfPhase<KA2, CT, NC, NB, BWD>; };
+template <int TERMS, bool SP, int KA2, int CT, int NC, int NB, bool BWD, bool GTIME = false>
+struct PhaseSel { using type = SplitPhase<KA2, CT, NC, NB, BWD, false, SP, GTIME>; };
+template <int KA2, int CT, int NC, int NB, bool BWD, bool GTIME>
+struct PhaseSel<1, false, KA2, CT, NC, NB, BWD, GTIME> { using type = HalfPhase<KA2, CT, NC, NB, BWD>; };
 
 // Activation of an accumulator layer + split into the next phase's B operands; relu family: sign bits in registers,
 // softplus: fp32 derivatives to the scratch (slot act.spslot + tile).  The accumulators hold act.to_true^-1 x the true
@@ -768,7 +815,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
 #pragma unroll
                 for (int t = 0; t < 32; ++t) x4[t] = x4[t] * bs;
             }
-            PhaseSel<TERMS, SP, 16, 2, 32, 32, false>::type::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], 2, sg_in, sg_ch), g);
+            PhaseSel<TERMS, SP, 16, 2, 32, 32, false, TIMING && TERMS == 3 && PNDF_GROUP_STAMPS>::type::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], 2, sg_in, sg_ch), g, &rc);
             tick<TIMING>(rc, 3);
             act_split_tiles<32, SG, SP>(x4, b4, m4, layer(SP_SLOT_X4, 3, sg_ch, 0.f), 0.f, bnd, sg_in);
             tick<TIMING>(rc, 4);
@@ -911,7 +958,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
 #pragma unroll
             for (int i = 0; i < TIMING_REGIONS; ++i) out[i] = rc.acc[i];
 #pragma unroll
-            for (int i = 0; i < TIMING_GROUPS; ++i) out[TIMING_REGIONS + i] = 0;
+            for (int i = 0; i < TIMING_GROUPS; ++i) out[TIMING_REGIONS + i] = rc.grp[i];
         }
     }
 
@@ -945,6 +992,11 @@ extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_rel
 // motion_denoise.py:162-163, sample_poses.py:115): fp32 derivatives through `scratch` as in the fp32 kernel
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_softplus_kernel(PndfKernelArgs args) {
     pndf_fused_split_body<false, 3, true>(args);
+}
+
+// the same with s_memtime region stamps (performance analysis only)
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_softplus_kernel_timing(PndfKernelArgs args) {
+    pndf_fused_split_body<true, 3, true>(args);
 }
 
 // plain-fp16 kernel (precision "f16"): one MFMA per product block, operands rounded to fp16 -- a measured comparison

@@ -17,9 +17,11 @@ TILES = [0, 640, 0, 4096, 0, 576, 0, 576, 4096, 640, 0, 0]
 
 
 def main():
-    B, steps = 65536, int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
-    cfg = amass_config("lrelu", "cuda:0")
+    act = sys.argv[3] if len(sys.argv) > 3 else "lrelu"
+    B = 65536 if act != "softplus" else 16384       # softplus: persistent grid, the stamps are per workgroup (one block each)
+    cfg = amass_config(act, "cuda:0")
     cfg["engine"] = {"precision": prec}
     net = PoseNDF(cfg)
     cyc_per_tile = {"fp32": 128, "f16x3": 24, "f16": 8}[prec]   # per stream tile: 4 MFMAs x 32 cycles; 1.5 x 16; 0.5 x 16
@@ -41,11 +43,11 @@ def main():
           f"{cyc.cpu().numpy().reshape(-1, R).sum(1).mean() * rounds / (ms * 1e-3) / 1e9:.2f} GHz")
     call = cyc.cpu().numpy().reshape(-1, R).astype(np.float64) / steps
     c = call[:, :12].copy()
-    if prec == "fp32":
+    if prec in ("fp32", "f16x3"):
         c[:, 3] += call[:, 12:].sum(1)      # the per-group stamps of the (lin2,lin3) phase take their time out of region 3
     mean = c.mean(0)
     tot = mean.sum()
-    print(f"[{prec}] per wave-step: total {tot:,.0f} shader cycles; ideal MFMA {sum(TILES) * cyc_per_tile:,} ({sum(TILES) * cyc_per_tile / tot * 100:.1f} %)")
+    print(f"[{prec} {act}] per wave-step: total {tot:,.0f} shader cycles; ideal MFMA {sum(TILES) * cyc_per_tile:,} ({sum(TILES) * cyc_per_tile / tot * 100:.1f} %)")
     for n, m, t in zip(NAMES, mean, TILES):
         ideal = t * cyc_per_tile
         extra = f"  ideal {ideal:9,d}  eff {ideal / m * 100:5.1f} %  over {m - ideal:9,.0f}" if t else f"  {'':40s}"
@@ -56,6 +58,11 @@ def main():
         print("per-group cycles inside one (lin2,lin3) chunk (ideal 512; includes the s_memtime stamp itself):")
         print("  part A:", " ".join(f"{v:5.0f}" for v in grp[:16]))
         print("  part B:", " ".join(f"{v:5.0f}" for v in grp[16:]))
+    if prec == "f16x3":
+        grp = grp / 31                       # per chunk of the (lin2,lin3) loop (31 iterations; ideal = 12 MFMAs = 192 cycles)
+        print("per-group cycles inside one (lin2,lin3) chunk (ideal 192; includes the s_memtime stamp itself):")
+        print("  part A(c+1):", " ".join(f"{v:5.0f}" for v in grp[:8]))
+        print("  part B(c)  :", " ".join(f"{v:5.0f}" for v in grp[8:16]))
     print("spread over waves (min/max of total):", c.sum(1).min(), c.sum(1).max())
 
 
