@@ -206,7 +206,8 @@ __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, 
     if constexpr (J < 4) {
         if (loaded) nxt[J].h = __builtin_bit_cast(f16x8, ring_tile(ring, TN + 2 * J));
     } else if constexpr (J < 8) {
-        if (loaded) nxt[J - 4].l = __builtin_bit_cast(f16x8, ring_tile(ring, TN + 2 * (J - 4) + 1));
+        if (PNDF_ABLATE & 16) nxt[J - 4].l = nxt[J - 4].h;      // (energy-model experiment: no LDS read of the lo tiles)
+        else if (loaded) nxt[J - 4].l = __builtin_bit_cast(f16x8, ring_tile(ring, TN + 2 * (J - 4) + 1));
     } else if constexpr (J == 9 || J == 11) {
         if (TN == 0 || loaded) dma_step<TN, J == 11, BIG>(dp);
     }
@@ -245,7 +246,8 @@ struct SplitPhase {
             if constexpr (M == 8) __builtin_amdgcn_s_waitcnt(0xC87F);     // lgkmcnt(8): this group's lo tiles
             const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
             const f16x8 x = (term == 1) ? xin[kb].l : xin[kb].h;
-            ch[PARTIALS == 3 ? term : 0][ci] = mf16(w, x, ch[PARTIALS == 3 ? term : 0][ci]);
+            if (!((PNDF_ABLATE & 8) && term == 2))      // (energy-model experiment: no third term)
+                ch[PARTIALS == 3 ? term : 0][ci] = mf16(w, x, ch[PARTIALS == 3 ? term : 0][ci]);
             __builtin_amdgcn_sched_barrier(0);
             feed<TN, M, BIG>(nxt, ring, dp, true);     // part B follows, so there is always a next group
             __builtin_amdgcn_sched_barrier(0);
@@ -428,7 +430,7 @@ struct SplitPhase {
             }
             const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
             const f16x8 x = (term == 1) ? chb[b].l : chb[b].h;
-            acc[nb] = mf16(w, x, acc[nb]);
+            if (!((PNDF_ABLATE & 8) && term == 2)) acc[nb] = mf16(w, x, acc[nb]);
             __builtin_amdgcn_sched_barrier(0);
             feed<TN, M, BIG>(nxt, ring, dp, LOADED);
             if constexpr (MORE && 12 * GB + M < EPI_SLOTS) epi.template slot<12 * GB + M>();
