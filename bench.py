@@ -157,6 +157,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)                                       # does not return
 
+    # stdout carries exactly ONE line, the JSON of rank 0: libraries that print to the C stdout (RCCL announces
+    # "Librccl path : ..." there when a process group comes or goes) are sent to stderr by pointing fd 1 at fd 2 for the
+    # whole run; the JSON line is written to the saved original descriptor at the very end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     from posendf_amd import PoseNDF, amass_config, synth
@@ -354,9 +361,13 @@ def main():
             out["gpu_torch_baseline"] = gt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.act, sd, args.proj_steps, args.cpu_budget)
-        print(json.dumps(out))
+        json_line = json.dumps(out)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        os.write(json_fd, (json_line + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

@@ -49,6 +49,20 @@ def test_bench_json_line_fp32_and_softplus():
     assert d["roofline"]["kernel"] == "pndf_fused_split_softplus_kernel"
 
 
+@pytest.mark.gpu
+def test_bench_collective_path_single_rank():
+    """The N > 1 code path (process group on RCCL, barriers, all_gather_into_tensor into the preallocated buffer,
+    max-over-ranks reduction) with world size 1 -- all a one-GPU box can exercise of it."""
+    env = dict(os.environ, PNDF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", RANK="0",
+               LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4096",
+           "--proj-steps", "5", "--no-cpu-baseline", "--no-fp32-ref", "--no-gpu-torch-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+
+
 def test_bench_refuses_more_gpus_than_visible():
     """`python bench.py --gpus N` launches its own N ranks (torch.distributed.run); with fewer visible devices it must
     fail loudly instead of printing an n_gpus: 1 line for a job that was asked to be N = 8."""

@@ -66,3 +66,29 @@ def test_kernel_rejects_bad_arguments():
     noise, valid = synth.make_candidates(2, 4, seed=1)
     with pytest.raises(RuntimeError):
         calc.dist_calc(torch.from_numpy(noise).cuda(), torch.from_numpy(valid).cuda(), 4, 5)     # k > K
+
+
+@pytest.mark.gpu
+def test_fewer_finite_candidates_than_k():
+    """with NaN candidates fewer than k distances compare; the kernel must report NaN / -1 for the missing
+    ranks instead of writing through an uninitialised index."""
+    import ctypes
+    import torch
+    from posendf_amd import synth
+    from posendf_amd.engine import load_library
+    lib = load_library()
+    B, K, k = 3, 40, 5
+    noise, valid = synth.make_candidates(B, K, seed=3)
+    valid = valid.copy()
+    valid[1, 2:] = np.nan                      # query 1: only candidates 0 and 1 have a distance
+    n_t, v_t = torch.from_numpy(noise).cuda(), torch.from_numpy(valid).cuda()
+    vals = torch.empty(B, k, device="cuda")
+    idx = torch.empty(B, k, device="cuda", dtype=torch.int64)
+    rc = lib.pndf_quat_topk(n_t.data_ptr(), v_t.data_ptr(), B, K, 0, None, k, vals.data_ptr(), idx.data_ptr(),
+                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    v, i = vals.cpu().numpy(), idx.cpu().numpy()
+    assert np.isfinite(v[0]).all() and np.isfinite(v[2]).all() and (i[0] >= 0).all() and (i[2] < K).all()
+    assert sorted(i[1, :2].tolist()) == [0, 1] and np.isfinite(v[1, :2]).all()
+    assert np.isnan(v[1, 2:]).all() and (i[1, 2:] == -1).all()
