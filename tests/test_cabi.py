@@ -160,3 +160,21 @@ def test_reference_checkpoint_interchange(tmp_path):
     s1, b1 = engine.pack_host({k: v.numpy() for k, v in src.state_dict().items()})
     s2, b2 = engine.pack_host({k: v.numpy() for k, v in dst.state_dict().items()})
     assert np.array_equal(s1, s2) and np.array_equal(b1, b2)
+
+
+def test_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/posendf_amd.h must compile as C99 (no C++-isms, no torch / HIP types in
+    the signatures) and a C translation unit must be able to name every entry point."""
+    import shutil
+    import subprocess
+    from conftest import REPO
+    from posendf_amd import engine
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "use_header.c"
+    refs = "\n".join(f"    (void)&{name};" for name in engine.EXPORTS)
+    src.write_text('#include "posendf_amd.h"\nint main(void) {\n' + refs + "\n    return sizeof(pndf_config) > 0 ? 0 : 1;\n}\n")
+    r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(REPO, "include"),
+                        str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
