@@ -51,7 +51,9 @@ typedef struct {
     int32_t num_joints;     /* 21 */
     int32_t n_dims;         /* 8: in_dim, dims..., 1 */
     int32_t dims[16];       /* 126,256,512,1024,512,256,64,1 (amass.yaml:26,30); dims[0] = 84 selects the
-                               encoder-less model (model.StrEnc.use = False, model/posendf.py:40-42,73-74) */
+                               encoder-less model (model.StrEnc.use = False, model/posendf.py:40-42,73-74); hidden
+                               widths dims[1..6] may be SMALLER (the network runs zero padded on the same kernels),
+                               wider layers or another depth are refused with PNDF_ERR_UNSUPPORTED */
     int32_t parent[32];     /* net_utils.py:46 */
     int32_t precision;      /* pndf_precision: arithmetic of the trunk (engine knob, no reference counterpart) */
 } pndf_config;

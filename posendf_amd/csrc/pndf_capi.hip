@@ -103,9 +103,14 @@ static int check_config(pndf_engine* h, const pndf_config* cfg) {
     if (!cfg) return fail(h, PNDF_ERR_BAD_ARG, "cfg is null");
     if (cfg->num_joints != NJ || cfg->n_dims != NLIN + 1)
         return fail(h, PNDF_ERR_UNSUPPORTED, "only the 21-joint, 7-layer configs/amass.yaml architecture is implemented");
-    for (int i = 0; i <= NLIN; ++i)
-        if (cfg->dims[i] != DIMS[i] && !(i == 0 && cfg->dims[0] == NOENC_IN))
-            return fail(h, PNDF_ERR_UNSUPPORTED, "DFNet dims must be 126 (StrEnc.use=True) or 84 (False),256,512,1024,512,256,64,1");
+    // The kernels are laid out for configs/amass.yaml (126 | 84, 256, 512, 1024, 512, 256, 64, 1).  A DFNet of the same
+    // depth whose hidden layers are NARROWER runs on them zero-padded (padded units have zero outgoing weights, so they
+    // reach neither the distance nor its gradient, whatever the activation); anything wider or of another depth is refused.
+    if ((cfg->dims[0] != DIMS[0] && cfg->dims[0] != NOENC_IN) || cfg->dims[NLIN] != 1)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "DFNet in_dim must be 126 (StrEnc.use=True) or 84 (False), its output 1");
+    for (int i = 1; i < NLIN; ++i)
+        if (cfg->dims[i] < 1 || cfg->dims[i] > DIMS[i])
+            return fail(h, PNDF_ERR_UNSUPPORTED, "DFNet hidden widths must not exceed 256,512,1024,512,256,64 (configs/amass.yaml)");
     for (int i = 0; i < NJ; ++i)
         if (cfg->parent[i] != PARENT[i]) return fail(h, PNDF_ERR_UNSUPPORTED, "parent table must be get_parent_mapping('smpl')");
     if (cfg->act != PNDF_ACT_RELU && cfg->act != PNDF_ACT_LRELU && cfg->act != PNDF_ACT_SOFTPLUS)
@@ -236,9 +241,15 @@ void emit_enc_tile(const EncMat& m, float* dst) {
 // in_dim of the trunk: 126 with the structure encoder, 84 = 21 x 4 without it (model.StrEnc.use = False, reference
 // model/posendf.py:40-42,73-74: DFNet sees the normalised quaternions, `p.reshape(len(p), -1)` net_modules.py:49)
 static bool table_has_encoder(int n) { return n == 4 * NJ + 2 * NLIN; }
-static int lin_in(int l, bool enc) { return (l == 0 && !enc) ? NOENC_IN : DIMS[l]; }
 
-static const char* check_tensors(const float* const* tensors, const int64_t* numel, int n) {
+// widths of the DFNet in a state-dict table: dims[0] = in_dim (126 | 84), dims[l + 1] = rows of dfnet.lin{l}
+struct NetDims {
+    int d[NLIN + 1];
+    int in(int l) const { return d[l]; }
+    int out(int l) const { return d[l + 1]; }
+};
+
+static const char* check_tensors(const float* const* tensors, const int64_t* numel, int n, NetDims* dims_out = nullptr) {
     if (!tensors || !numel) return "tensors / numel is null";
     if (n != 4 * NJ + 2 * NLIN && n != 2 * NLIN)
         return "expected 98 tensors (encoder + dfnet) or 14 (dfnet only, StrEnc.use = False) in state-dict order";
@@ -249,25 +260,31 @@ static const char* check_tensors(const float* const* tensors, const int64_t* num
         for (int k = 0; k < 4; ++k, ++t)
             if (!tensors[t] || numel[t] != want[k]) return "encoder tensor missing or of the wrong size";
     }
-    for (int l = 0; l < NLIN; ++l) {
-        if (!tensors[t] || numel[t] != (int64_t)DIMS[l + 1] * lin_in(l, enc)) return "dfnet weight missing or of the wrong size";
-        ++t;
-        if (!tensors[t] || numel[t] != DIMS[l + 1]) return "dfnet bias missing or of the wrong size";
-        ++t;
+    NetDims nd;
+    nd.d[0] = enc ? DIMS[0] : NOENC_IN;
+    for (int l = 0; l < NLIN; ++l) {             // the bias lengths are the layer widths
+        const int64_t out = numel[t + 2 * l + 1];
+        if (!tensors[t + 2 * l] || !tensors[t + 2 * l + 1] || out < 1 || out > DIMS[l + 1] || (l == NLIN - 1 && out != 1))
+            return "dfnet tensor missing, or a layer wider than the configs/amass.yaml architecture (256,512,1024,512,256,64,1)";
+        nd.d[l + 1] = (int)out;
     }
+    for (int l = 0; l < NLIN; ++l)
+        if (numel[t + 2 * l] != (int64_t)nd.out(l) * nd.in(l)) return "dfnet weight of the wrong size";
+    if (dims_out) *dims_out = nd;
     return nullptr;
 }
 
 extern "C" int pndf_pack_host(const float* const* tensors, const int64_t* numel, int n_tensors, float* stream,
                               float* bias) {
-    if (check_tensors(tensors, numel, n_tensors) || !stream || !bias) return PNDF_ERR_BAD_SHAPE;
+    NetDims nd;
+    if (check_tensors(tensors, numel, n_tensors, &nd) || !stream || !bias) return PNDF_ERR_BAD_SHAPE;
     // ---- bias block: b0..b5 | w6 | b6 | per joint: b1 padded to 16, b2 on rows 4..9 of 16
     memset(bias, 0, BIAS_FLOATS * sizeof(float));
     for (int l = 0; l < 8; ++l) bias[SCALE_OFF + l] = 1.0f;
     const bool enc = table_has_encoder(n_tensors);     // without the encoder its tiles / biases stay zero (skipped on chip)
     const float* const* lin = tensors + (enc ? 4 * NJ : 0);
-    for (int l = 0; l < NLIN - 1; ++l) memcpy(bias + BIAS_OFF[l], lin[2 * l + 1], sizeof(float) * DIMS[l + 1]);
-    memcpy(bias + W6_OFF, lin[2 * (NLIN - 1)], sizeof(float) * DIMS[NLIN - 1]);
+    for (int l = 0; l < NLIN - 1; ++l) memcpy(bias + BIAS_OFF[l], lin[2 * l + 1], sizeof(float) * nd.out(l));   // narrower layers: zero padded
+    memcpy(bias + W6_OFF, lin[2 * (NLIN - 1)], sizeof(float) * nd.in(NLIN - 1));
     bias[BIAS_OFF[NLIN - 1]] = lin[2 * (NLIN - 1) + 1][0];
     for (int j = 0; enc && j < NJ; ++j) {
         memcpy(bias + ENCB_OFF + 32 * j, tensors[4 * j + 1], sizeof(float) * HID);
@@ -283,8 +300,8 @@ extern "C" int pndf_pack_host(const float* const* tensors, const int64_t* numel,
     dst = stream + (size_t)ENC_TILES_PADDED * TILE_FLOATS;
     for (int ph = 0; ph < 6; ++ph) {
         const Phase& P = PHASES[ph];
-        const Mat A{lin[2 * P.a_lin], DIMS[P.a_lin + 1], lin_in(P.a_lin, enc), P.transposed};
-        const Mat B{lin[2 * P.b_lin], DIMS[P.b_lin + 1], lin_in(P.b_lin, enc), P.transposed};
+        const Mat A{lin[2 * P.a_lin], nd.out(P.a_lin), nd.in(P.a_lin), P.transposed};
+        const Mat B{lin[2 * P.b_lin], nd.out(P.b_lin), nd.in(P.b_lin), P.transposed};
         for (int c = 0; c < P.NC; ++c) {
             for (int kt = 0; kt < P.KA; ++kt)                       // part A: (kt, ci)
                 for (int ci = 0; ci < P.CT; ++ci, dst += TILE_FLOATS) emit_tile(A, c * P.CT + ci, kt, dst);
@@ -329,6 +346,8 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
     // biases and encoder tiles are identical to the fp32 stream (the encoder stays on fp32 MFMA)
     int rc = pndf_pack_host(tensors, numel, n_tensors, stream, bias);
     if (rc != PNDF_OK) return rc;
+    NetDims nd;
+    (void)check_tensors(tensors, numel, n_tensors, &nd);
     const bool enc = table_has_encoder(n_tensors);
     const float* const* lin = tensors + (enc ? 4 * NJ : 0);
     // per-layer weight scale; a layer without a finite non-zero weight cannot be scaled: refused (-> fp32 kernel)
@@ -336,7 +355,7 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
     for (int l = 0; l < 6; ++l) {
         float mx = 0.f;
         bool nan = false;
-        const int64_t n = (int64_t)DIMS[l + 1] * lin_in(l, enc);
+        const int64_t n = (int64_t)nd.out(l) * nd.in(l);
         for (int64_t i = 0; i < n; ++i) {
             const float a = std::fabs(lin[2 * l][i]);
             nan |= (a != a);
@@ -352,7 +371,7 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
     auto up = [](double v) { return std::nextafter((float)v, INFINITY); };
     for (int k = 0; k < 3; ++k) {
         const int lf = 2 * k, lb = 5 - 2 * k;           // forward chunk layers 0, 2, 4; backward chunk layers 5, 3, 1
-        const int inf = lin_in(lf, enc), outf = DIMS[lf + 1];
+        const int inf = nd.in(lf), outf = nd.out(lf);
         double rowmax = 0.0, bmax = 0.0;
         for (int o = 0; o < outf; ++o) {
             double sum = 0.0;
@@ -360,7 +379,7 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
             rowmax = std::max(rowmax, sum);
             bmax = std::max(bmax, std::fabs((double)lin[2 * lf + 1][o]));
         }
-        const int inb = lin_in(lb, enc), outb = DIMS[lb + 1];
+        const int inb = nd.in(lb), outb = nd.out(lb);
         double colmax = 0.0;
         for (int i = 0; i < inb; ++i) {
             double sum = 0.0;
@@ -374,8 +393,8 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
     float* dst = stream + (size_t)ENC_TILES_PADDED * TILE_FLOATS;
     for (int ph = 0; ph < 6; ++ph) {
         const Phase& P = PHASES[ph];
-        const Mat A{lin[2 * P.a_lin], DIMS[P.a_lin + 1], lin_in(P.a_lin, enc), P.transposed};
-        const Mat B{lin[2 * P.b_lin], DIMS[P.b_lin + 1], lin_in(P.b_lin, enc), P.transposed};
+        const Mat A{lin[2 * P.a_lin], nd.out(P.a_lin), nd.in(P.a_lin), P.transposed};
+        const Mat B{lin[2 * P.b_lin], nd.out(P.b_lin), nd.in(P.b_lin), P.transposed};
         auto partA = [&](int c) {
             for (int kb = 0; kb < P.KA / 2; ++kb)
                 for (int ci = 0; ci < P.CT; ++ci, dst += 2 * TILE_FLOATS) emit_pair(A, c * P.CT + ci, kb, dst, wscale[P.a_lin]);
@@ -396,9 +415,12 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
 
 extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, const int64_t* numel, int n_tensors) {
     if (!h) return PNDF_ERR_BAD_ARG;
-    if (const char* why = check_tensors(tensors, numel, n_tensors)) return fail(h, PNDF_ERR_BAD_SHAPE, why);
+    NetDims nd;
+    if (const char* why = check_tensors(tensors, numel, n_tensors, &nd)) return fail(h, PNDF_ERR_BAD_SHAPE, why);
     if (table_has_encoder(n_tensors) != (h->cfg.dims[0] == DIMS[0]))
         return fail(h, PNDF_ERR_BAD_SHAPE, "tensor table does not match the configured in_dim (98 tensors for 126, 14 for 84)");
+    for (int i = 0; i <= NLIN; ++i)
+        if (nd.d[i] != h->cfg.dims[i]) return fail(h, PNDF_ERR_BAD_SHAPE, "dfnet tensor shapes do not match the configured dims");
     std::vector<float> stream((size_t)STEP_TILES * TILE_FLOATS), bias(BIAS_FLOATS);
     const int prc = (h->cfg.precision != PNDF_PREC_FP32)
                         ? pndf_pack_host_split(tensors, numel, n_tensors, stream.data(), bias.data())

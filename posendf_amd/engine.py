@@ -117,7 +117,7 @@ class Engine:
     """One engine per device.  All compute methods take raw device pointers and a stream handle."""
 
     def __init__(self, act: str = "lrelu", beta: float = 100.0, device: int = 0, lib=None, precision: str = "fp32",
-                 encoder: bool = True):
+                 encoder: bool = True, hidden=None):
         self.lib = lib or load_library()
         if act not in ACT_CODES:
             raise PndfError(f"unknown activation {act!r}")
@@ -128,6 +128,12 @@ class Engine:
         cfg.precision = PRECISION_CODES[precision]
         if not encoder:
             cfg.dims[0] = 84          # model.StrEnc.use = False: DFNet on the 21 x 4 normalised quaternions
+        if hidden is not None:        # model.DFNet.dims: hidden widths narrower than configs/amass.yaml run zero padded
+            hidden = [int(w) for w in hidden]
+            if len(hidden) != 6:
+                raise PndfError(f"DFNet with {len(hidden)} hidden layers: the kernels implement the 6 of configs/amass.yaml")
+            for i, w in enumerate(hidden):
+                cfg.dims[i + 1] = w
         self.precision = precision
         self.handle = c_void_p()
         rc = self.lib.pndf_create(ctypes.byref(self.handle), ctypes.byref(cfg), int(device))

@@ -81,6 +81,7 @@ class PoseNDF(nn.Module):
         self._beta = float(opt["model"]["DFNet"].get("beta", 100.0))
         if self.enc is not None and opt["model"]["StrEnc"]["act"] != self._act:
             raise PndfError("StrEnc.act and DFNet.act differ; the fused kernel uses one activation family")
+        self._hidden = list(opt["model"]["DFNet"]["dims"])       # net_modules.py:14-28; narrower than amass.yaml: zero padded
         self._engines = {}          # device index -> (Engine, weight fingerprint)
 
     # ---- nn.Module conveniences the reference callers rely on -----------------------------------
@@ -102,7 +103,7 @@ class PoseNDF(nn.Module):
             # the plain-f16 comparison kernel is relu-family only; fp32 and f16x3 implement all three activations
             prec = "fp32" if (self._act == "softplus" and self._precision == "f16") else self._precision
             entry = [Engine(self._act, self._beta, idx, precision="f16x3" if prec == "auto" else prec,
-                            encoder=self.enc is not None), None]
+                            encoder=self.enc is not None, hidden=self._hidden), None]
             self._engines[idx] = entry
         if entry[1] != fp:          # first use, load_state_dict, optimiser step, .to(): re-pack the weights
             sd = self.state_dict()
@@ -114,7 +115,8 @@ class PoseNDF(nn.Module):
                     raise
                 # both are HIP kernels: this is a choice of arithmetic, not a fallback off the engine
                 warnings.warn(f"posendf_amd: {e}; precision 'auto' selects the exact fp32 kernel for this network")
-                entry[0] = Engine(self._act, self._beta, idx, precision="fp32", encoder=self.enc is not None)
+                entry[0] = Engine(self._act, self._beta, idx, precision="fp32", encoder=self.enc is not None,
+                                  hidden=self._hidden)
                 entry[0].load_weights(weights)
             entry[1] = fp
         return entry[0]

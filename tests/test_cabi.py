@@ -54,8 +54,17 @@ def test_create_rejects_unsupported(lib):
     assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -4
     lib.pndf_default_config(ctypes.byref(cfg), 1, 100.0)
     assert cfg.precision == 0
-    cfg.dims[2] = 384                                               # other architecture
+    cfg.dims[2] = 640                                               # wider than the kernels' layout
     assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -4
+    cfg.dims[2] = 512
+    cfg.n_dims = 7                                                  # another depth
+    assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -4
+    cfg.n_dims = 8
+    cfg.dims[2] = 384                                               # narrower: accepted (runs zero padded) -- the
+    assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) in (0, -6)    # next hurdle is the device
+    if h.value:
+        lib.pndf_destroy(h)
+        h = ctypes.c_void_p()
     cfg.dims[2] = 512
     cfg.parent[3] = 0
     assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -4

@@ -254,7 +254,10 @@ def test_weight_reload_and_errors(torch_cuda):
     d_c = net(q, train=False)["dist_pred"]
     assert torch.allclose(d_c, d_b + 1.0, atol=1e-5)
     cfg = amass_config("lrelu", "cuda:0")
-    cfg["model"]["DFNet"]["dims"] = [256, 512, 768, 512, 256, 64]      # another architecture: loud failure
+    cfg["model"]["DFNet"]["dims"] = [256, 512, 2048, 512, 256, 64]     # wider than the kernels' layout: loud failure
+    with pytest.raises(PndfError):
+        PoseNDF(cfg)(q, train=False)
+    cfg["model"]["DFNet"]["dims"] = [256, 512, 1024, 512, 256]         # another depth: loud failure
     with pytest.raises(PndfError):
         PoseNDF(cfg)(q, train=False)
     with pytest.raises(RuntimeError):                      # no double backward on the engine path
@@ -418,3 +421,32 @@ def test_precision_auto_selects_by_weight_range(torch_cuda):
     d_o, _ = onp.forward_grad(q.cpu().numpy(), {k: v.numpy() for k, v in tiny.items()}, "lrelu")
     assert d_err(d2.detach().cpu().numpy().ravel(), d_o.ravel()) < TOL
     assert torch.isfinite(d).all()
+
+
+@pytest.mark.parametrize("act,precision", cases(["lrelu", "softplus"]))
+def test_narrower_architecture_runs_zero_padded(torch_cuda, act, precision):
+    """reference net_modules.py:14-28 builds DFNet from `dims`: a network of the amass.yaml depth with NARROWER hidden layers
+    runs on the same kernels zero padded (the padded units have zero outgoing weights: they reach neither d nor its
+    gradient -- also for softplus, whose padded units output ln 2 / beta)."""
+    torch = torch_cuda
+    from oracle import posendf_np as onp
+    from posendf_amd import PoseNDF, amass_config, synth
+    hidden = [192, 384, 700, 300, 200, 48]
+    sd = synth.make_weights(5, 2.0, 0.1, dims=(126, *hidden, 1))
+    cfg = amass_config(act, "cuda:0")
+    cfg["model"]["DFNet"]["dims"] = hidden
+    cfg["engine"] = {"precision": precision}
+    net = PoseNDF(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    qn = synth.make_poses(300, seed=41, signed=True)
+    q = torch.from_numpy(qn).cuda().requires_grad_(True)
+    d = net(q, train=False)["dist_pred"]
+    (dq,) = torch.autograd.grad(d.sum(), q)
+    sig_d, sig_g, d64, g64 = fp32_noise(qn, sd, act)
+    pose_gate(d_rows(d.detach().cpu().numpy(), d64), sig_d, "d")
+    pose_gate(rel_err_rows(dq.cpu().numpy(), g64), sig_g, "dq", exempt=kink_exempt(qn, sd, act))
+    qp, _ = net.project(q.detach(), steps=5)
+    q64, _ = onp.project(qn, sd, steps=5, act=act, dtype=np.float64)
+    q32, _ = onp.project(qn, sd, steps=5, act=act)
+    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project5")
