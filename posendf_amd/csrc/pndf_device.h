@@ -64,6 +64,8 @@ struct Ring {
     uint32_t prev_off;     // uniform: buffer of the previous slot = the one the mid-slot fetch refills
     uint32_t dst_base;     // uniform: LDS address of this wave's 4 KiB window of buffer 0
     int lane;
+    uint32_t nfetch;       // (PNDF_ABLATE & 32 only) uniform: fetches issued so far in this step
+    uint32_t lane_off;     // (PNDF_ABLATE & 32 only) per lane: this lane's byte offset inside a slot
 };
 
 // LDS-DMA of one 16 KiB slot: each wave moves 4 tiles (global_load_lds_dwordx4 = 1 KiB per instruction,
@@ -84,7 +86,10 @@ struct DmaSrc {
 // saving / restoring it only costs issue slots.  Pieces 1..3 rely on M0 still holding piece 0's value.
 #ifndef PNDF_ABLATE
 #define PNDF_ABLATE 0     // timing experiments ONLY (wrong results): 1 = no mid-slot barrier, 2 = no slot fetches after the
-#endif                    // first four, 4 = no counted vmcnt wait -- what each ring event costs (profiles/r02/ablation.txt)
+#endif                    // first four, 4 = no counted vmcnt wait -- what each ring event costs (profiles/r02/ablation.txt);
+                          // 32 = the backward half of a step walks the forward half's slots in reverse (L2 reuse experiment;
+                          // +64 = its control arm, -DPNDF_WRAP_SLOTS=N = wrapped footprint), 256 / 512 = every tile read /
+                          // slot fetch of the split kernel issued twice (profiles/r02/ab_mirror_walk.txt, ab_additive.txt)
 __device__ __forceinline__ void ring_dma_piece(const DmaSrc& src, uint32_t dst, int j) {
     if (PNDF_ABLATE & 2) return;
     if (j == 0)
@@ -100,6 +105,18 @@ __device__ __forceinline__ void ring_dma_piece(const DmaSrc& src, uint32_t dst, 
 
 // source / destination of this wave's share of the next slot to fetch (into the buffer of the previous slot)
 __device__ __forceinline__ void ring_dma_begin(Ring& r, DmaSrc& src, uint32_t& dst) {
+    if (PNDF_ABLATE & 32) {   // (L2 experiment: the backward half of a step re-reads the forward half's slots in reverse)
+        const uint32_t k = r.nfetch;
+        uint32_t zero;        // (PNDF_ABLATE & 64: control arm -- the same instructions, but the ordinary forward walk)
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+#ifdef PNDF_WRAP_SLOTS     // (footprint experiment: the walk wraps after PNDF_WRAP_SLOTS slots, a power of two)
+        const uint32_t s = (k + zero) & (uint32_t)(PNDF_WRAP_SLOTS - 1);
+#else
+        const uint32_t s = k < (uint32_t)FWD_SLOTS ? k : (PNDF_ABLATE & 64) ? zero + k : (uint32_t)STEP_SLOTS - 1 - k;
+#endif
+        r.nfetch = (k + 1 == (uint32_t)STEP_SLOTS) ? 0u : k + 1;
+        r.fetch_off = r.lane_off + s * SLOT_BYTES - SLOT_BYTES;
+    }
     r.fetch_off += SLOT_BYTES;
     src.base = r.gstream;
     src.off = r.fetch_off;
@@ -123,6 +140,8 @@ __device__ __forceinline__ void ring_wait_next_slot() { asm volatile("s_waitcnt 
 __device__ __forceinline__ void ring_start(Ring& r, int wave) {
     r.dst_base = (uint32_t)(size_t)(PNDF_LDS char*)(r.smem + LDS_RING) + wave * (4 * TILE_BYTES);
     r.fetch_off = wave * (4 * TILE_BYTES) + r.lane * 16 - SLOT_BYTES;
+    r.nfetch = 0;
+    r.lane_off = wave * (4 * TILE_BYTES) + r.lane * 16;
     r.prev_off = 0;
 #pragma unroll
     for (int b = 0; b < RING_SLOTS - 1; ++b) {

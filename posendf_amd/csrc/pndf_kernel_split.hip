@@ -184,6 +184,9 @@ __device__ __forceinline__ void dma_step(const DmaPieces& d) {
         PNDF_DMA_VARIANTS(" nt")
     } else {
         PNDF_DMA_VARIANTS("")
+        if constexpr ((PNDF_ABLATE & 512) != 0) {          // (additive energy experiment: every slot fetch issued twice)
+            PNDF_DMA_VARIANTS("")
+        }
     }
 }
 
@@ -201,6 +204,12 @@ __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, 
             if constexpr (TN == 0) ring_boundary(ring);
             if constexpr (TN == SLOT_TILES / 2) ring_midslot_sync(ring);
             dma_begin<TN>(dp, ring, true);
+        }
+    }
+    if constexpr (J < 8 && (PNDF_ABLATE & 256) != 0) {      // (additive energy experiment: every tile read issued twice)
+        if (loaded) {
+            const f32x4 dup = ring_tile(ring, TN + (J < 4 ? 2 * J : 2 * (J - 4) + 1));
+            asm volatile("" : : "v"(dup));
         }
     }
     if constexpr (J < 4) {
