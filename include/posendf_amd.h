@@ -16,7 +16,9 @@
  *     caller's current device before it returns;
  *   - the caller owns every buffer; the engine owns its packed copy of the weights and, for softplus, one derivative
  *     scratch (843 KB per compute unit, allocated by pndf_create).  Softplus launches of one handle share that scratch:
- *     a launch on another stream than the previous one first waits (on the device) for the previous one's completion;
+ *     a launch on another stream than the previous one first waits (on the device) for the previous one's completion.
+ *     Launches recorded during stream capture are not tracked that way: replays of a captured softplus launch must be
+ *     ordered by the caller against other launches of the same handle (use one handle per concurrently replayed graph);
  *   - return value: 0 on success, a negative pndf_status otherwise; pndf_last_error() has the text;
  *   - a handle belongs to one device and must not be used from two threads at once.
  */
