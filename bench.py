@@ -271,9 +271,26 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / 5
 
+    # The boundary takes device pointers; a caller that holds HOST tensors (the facade accepts them, posendf.py:64) pays
+    # the PCIe copies on top: pinned host -> device, project, device -> pinned host.  Reported beside `value`, never as it.
+    def host_boundary_ms():
+        qh = q0.cpu().pin_memory()
+        oh = torch.empty_like(qh).pin_memory()
+        ms = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            qd = qh.to(dev, non_blocking=True)
+            qo, _ = net.project(qd, steps=args.proj_steps)
+            oh.copy_(qo, non_blocking=True)
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t) * 1e3)
+        return sorted(ms)[1]
+
     side = world == 1 and not args.no_fp32_ref      # the side runs belong to the N = 1 line; scaling runs stay short
-    fwd_grad = None
+    fwd_grad = host_ms = None
     if side:
+        host_ms = host_boundary_ms()
         ms1 = fwd_grad_ms(net)
         fwd_grad = {"workload": f"BASELINE.json configs[1]: one forward + d d/d q launch, batch={B}", "precision": precision,
                     "ms": ms1, "pose_steps_per_s": B / (ms1 * 1e-3),
@@ -343,8 +360,12 @@ def main():
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)",
                          "algorithmic_bytes_per_launch": B * 676 + 10720 * 1024,
                          "kernel": kname, "kernel_ms": kern_ms,
+                         "kernel_ms_median": float(np.median([a.elapsed_time(b) for a, b in ev])) if args.steps else None,
                          "algorithmic_flop_per_launch": B * args.proj_steps * FLOP_PER_POSE_STEP},
         }
+        if host_ms is not None:
+            out["host_boundary"] = {"what": "pinned host poses -> device, project(), device -> pinned host (median of 3)",
+                                    "ms": host_ms, "poses_per_s": B / (host_ms * 1e-3)}
         if fwd_grad is not None:
             out["forward_grad_single_launch"] = fwd_grad
         if fp32_ref is not None:

@@ -37,6 +37,9 @@ def test_bench_json_line_default_precision():
     assert {"cpu", "runs_s", "config0_forward_only"} <= set(cb) and cb["config0_forward_only"]["poses_per_s"] > 0
     assert "fp32_exact" in d and "f16_single" in d and "forward_grad_single_launch" in d
     assert d["softplus"]["kernel"] == "pndf_fused_split_softplus_kernel" and d["softplus"]["kernel_ms"] > 0
+    hb = d["host_boundary"]                       # PCIe-inclusive rate of a host-tensor caller: reported, never `value`
+    assert hb["ms"] > d["roofline"]["kernel_ms"] and 0 < hb["poses_per_s"] < d["value"] * 1.02
+    assert d["roofline"]["kernel_ms_median"] > 0
     gt = d["gpu_torch_baseline"]                  # the denominator of north_star's ">= 10x", measured in the same run
     assert gt["value"] > 0 and abs(gt["speedup_of_value"] - d["value"] / gt["value"]) < 1e-9
 

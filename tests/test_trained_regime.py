@@ -1,0 +1,128 @@
+"""A TRAINED network as a parity regime (tests/golden/trained_<act>.npz, make_golden_trained.py): the imported reference
+trained its own DFNet -- built narrower than configs/amass.yaml through `model.DFNet.dims`, net_modules.py:14-28 -- on a
+synthetic pose manifold, and then produced d, dd/dq, the autograd contract and 1/10-step projections in fp32 and fp64.
+Every other golden file holds random-init weights of the amass.yaml widths.
+
+CPU part: the numpy oracle against those vectors (pins the oracle on a narrower, trained network).
+GPU part: both kernels through the facade / C ABI against them, with the per-pose gates of conftest.py."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, d_rows, fp32_noise, outlier_gate, pose_gate, rel_err_rows
+
+ACTS = ("lrelu", "softplus")
+TOL = 1e-4
+EDGE = {92: "zero component column (eps clamp of F.normalize)", 93: "tiny pose (scale invariance)",
+        94: "all joints equal", 95: "one zero quaternion"}            # make_golden_trained.py:one
+
+
+def load(act):
+    g = dict(np.load(os.path.join(GOLDEN, f"trained_{act}.npz")))
+    sd = {k[3:]: v.astype(np.float32) for k, v in g.items() if k.startswith("w::")}      # fp16 on disk = the checkpoint
+    return g, sd, [int(h) for h in g["hidden"]]
+
+
+@pytest.mark.parametrize("act", ACTS)
+def test_trained_network_means_something(act):
+    """the fixture is a trained distance field, not noise: near the manifold the prediction follows the label"""
+    g, sd, hidden = load(act)
+    assert [sd[f"dfnet.lin{l}.weight"].shape[0] for l in range(6)] == hidden and len(sd) == 98
+    d = g["d_f32"][:48, 0]
+    assert np.corrcoef(g["label_near"], d)[0, 1] > 0.7
+    assert abs(d.mean() - g["label_near"].mean()) < 0.03
+    assert g["dtrace_f32"][-1].mean() < 0.9 * g["dtrace_f32"][0].mean()      # projection steps walk towards the manifold
+
+
+@pytest.mark.parametrize("act", ACTS)
+def test_oracle_matches_reference_on_trained_network(act):
+    from oracle import posendf_np as onp
+    g, sd, _ = load(act)
+    d64, g64 = onp.forward_grad(g["q"], sd, act, dtype=np.float64)
+    assert np.abs(d64 - g["d_f64"].reshape(d64.shape)).max() < 1e-12
+    ok = np.ones(len(g["q"]), bool)
+    ok[92] = False                                  # eps-clamp pose: gradient ~1e10, compared relatively below
+    assert np.abs(g64.reshape(len(ok), -1)[ok] - g["dq_f64"].reshape(len(ok), -1)[ok]).max() < 1e-10
+    assert rel_err_rows(g64, g["dq_f64"]).max() < 1e-9
+    d32, g32 = onp.forward_grad(g["q"], sd, act, dtype=np.float32)
+    # fp32 oracle vs the reference's fp32 run: both within fp32 rounding of the fp64 truth
+    assert np.median(d_rows(d32, g["d_f64"])) < 2e-6 and np.median(d_rows(g["d_f32"], g["d_f64"])) < 2e-6
+    q10, _, trace = onp.project(g["q"], sd, steps=10, act=act, dtype=np.float64, trace=True)
+    assert rel_err_rows(q10, g["q10_f64"]).max() < 1e-6          # kink-free in fp64 on both sides
+    assert np.abs(np.asarray(trace) - g["dtrace_f64"]).max() < 1e-9
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (no CPU fallback exists)")
+    return torch
+
+
+def make_net(torch, act, sd, hidden, precision):
+    from posendf_amd import PoseNDF, amass_config
+    cfg = amass_config(act, "cuda:0")
+    cfg["model"]["DFNet"]["dims"] = hidden
+    cfg["engine"] = {"precision": precision}
+    net = PoseNDF(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    return net
+
+
+def kink_exempt(q, sd, act):
+    from oracle import posendf_np as onp
+    return None if act == "softplus" else onp.kink_margin(q, sd, act) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("act", ACTS)
+def test_trained_single_step(torch_cuda, act, precision):
+    torch = torch_cuda
+    g, sd, hidden = load(act)
+    net = make_net(torch, act, sd, hidden, precision)
+    q = torch.from_numpy(g["q"]).cuda().requires_grad_(True)
+    d = net(q, train=False)["dist_pred"]
+    (dq,) = torch.autograd.grad(d, q, grad_outputs=torch.ones_like(d))
+    d_np, dq_np = d.detach().cpu().numpy(), dq.cpu().numpy()
+    sig_d, sig_g, _, _ = fp32_noise(g["q"], sd, act, extra_d=[d_rows(g["d_f32"], g["d_f64"])],
+                                    extra_g=[rel_err_rows(g["dq_f32"], g["dq_f64"])])
+    e_d, e_g = d_rows(d_np, g["d_f64"]), rel_err_rows(dq_np, g["dq_f64"])
+    ex = kink_exempt(g["q"], sd, act)
+    pose_gate(e_d, sig_d, "d")
+    pose_gate(e_g, sig_g, "dq", exempt=ex)
+    for i, name in EDGE.items():
+        assert e_d[i] <= 8 * sig_d[i] + 8e-6, (name, "d", e_d[i], sig_d[i])
+        assert e_g[i] <= 8 * sig_g[i] + 8e-6 or (ex is not None and ex[i]), (name, "dq", e_g[i], sig_g[i])
+        assert np.isfinite(d_np[i]).all() and np.isfinite(dq_np[i]).all(), name
+    if act != "softplus":        # poses the reference clips in fp32 AND fp64 (on the manifold): exactly zero d and gradient
+        z = (g["d_f32"][:, 0] == 0) & (g["d_f64"][:, 0] == 0)
+        assert np.all(d_np[z, 0] == 0) and np.all(dq_np[z] == 0)
+    # autograd contract with an arbitrary upstream gradient (motion_denoise.py:82-83,97-98)
+    q2 = torch.from_numpy(g["q"]).cuda().requires_grad_(True)
+    (net(q2, train=False)["dist_pred"] * torch.from_numpy(g["grad_out"]).cuda()).sum().backward()
+    truth = g["dq_f64"] * g["grad_out"].reshape(-1, 1, 1)
+    pose_gate(rel_err_rows(q2.grad.cpu().numpy(), truth), sig_g, "grad_pose", exempt=ex)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("act", ACTS)
+def test_trained_projection(torch_cuda, act, precision):
+    """sample_poses.py:67-74 on the trained network: 1 and 10 steps against the reference's fp64 trajectory, within the
+    envelope of the reference's own fp32 trajectory; distances after ten steps against the reference's trace"""
+    torch = torch_cuda
+    g, sd, hidden = load(act)
+    net = make_net(torch, act, sd, hidden, precision)
+    q0 = torch.from_numpy(g["q"]).cuda()
+    for steps in (1, 10):
+        qp, d_last = net.project(q0, steps=steps)
+        outlier_gate(rel_err_rows(qp.cpu().numpy(), g[f"q{steps}_f64"]),
+                     rel_err_rows(g[f"q{steps}_f32"], g[f"q{steps}_f64"]), TOL, f"q{steps}")
+        ref = g["dtrace_f64"][steps - 1]
+        err = np.abs(d_last.cpu().numpy().reshape(-1) - ref) / np.maximum(np.abs(ref), 0.05 * np.abs(ref).max())
+        ref32 = np.abs(g["dtrace_f32"][steps - 1] - ref) / np.maximum(np.abs(ref), 0.05 * np.abs(ref).max())
+        outlier_gate(err, ref32, TOL, f"d_last{steps}")
