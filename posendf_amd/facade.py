@@ -83,6 +83,7 @@ class PoseNDF(nn.Module):
             raise PndfError("StrEnc.act and DFNet.act differ; the fused kernel uses one activation family")
         self._hidden = list(opt["model"]["DFNet"]["dims"])       # net_modules.py:14-28; narrower than amass.yaml: zero padded
         self._engines = {}          # device index -> (Engine, weight fingerprint)
+        self._param_list = None     # cached list(self.parameters()): walking the module tree costs 0.15 ms per call
 
     # ---- nn.Module conveniences the reference callers rely on -----------------------------------
     def train(self, mode=True):     # the reference override returns None (posendf.py:58-59); returning
@@ -91,7 +92,17 @@ class PoseNDF(nn.Module):
 
     # ---- engine plumbing -----------------------------------------------------------------------
     def _fingerprint(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._param_list is None:
+            self._param_list = list(self.parameters())
+        return tuple((p.data_ptr(), p._version) for p in self._param_list)
+
+    def _apply(self, fn, *args, **kwargs):          # .to() / .float() / .cuda(): parameters may be replaced
+        self._param_list = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):     # assign=True replaces the Parameter objects
+        self._param_list = None
+        return super().load_state_dict(*args, **kwargs)
 
     def _engine_for(self, device):
         if device.type != "cuda":
