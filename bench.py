@@ -188,11 +188,11 @@ def main():
     sd = synth.make_weights(0, 2.0, 0.1)                        # BASELINE.md section 3 "live regime"
     precision = "fp32" if (args.act == "softplus" and args.precision == "f16") else args.precision
 
-    def build(prec, act=None):
+    def build(prec, act=None, weights=None):
         cfg = amass_config(act or args.act, f"cuda:{local}")
         cfg["engine"] = {"precision": prec}
         m = PoseNDF(cfg)
-        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in (weights or sd).items()})
         m.eval()
         return m
 
@@ -238,8 +238,8 @@ def main():
 
     # the exact-fp32 and the plain-fp16 kernels beside the split-precision one (same inputs, short runs, outside the
     # timed region): the three points of BASELINE.json configs[2] "fp32 vs bf16"
-    def side_run(prec, act=None):
-        ref = build(prec, act)
+    def side_run(prec, act=None, weights=None):
+        ref = build(prec, act, weights)
         ref.project(q0, steps=args.proj_steps)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
@@ -252,7 +252,7 @@ def main():
         # agreement with the measured kernel on this batch after the full projection (median per-pose relative difference)
         a, b = qp.reshape(B, -1), q_ref.reshape(B, -1)
         diff = ((a - b).abs().amax(1) / b.abs().amax(1).clamp_min(1e-30)).median().item()
-        return {"kernel": KERNELS[prec][0], "kernel_ms": ms, "poses_per_s_per_gpu": B / (ms * 1e-3),
+        return {"kernel": ref._engine_for(dev).kernel_name(), "kernel_ms": ms, "poses_per_s_per_gpu": B / (ms * 1e-3),
                 "achieved_tflops": tf, "median_rel_diff_of_projected_poses_vs_f16x3": diff}
 
     # BASELINE.json configs[1]: the single forward + d d/d q launch on the same batch (outside the timed region)
@@ -296,18 +296,23 @@ def main():
                     "ms": ms1, "pose_steps_per_s": B / (ms1 * 1e-3),
                     "achieved_tflops": B * FLOP_PER_POSE_STEP / (ms1 * 1e-3) / 1e12}
 
-    fp32_ref = f16_ref = sp_ref = None
+    fp32_ref = f16_ref = sp_ref = h16_ref = None
     if precision == "f16x3" and side and args.act != "softplus":
         # the activation of the reference's published checkpoints (sample_poses.py:115, motion_denoise.py:162-163)
         sp_ref = side_run("f16x3", "softplus")
-        sp_ref["kernel"] = "pndf_fused_split_softplus_kernel"
         sp_ref["frac_of_fp16_mfma_peak"] = sp_ref["achieved_tflops"] / PEAK_F16_MFMA_TFLOPS
         sp_ref.pop("median_rel_diff_of_projected_poses_vs_f16x3")     # another network: not comparable
+    if precision == "f16x3" and side and args.act != "softplus":
+        # a half-precision checkpoint (the same network with its weights rounded to fp16): ANOTHER network, on which the
+        # lo*hi term of the split arithmetic vanishes identically and the engine selects the two-term kernels by itself
+        h16_ref = side_run("f16x3", weights={k: v.astype(np.float16).astype(np.float32) for k, v in sd.items()})
+        h16_ref.pop("median_rel_diff_of_projected_poses_vs_f16x3")      # another network: not comparable
+        h16_ref["what"] = ("weights rounded to fp16 (a half-precision checkpoint): every lo half of the packed weights is "
+                           "zero, pndf_load_weights selects the two-term kernels; bit-identical to the three-term kernels "
+                           "on those weights (tests/test_trained_regime.py); not the headline network")
     if precision == "f16x3" and side:
         fp32_ref = side_run("fp32")
         fp32_ref["frac_of_fp32_mfma_peak"] = fp32_ref["achieved_tflops"] / PEAK_FP32_MFMA_TFLOPS
-        if args.act == "softplus":
-            fp32_ref["kernel"] = "pndf_fused_softplus_kernel"
     if precision == "f16x3" and side and args.act != "softplus":
         f16_ref = side_run("f16")
         f16_ref["frac_of_fp16_mfma_peak"] = f16_ref["achieved_tflops"] / PEAK_F16_MFMA_TFLOPS
@@ -316,9 +321,8 @@ def main():
                            "as a comparison point only")
 
     if rank == 0:
-        kname, peak, dtype = KERNELS[precision]
-        if args.act == "softplus":
-            kname = "pndf_fused_split_softplus_kernel" if precision == "f16x3" else "pndf_fused_softplus_kernel"
+        _, peak, dtype = KERNELS[precision]
+        kname = net._engine_for(dev).kernel_name()
         # HBM traffic of the dominant kernel: from the committed PMC passes of the same command
         # (tools/gpu_profile.sh -> profiles/traffic.json); bench.py itself cannot run rocprofv3
         traffic = None
@@ -374,6 +378,8 @@ def main():
             out["f16_single"] = f16_ref
         if sp_ref is not None:
             out["softplus"] = sp_ref
+        if h16_ref is not None:
+            out["fp16_checkpoint"] = h16_ref
         if world == 1 and not args.no_gpu_torch_baseline:
             gt = gpu_torch_baseline(args.act, sd, B, args.proj_steps, dev)
             gt["speedup_of_value"] = out["value"] / gt["value"]

@@ -68,6 +68,11 @@ typedef struct {
  *                  and gradients PER POSE from bounds measured on the chip or derived from the layers' norms, so that
  *                  no operand can overflow fp16 for any finite weights and poses and none is flushed for poses whose
  *                  gradients are tiny (small-gain networks).
+ *                  When every trunk weight is exactly representable in fp16 at its layer scale (e.g. a checkpoint saved
+ *                  in half precision), all lo halves of the weights are zero and the lo*hi term vanishes identically:
+ *                  pndf_load_weights then selects the two-term kernels (2 MFMAs per block, no lo-tile reads) -- the same
+ *                  results bit for bit, ~1.2x the throughput.  The environment variable PNDF_THREE_TERMS=1 keeps the
+ *                  three-term kernels (A/B runs); pndf_kernel_name() tells which one a handle launches.
  * PNDF_PREC_F16  : plain fp16 operands (round to nearest), ONE MFMA per product block, fp32 accumulate.  A measured
  *                  comparison point (BASELINE.json configs[2] "fp32 vs bf16"): ~1e-3 relative, NOT within the 1e-4
  *                  parity bar of the two modes above; never selected implicitly; relu / lrelu only. */
@@ -147,6 +152,9 @@ int pndf_quat_topk(const float* noise, const float* valid, int64_t B, int32_t K,
 
 const char* pndf_last_error(pndf_handle h);   /* h may be NULL: last error of a failed pndf_create */
 const char* pndf_version(void);
+/* Name of the device kernel the compute calls of this handle launch (valid after pndf_load_weights): for logs, profiles
+ * and tests; "" for a NULL handle. */
+const char* pndf_kernel_name(pndf_handle h);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,8 @@ extern "C" __global__ void pndf_fused_split_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_split_relu_kernel_timing(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_split_softplus_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_split_softplus_kernel_timing(PndfKernelArgs args);
+extern "C" __global__ void pndf_fused_split2_relu_kernel(PndfKernelArgs args);        // pndf_kernel_split_x2.hip
+extern "C" __global__ void pndf_fused_split2_softplus_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_half_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_half_relu_kernel_timing(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_relu_kernel_timing(PndfKernelArgs args);
@@ -55,6 +57,9 @@ struct pndf_engine {
     pndf_config cfg;
     int device = 0;
     bool have_weights = false;
+    // f16x3 only: every lo tile of the packed trunk is zero (weights exactly representable in fp16 at their layer scale),
+    // so the lo hi term vanishes identically and the two-term kernels give bit-identical results with 2/3 of the MFMAs
+    bool lo_all_zero = false;
     char* d_stream = nullptr;   // STEP_TILES KiB + a replica of the first STREAM_PAD_SLOTS slots (the ring never wraps)
     float* d_bias = nullptr;
     // softplus: fp32 derivative scratch, one block per RESIDENT workgroup (= per CU: the kernels take a whole CU each
@@ -159,6 +164,10 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
         e = hipFuncSetAttribute((const void*)pndf_fused_split_softplus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_split_softplus_kernel_timing, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)pndf_fused_split2_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)pndf_fused_split2_softplus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_half_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
@@ -329,20 +338,29 @@ inline void split_f16(float w, _Float16& hi, _Float16& lo) {
     hi = (_Float16)w;                       // round to nearest even
     lo = (_Float16)(w - (float)hi);
 }
-// block(M, nt, kb): hi tile then lo tile, 8 halfs per lane each
-void emit_pair(const Mat& m, int nt, int kb, float* dst, float scale) {
+// block(M, nt, kb): hi tile then lo tile, 8 halfs per lane each; returns whether any lo half is non-zero
+bool emit_pair(const Mat& m, int nt, int kb, float* dst, float scale) {
     _Float16* hi = (_Float16*)dst;
     _Float16* lo = (_Float16*)(dst + TILE_FLOATS);
+    bool any_lo = false;
     for (int lane = 0; lane < 64; ++lane)
         for (int jj = 0; jj < 8; ++jj) {
             const float w = m.at(16 * nt + (lane & 15), 16 * (2 * kb + (jj >> 2)) + 4 * (lane >> 4) + (jj & 3));
             split_f16(w * scale, hi[lane * 8 + jj], lo[lane * 8 + jj]);
+            any_lo |= (lo[lane * 8 + jj] != (_Float16)0);
         }
+    return any_lo;
 }
 }  // namespace
 
+static int pack_host_split(const float* const* tensors, const int64_t* numel, int n_tensors, float* stream, float* bias,
+                           bool* lo_all_zero);
 extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* numel, int n_tensors, float* stream,
                                     float* bias) {
+    return pack_host_split(tensors, numel, n_tensors, stream, bias, nullptr);
+}
+static int pack_host_split(const float* const* tensors, const int64_t* numel, int n_tensors, float* stream, float* bias,
+                           bool* lo_all_zero) {
     // biases and encoder tiles are identical to the fp32 stream (the encoder stays on fp32 MFMA)
     int rc = pndf_pack_host(tensors, numel, n_tensors, stream, bias);
     if (rc != PNDF_OK) return rc;
@@ -391,17 +409,18 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
         bias[NORM_OFF + 6 + k] = up(colmax);
     }
     float* dst = stream + (size_t)ENC_TILES_PADDED * TILE_FLOATS;
+    bool any_lo = false;
     for (int ph = 0; ph < 6; ++ph) {
         const Phase& P = PHASES[ph];
         const Mat A{lin[2 * P.a_lin], nd.out(P.a_lin), nd.in(P.a_lin), P.transposed};
         const Mat B{lin[2 * P.b_lin], nd.out(P.b_lin), nd.in(P.b_lin), P.transposed};
         auto partA = [&](int c) {
             for (int kb = 0; kb < P.KA / 2; ++kb)
-                for (int ci = 0; ci < P.CT; ++ci, dst += 2 * TILE_FLOATS) emit_pair(A, c * P.CT + ci, kb, dst, wscale[P.a_lin]);
+                for (int ci = 0; ci < P.CT; ++ci, dst += 2 * TILE_FLOATS) any_lo |= emit_pair(A, c * P.CT + ci, kb, dst, wscale[P.a_lin]);
         };
         auto partB = [&](int c) {
             for (int nb = 0; nb < P.NB; ++nb)
-                for (int b = 0; b < P.CT / 2; ++b, dst += 2 * TILE_FLOATS) emit_pair(B, nb, (c * P.CT) / 2 + b, dst, wscale[P.b_lin]);
+                for (int b = 0; b < P.CT / 2; ++b, dst += 2 * TILE_FLOATS) any_lo |= emit_pair(B, nb, (c * P.CT) / 2 + b, dst, wscale[P.b_lin]);
         };
         partA(0);
         for (int c = 0; c < P.NC; ++c) {
@@ -410,6 +429,7 @@ extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* 
         }
     }
     if (dst - stream != (ptrdiff_t)(ENC_TILES_PADDED + TRUNK_FWD_TILES + TRUNK_BWD_TILES) * TILE_FLOATS) return PNDF_ERR_BAD_SHAPE;
+    if (lo_all_zero) *lo_all_zero = !any_lo;
     return PNDF_OK;
 }
 
@@ -422,8 +442,9 @@ extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, con
     for (int i = 0; i <= NLIN; ++i)
         if (nd.d[i] != h->cfg.dims[i]) return fail(h, PNDF_ERR_BAD_SHAPE, "dfnet tensor shapes do not match the configured dims");
     std::vector<float> stream((size_t)STEP_TILES * TILE_FLOATS), bias(BIAS_FLOATS);
+    bool lo_zero = false;
     const int prc = (h->cfg.precision != PNDF_PREC_FP32)
-                        ? pndf_pack_host_split(tensors, numel, n_tensors, stream.data(), bias.data())
+                        ? pack_host_split(tensors, numel, n_tensors, stream.data(), bias.data(), &lo_zero)
                         : pndf_pack_host(tensors, numel, n_tensors, stream.data(), bias.data());
     if (prc == PNDF_ERR_UNSUPPORTED)
         return fail(h, PNDF_ERR_UNSUPPORTED, "a trunk layer has no finite non-zero weight: outside the operating "
@@ -439,7 +460,23 @@ extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, con
                          (size_t)STREAM_PAD_SLOTS * SLOT_TILES * TILE_BYTES, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
     h->have_weights = true;
+    // PNDF_THREE_TERMS=1 keeps the three-term kernels (same-box A/B runs and the bit-identity test)
+    const char* keep3 = getenv("PNDF_THREE_TERMS");
+    h->lo_all_zero = lo_zero && h->cfg.precision == PNDF_PREC_F16X3 && !(keep3 && keep3[0] == '1');
     return PNDF_OK;
+}
+
+// name of the kernel the compute calls of this handle launch (after pndf_load_weights), for logs, benches and tests
+extern "C" const char* pndf_kernel_name(pndf_handle h) {
+    if (!h) return "";
+    const bool sp = h->cfg.act == PNDF_ACT_SOFTPLUS;
+    switch (h->cfg.precision) {
+        case PNDF_PREC_F16X3:
+            if (h->lo_all_zero) return sp ? "pndf_fused_split2_softplus_kernel" : "pndf_fused_split2_relu_kernel";
+            return sp ? "pndf_fused_split_softplus_kernel" : "pndf_fused_split_relu_kernel";
+        case PNDF_PREC_F16: return "pndf_fused_half_relu_kernel";
+        default: return sp ? "pndf_fused_softplus_kernel" : "pndf_fused_relu_kernel";
+    }
 }
 
 // ------------------------------------------------------------------------------------------ launches
@@ -490,6 +527,8 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
         a.scratch = h->d_scratch;
         if (timing)     // instrumented: one workgroup per block like the relu timing kernel needs B <= 64 * resident_wgs
             hipLaunchKernelGGL(pndf_fused_split_softplus_kernel_timing, pgrid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+        else if (h->cfg.precision == PNDF_PREC_F16X3 && h->lo_all_zero)
+            hipLaunchKernelGGL(pndf_fused_split2_softplus_kernel, pgrid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
         else if (h->cfg.precision == PNDF_PREC_F16X3)
             hipLaunchKernelGGL(pndf_fused_split_softplus_kernel, pgrid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
         else
@@ -507,6 +546,7 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
     if (half && timing) hipLaunchKernelGGL(pndf_fused_half_relu_kernel_timing, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else if (half) hipLaunchKernelGGL(pndf_fused_half_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else if (split && timing) hipLaunchKernelGGL(pndf_fused_split_relu_kernel_timing, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+    else if (split && h->lo_all_zero) hipLaunchKernelGGL(pndf_fused_split2_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else if (split) hipLaunchKernelGGL(pndf_fused_split_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else if (timing) hipLaunchKernelGGL(pndf_fused_relu_kernel_timing, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else if (dbg) hipLaunchKernelGGL(pndf_fused_relu_kernel_dbg, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);

@@ -197,7 +197,7 @@ __device__ __forceinline__ void dma_step(const DmaPieces& d) {
 // One LDS read per MFMA instead of a burst of eight: right after the workgroup barrier all four waves used to issue
 // their bursts at once and sat in the LDS queue with an empty MFMA pipe (tools/ubench/split_rate.hip: barrier cost
 // 150 -> 33 cycles per slot).
-template <int TN, int J, bool BIG = false>
+template <int TN, int J, bool BIG = false, int NT = 3>
 __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, bool loaded) {
     if constexpr (J == 0) {
         if (loaded) {
@@ -206,25 +206,32 @@ __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, 
             dma_begin<TN>(dp, ring, true);
         }
     }
-    if constexpr (J < 8 && (PNDF_ABLATE & 256) != 0) {      // (additive energy experiment: every tile read issued twice)
+    if constexpr (J < 8 && NT == 3 && (PNDF_ABLATE & 256) != 0) {      // (additive energy experiment: every tile read issued twice)
         if (loaded) {
             const f32x4 dup = ring_tile(ring, TN + (J < 4 ? 2 * J : 2 * (J - 4) + 1));
             asm volatile("" : : "v"(dup));
         }
     }
+    // NT == 2 (every lo tile of the network is zero, see PhaseSel): the lo tiles are neither read nor multiplied; the two
+    // DMA pieces of the group move up behind MFMAs 5 and 7 of its eight
+    constexpr int DMA0 = (NT == 3) ? 9 : 5, DMA1 = (NT == 3) ? 11 : 7;
     if constexpr (J < 4) {
         if (loaded) nxt[J].h = __builtin_bit_cast(f16x8, ring_tile(ring, TN + 2 * J));
-    } else if constexpr (J < 8) {
+    } else if constexpr (J < 8 && NT == 3) {
         if (PNDF_ABLATE & 16) nxt[J - 4].l = nxt[J - 4].h;      // (energy-model experiment: no LDS read of the lo tiles)
         else if (loaded) nxt[J - 4].l = __builtin_bit_cast(f16x8, ring_tile(ring, TN + 2 * (J - 4) + 1));
-    } else if constexpr (J == 9 || J == 11) {
-        if (TN == 0 || loaded) dma_step<TN, J == 11, BIG>(dp);
+    }
+    if constexpr (J == DMA0 || J == DMA1) {
+        if (TN == 0 || loaded) dma_step<TN, J == DMA1, BIG>(dp);
     }
 }
 
 // ------------------------------------------------------------------ one fused layer pair, split precision
-template <int KA2, int CT, int NC, int NB, bool BWD, bool SINGLE = false, bool SP = false, bool GTIME = false>
+template <int KA2, int CT, int NC, int NB, bool BWD, bool SINGLE = false, bool SP = false, bool GTIME = false, int NT = 3>
 struct SplitPhase {
+    // NT: MFMAs per product block -- 3 (hi hi + hi lo + lo hi), or 2 when every lo tile of the network is zero (weights that
+    // are exactly representable in fp16 at their layer scale: the lo hi term vanishes identically, results are bit-identical)
+    static_assert(NT == 3 || NT == 2, "terms per product block");
     // GTIME (instrumented kernel only): s_memtime stamp per group of the chunk loop, accumulated in rc->grp[group]
     static __device__ __forceinline__ void gstamp(RegionClock* rc, int group) {
         if constexpr (GTIME) {
@@ -249,7 +256,7 @@ struct SplitPhase {
     template <int GA, int M>
     static __device__ __forceinline__ void a_steps(const Blk (&xin)[KA2], f32x4 (&ch)[3][CT], const Pair (&cur)[4],
                                                    Pair (&nxt)[4], Ring& ring, DmaPieces& dp) {
-        if constexpr (M < 12) {
+        if constexpr (M < 4 * NT) {
             constexpr int term = M / 4, i = M % 4, pi = 4 * GA + i, kb = pi / CT, ci = pi % CT;
             constexpr int TN = (8 * (GA + 1)) % SLOT_TILES;
             if constexpr (M == 8) __builtin_amdgcn_s_waitcnt(0xC87F);     // lgkmcnt(8): this group's lo tiles
@@ -258,7 +265,7 @@ struct SplitPhase {
             if (!((PNDF_ABLATE & 8) && term == 2))      // (energy-model experiment: no third term)
                 ch[PARTIALS == 3 ? term : 0][ci] = mf16(w, x, ch[PARTIALS == 3 ? term : 0][ci]);
             __builtin_amdgcn_sched_barrier(0);
-            feed<TN, M, BIG>(nxt, ring, dp, true);     // part B follows, so there is always a next group
+            feed<TN, M, BIG, NT>(nxt, ring, dp, true);     // part B follows, so there is always a next group
             __builtin_amdgcn_sched_barrier(0);
             a_steps<GA, M + 1>(xin, ch, cur, nxt, ring, dp);
         }
@@ -268,7 +275,8 @@ struct SplitPhase {
                                                   DmaPieces& dp, RegionClock* rc = nullptr) {
         if constexpr (GA < AG) {
             Pair nxt[4];
-            __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt(4): this group's hi tiles
+            if constexpr (NT == 3) __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt(4): this group's hi tiles
+            else __builtin_amdgcn_s_waitcnt(0xC07F);                          // (two terms: nothing younger is in flight)
             __builtin_amdgcn_sched_barrier(0);
             a_steps<GA, 0>(xin, ch, cur, nxt, ring, dp);
 #pragma unroll
@@ -295,7 +303,7 @@ struct SplitPhase {
     // one block behind an MFMA it stalls the pipe for ~120 cycles, so it is cut into SUB = 8 stages of at most one
     // transcendental or three plain instructions.
     static constexpr int SUB = (SP && !BWD) ? 8 : 1;
-    static constexpr int NV = 4 * CT, NS = NV * SUB + 2 + 2 * CT, EPI_SLOTS = 12 * (BG < 8 ? BG : 8);
+    static constexpr int NV = 4 * CT, NS = NV * SUB + 2 + 2 * CT, EPI_SLOTS = 4 * NT * (BG < 8 ? BG : 8);
     static_assert(BG >= 2, "the epilogue is dealt out over at least two groups of part B");
     struct Epi {
         f32x4 (&ch)[3][CT];
@@ -429,7 +437,7 @@ struct SplitPhase {
     template <bool MORE, int GB, int M>
     static __device__ __forceinline__ void b_steps(const Blk (&chb)[CB], f32x4 (&acc)[NB], const Pair (&cur)[4],
                                                    Pair (&nxt)[4], Ring& ring, DmaPieces& dp, Epi& epi) {
-        if constexpr (M < 12) {
+        if constexpr (M < 4 * NT) {
             constexpr int term = M / 4, i = M % 4, pi = 4 * GB + i, nb = pi / CB, b = pi % CB;
             constexpr int TN = (A_TILES + 8 * (GB + 1)) % SLOT_TILES;
             constexpr bool LOADED = MORE || (GB + 1 < BG);
@@ -441,8 +449,8 @@ struct SplitPhase {
             const f16x8 x = (term == 1) ? chb[b].l : chb[b].h;
             if (!((PNDF_ABLATE & 8) && term == 2)) acc[nb] = mf16(w, x, acc[nb]);
             __builtin_amdgcn_sched_barrier(0);
-            feed<TN, M, BIG>(nxt, ring, dp, LOADED);
-            if constexpr (MORE && 12 * GB + M < EPI_SLOTS) epi.template slot<12 * GB + M>();
+            feed<TN, M, BIG, NT>(nxt, ring, dp, LOADED);
+            if constexpr (MORE && 4 * NT * GB + M < EPI_SLOTS) epi.template slot<4 * NT * GB + M>();
             __builtin_amdgcn_sched_barrier(0);
             b_steps<MORE, GB, M + 1>(chb, acc, cur, nxt, ring, dp, epi);
         }
@@ -452,7 +460,8 @@ struct SplitPhase {
                                                   DmaPieces& dp, Epi& epi, RegionClock* rc = nullptr) {
         if constexpr (GB < BG) {
             Pair nxt[4];
-            __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt(4): hi tiles of this group
+            if constexpr (NT == 3) __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt(4): hi tiles of this group
+            else __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_sched_barrier(0);
             b_steps<MORE, GB, 0>(chb, acc, cur, nxt, ring, dp, epi);
 #pragma unroll
@@ -619,7 +628,7 @@ struct HalfPhase {
 };
 
 template <int TERMS, bool SP, int KA2, int CT, int NC, int NB, bool BWD, bool GTIME = false>
-struct PhaseSel { using type = SplitPhase<KA2, CT, NC, NB, BWD, false, SP, GTIME>; };
+struct PhaseSel { using type = SplitPhase<KA2, CT, NC, NB, BWD, false, SP, GTIME, TERMS>; };
 template <int KA2, int CT, int NC, int NB, bool BWD, bool GTIME>
 struct PhaseSel<1, false, KA2, CT, NC, NB, BWD, GTIME> { using type = HalfPhase<KA2, CT, NC, NB, BWD>; };
 
@@ -990,6 +999,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
     }   // block loop
 }
 
+#ifndef PNDF_SPLIT_X2_TU
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_relu_kernel(PndfKernelArgs args) {
     pndf_fused_split_body<false, 3>(args);
 }
@@ -1018,3 +1028,15 @@ extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_half_relu
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_half_relu_kernel_timing(PndfKernelArgs args) {
     pndf_fused_split_body<true, 3 - 2>(args);
 }
+#else
+// Two-term variants (compiled as their own translation unit, pndf_kernel_split_x2.hip): the split kernels for networks
+// whose trunk weights are exactly representable in fp16 at their layer scale (every lo tile of the packed stream is zero,
+// e.g. a checkpoint that was saved in half precision).  The lo hi term then vanishes identically, so dropping its MFMA and
+// the LDS reads of the lo tiles changes no bit of the result; pndf_load_weights selects them by itself.
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split2_relu_kernel(PndfKernelArgs args) {
+    pndf_fused_split_body<false, 2>(args);
+}
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split2_softplus_kernel(PndfKernelArgs args) {
+    pndf_fused_split_body<false, 2, true>(args);
+}
+#endif

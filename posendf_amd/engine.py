@@ -69,6 +69,8 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.pndf_last_error.argtypes = [H]
     lib.pndf_last_error.restype = c_char_p
     lib.pndf_version.restype = c_char_p
+    lib.pndf_kernel_name.argtypes = [H]
+    lib.pndf_kernel_name.restype = c_char_p
     for name in ("pndf_create", "pndf_destroy", "pndf_load_weights", "pndf_forward", "pndf_forward_grad",
                  "pndf_project", "pndf_debug_forward_grad", "pndf_pack_host", "pndf_pack_host_split"):
         getattr(lib, name).restype = c_int
@@ -79,7 +81,7 @@ EXPORTS = ("pndf_default_config", "pndf_create", "pndf_destroy", "pndf_load_weig
            "pndf_forward_grad", "pndf_project", "pndf_debug_forward_grad", "pndf_debug_floats",
            "pndf_debug_project_timing", "pndf_debug_timing_regions",
            "pndf_packed_sizes", "pndf_pack_host", "pndf_pack_host_split", "pndf_aa2quat", "pndf_denoise_update", "pndf_quat_topk",
-           "pndf_last_error", "pndf_version")
+           "pndf_last_error", "pndf_version", "pndf_kernel_name")
 
 
 def state_dict_order(encoder: bool = True):
@@ -151,6 +153,10 @@ class Engine:
     def load_weights(self, sd_np):
         arrs, ptrs, numel = _tensor_table(sd_np)
         self._check(self.lib.pndf_load_weights(self.handle, ptrs, numel, len(arrs)), "pndf_load_weights")
+
+    def kernel_name(self) -> str:
+        """the device kernel this engine's compute calls launch (after load_weights)"""
+        return self.lib.pndf_kernel_name(self.handle).decode()
 
     def forward(self, q_ptr, d_ptr, B, stream=0):
         self._check(self.lib.pndf_forward(self.handle, q_ptr, d_ptr, B, stream), "pndf_forward")

@@ -37,6 +37,9 @@ def test_bench_json_line_default_precision():
     assert {"cpu", "runs_s", "config0_forward_only"} <= set(cb) and cb["config0_forward_only"]["poses_per_s"] > 0
     assert "fp32_exact" in d and "f16_single" in d and "forward_grad_single_launch" in d
     assert d["softplus"]["kernel"] == "pndf_fused_split_softplus_kernel" and d["softplus"]["kernel_ms"] > 0
+    h16 = d["fp16_checkpoint"]                    # half-precision checkpoint: two-term kernels, a side block, never `value`
+    assert h16["kernel"] == "pndf_fused_split2_relu_kernel" and h16["kernel_ms"] < d["roofline"]["kernel_ms"]
+    assert d["roofline"]["kernel"] == "pndf_fused_split_relu_kernel"
     hb = d["host_boundary"]                       # PCIe-inclusive rate of a host-tensor caller: reported, never `value`
     assert hb["ms"] > d["roofline"]["kernel_ms"] and 0 < hb["poses_per_s"] < d["value"] * 1.02
     assert d["roofline"]["kernel_ms_median"] > 0

@@ -126,3 +126,37 @@ def test_trained_projection(torch_cuda, act, precision):
         err = np.abs(d_last.cpu().numpy().reshape(-1) - ref) / np.maximum(np.abs(ref), 0.05 * np.abs(ref).max())
         ref32 = np.abs(g["dtrace_f32"][steps - 1] - ref) / np.maximum(np.abs(ref), 0.05 * np.abs(ref).max())
         outlier_gate(err, ref32, TOL, f"d_last{steps}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act", ACTS)
+def test_fp16_checkpoint_runs_two_term_kernel_bit_identically(torch_cuda, act, monkeypatch):
+    """The trained fixture is a half-precision checkpoint: every weight is exactly representable in fp16, so the lo halves
+    of the packed weights are all zero, the lo*hi term of the split arithmetic vanishes identically, and pndf_load_weights
+    selects the two-term kernels.  Same results bit for bit as the three-term kernels (PNDF_THREE_TERMS=1); a network
+    with ordinary fp32 weights stays on three terms."""
+    torch = torch_cuda
+    from posendf_amd import synth
+    g, sd, hidden = load(act)
+    q0 = torch.from_numpy(np.concatenate([g["q"], synth.make_poses(1000, seed=3, signed=True)])).cuda()
+
+    def run(net):
+        q = q0.clone().requires_grad_(True)
+        d = net(q, train=False)["dist_pred"]
+        (dq,) = torch.autograd.grad(d.sum(), q)
+        qp, dl = net.project(q0, steps=10)
+        return net._engine_for(q0.device).kernel_name(), d.detach(), dq, qp, dl
+
+    name2, *out2 = run(make_net(torch, act, sd, hidden, "f16x3"))
+    monkeypatch.setenv("PNDF_THREE_TERMS", "1")
+    name3, *out3 = run(make_net(torch, act, sd, hidden, "f16x3"))
+    monkeypatch.delenv("PNDF_THREE_TERMS")
+    fam = "softplus" if act == "softplus" else "relu"
+    assert name2 == f"pndf_fused_split2_{fam}_kernel" and name3 == f"pndf_fused_split_{fam}_kernel"
+    for a, b in zip(out2, out3):
+        assert torch.equal(a, b)
+    # ordinary fp32 weights (lo halves non-zero): three terms; one weight off the fp16 grid is enough
+    sd_off = {k: v.copy() for k, v in sd.items()}
+    sd_off["dfnet.lin3.weight"][5, 7] += np.float32(2.0 ** -20)
+    assert run(make_net(torch, act, sd_off, hidden, "f16x3"))[0] == f"pndf_fused_split_{fam}_kernel"
+    assert run(make_net(torch, act, sd, hidden, "fp32"))[0] == ("pndf_fused_softplus_kernel" if act == "softplus" else "pndf_fused_relu_kernel")
