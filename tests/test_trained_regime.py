@@ -160,3 +160,42 @@ def test_fp16_checkpoint_runs_two_term_kernel_bit_identically(torch_cuda, act, m
     sd_off["dfnet.lin3.weight"][5, 7] += np.float32(2.0 ** -20)
     assert run(make_net(torch, act, sd_off, hidden, "f16x3"))[0] == f"pndf_fused_split_{fam}_kernel"
     assert run(make_net(torch, act, sd, hidden, "fp32"))[0] == ("pndf_fused_softplus_kernel" if act == "softplus" else "pndf_fused_relu_kernel")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act", ["lrelu", "relu", "softplus"])
+def test_two_term_kernel_full_width_bit_identity(torch_cuda, act, monkeypatch):
+    """amass.yaml widths, benchmark weights rounded to fp16, a ragged batch: two-term and three-term kernels agree bit for
+    bit on d, dd/dq (with grad_outputs) and a 20-step projection, and both meet the oracle gate."""
+    torch = torch_cuda
+    from oracle import posendf_np as onp
+    from posendf_amd import PoseNDF, amass_config, synth
+    sd = {k: v.astype(np.float16).astype(np.float32) for k, v in synth.make_weights(2, 2.5, 0.05).items()}
+    qn = synth.make_poses(4096 + 37, seed=9, signed=True)
+    q0 = torch.from_numpy(qn).cuda()
+    go = torch.from_numpy(np.random.default_rng(3).normal(size=(len(qn), 1)).astype(np.float32)).cuda()
+
+    def run():
+        cfg = amass_config(act, "cuda:0")
+        cfg["engine"] = {"precision": "f16x3"}
+        net = PoseNDF(cfg)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net.eval()
+        q = q0.clone().requires_grad_(True)
+        d = net(q, train=False)["dist_pred"]
+        (dq,) = torch.autograd.grad(d, q, grad_outputs=go)
+        qp, dl = net.project(q0, steps=20)
+        q1 = q0[:512].clone().requires_grad_(True)
+        (g1,) = torch.autograd.grad(net(q1, train=False)["dist_pred"].sum(), q1)
+        return net._engine_for(q0.device).kernel_name(), d.detach(), dq, qp, dl, g1
+
+    two = run()
+    monkeypatch.setenv("PNDF_THREE_TERMS", "1")
+    three = run()
+    assert "split2" in two[0] and "split2" not in three[0]
+    for a, b in zip(two[1:], three[1:]):
+        assert torch.equal(a, b)
+    sig_d, sig_g, d64, g64 = fp32_noise(qn[:512], sd, act)
+    pose_gate(d_rows(two[1][:512].cpu().numpy(), d64), sig_d, "d")
+    ex = None if act == "softplus" else onp.kink_margin(qn[:512], sd, act) < 1e-5
+    pose_gate(rel_err_rows(two[5].cpu().numpy(), g64), sig_g, "dq", exempt=ex)
