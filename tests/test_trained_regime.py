@@ -159,6 +159,13 @@ def test_fp16_checkpoint_runs_two_term_kernel_bit_identically(torch_cuda, act, m
     sd_off = {k: v.copy() for k, v in sd.items()}
     sd_off["dfnet.lin3.weight"][5, 7] += np.float32(2.0 ** -20)
     assert run(make_net(torch, act, sd_off, hidden, "f16x3"))[0] == f"pndf_fused_split_{fam}_kernel"
+    # the choice follows the weights of the SAME module through reloads (engine re-packs on a changed fingerprint)
+    net = make_net(torch, act, sd, hidden, "f16x3")
+    assert run(net)[0] == f"pndf_fused_split2_{fam}_kernel"
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_off.items()})
+    assert run(net)[0] == f"pndf_fused_split_{fam}_kernel"
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    assert run(net)[0] == f"pndf_fused_split2_{fam}_kernel"
     assert run(make_net(torch, act, sd, hidden, "fp32"))[0] == ("pndf_fused_softplus_kernel" if act == "softplus" else "pndf_fused_relu_kernel")
 
 
