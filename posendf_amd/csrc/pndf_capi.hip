@@ -451,6 +451,14 @@ extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, con
                                              "range of the fp16 hi/lo split -- use precision fp32 for this network");
     if (prc != PNDF_OK)
         return fail(h, PNDF_ERR_BAD_SHAPE, "internal: packed stream length mismatch");
+    if (h->cfg.act == PNDF_ACT_SOFTPLUS) {
+        // zero-padded units of a narrower network: softplus(0) = ln 2 / beta with derivative 1/2 is harmless for the
+        // result (zero outgoing weights) but would enter the per-pose operand bounds the split kernels measure (largest
+        // activation, largest derivative of a layer).  A bias of -1e6 makes both exactly zero; relu-family units are
+        // zero at 0 anyway.
+        for (int l = 0; l < NLIN - 1; ++l)
+            for (int j = nd.out(l); j < DIMS[l + 1]; ++j) bias[BIAS_OFF[l] + j] = -1.0e6f;
+    }
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(h, PNDF_ERR_HIP, "hipSetDevice failed");
     HIP_TRY(h, hipDeviceSynchronize());   // no launch may still be reading the old weights

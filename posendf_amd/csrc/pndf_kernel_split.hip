@@ -318,6 +318,7 @@ struct SplitPhase {
         unsigned hw[2 * CT], lw[2 * CT];
         float cf, k1, k0;
         float sz, sbz, se, su, st2, sru, slg, sd;      // forward softplus: the value in flight (act_softplus, staged)
+        float smax;                                    // forward softplus: largest derivative of this lane's chunk values
 
         template <int S>
         __device__ __forceinline__ void step() {
@@ -366,6 +367,7 @@ struct SplitPhase {
                         sz = lin ? sz : slg * __builtin_amdgcn_rcpf(act.beta);      // beta is uniform: hoisted
                     } else {
                         y[ci][r] = sz * act.oscale;
+                        smax = fmaxf(smax, sd);
                         bt[ci][r] = sd;                              // the bias value is dead: its slot carries the derivative
                         if constexpr (r == 3) *act.sp.slot(act.spslot + c * CT + ci) = bt[ci];
                     }
@@ -410,10 +412,11 @@ struct SplitPhase {
         }
     };
     // the whole epilogue at once (chunk 0 of a phase: there is no MFMA to hide behind; the single-term comparison mode)
-    static __device__ __forceinline__ void epilogue(f32x4 (&ch)[3][CT], Blk (&out)[CB], uint8_t* mask, int c, const SAct& act,
-                                                    const float* biasA, int g) {
-        Epi e{ch, out, mask, c, act, biasA, g};
+    static __device__ __forceinline__ float epilogue(f32x4 (&ch)[3][CT], Blk (&out)[CB], uint8_t* mask, int c, const SAct& act,
+                                                     const float* biasA, int g) {
+        Epi e{ch, out, mask, c, act, biasA, g};      // (the members not named here, smax among them, start at zero)
         e.template steps<0, NS>();
+        return e.smax;
     }
 
     // Backward softplus: the chunk's parked derivatives are fetched HERE, a whole part A (thousands of cycles) before the
@@ -471,8 +474,12 @@ struct SplitPhase {
         }
     }
 
-    static __device__ __forceinline__ void run(const Blk (&xin)[KA2], f32x4 (&acc)[NB], Ring& ring, const float* biasA,
-                                               uint8_t* mask, const SAct& act, int g, RegionClock* rc = nullptr) {
+    // Returns (forward softplus only; 0 otherwise) the largest activation derivative among this lane's values of the chunk
+    // layer: the backward pass multiplies that layer's gradient by these derivatives, and its operand bound may shrink by
+    // their maximum (body: `smax`) -- a layer whose units are ALL saturated low would otherwise sit 2^20 and more below
+    // its a-priori bound and lose its lo halves (narrow bottleneck layers: tests/test_gpu_parity.py width extremes).
+    static __device__ __forceinline__ float run(const Blk (&xin)[KA2], f32x4 (&acc)[NB], Ring& ring, const float* biasA,
+                                                uint8_t* mask, const SAct& act, int g, RegionClock* rc = nullptr) {
         Pair cur[4];
         load_pairs<0>(cur, ring);
         DmaPieces dp;
@@ -482,7 +489,7 @@ struct SplitPhase {
         Blk chb[CB];
         init_chunk(ch, biasA, 0, g, act);
         part_a<0>(xin, ch, cur, ring, dp);
-        epilogue(ch, chb, mask, 0, act, biasA, g);
+        float smax = epilogue(ch, chb, mask, 0, act, biasA, g);
         for (int c = 0; c + 1 < NC; ++c) {
             Blk nextb[CB];
             init_chunk(ch, biasA, c + 1, g, act);
@@ -490,6 +497,7 @@ struct SplitPhase {
             part_a<0>(xin, ch, cur, ring, dp, rc);
             Epi epi{ch, nextb, mask, c + 1, act, biasA, g};
             part_b<true, 0>(chb, acc, cur, ring, dp, epi, rc);
+            if constexpr (SP && !BWD) smax = fmaxf(smax, epi.smax);
 #pragma unroll
             for (int b = 0; b < CB; ++b) chb[b] = nextb[b];
         }
@@ -498,6 +506,7 @@ struct SplitPhase {
             Epi epi{ch, unused, mask, NC, act, biasA, g};      // no next chunk: no micro-step is ever taken from it
             part_b<false, 0>(chb, acc, cur, ring, dp, epi);
         }
+        return (SP && !BWD) ? smax : 0.f;
     }
 };
 
@@ -601,8 +610,8 @@ struct HalfPhase {
         }
     }
 
-    static __device__ __forceinline__ void run(const Blk (&xin)[KA2], f32x4 (&acc)[NB], Ring& ring, const float* biasA,
-                                               uint8_t* mask, const SAct& act, int g, RegionClock* = nullptr) {
+    static __device__ __forceinline__ float run(const Blk (&xin)[KA2], f32x4 (&acc)[NB], Ring& ring, const float* biasA,
+                                                uint8_t* mask, const SAct& act, int g, RegionClock* = nullptr) {
         f16x8 cur[8];
         load_half(cur, ring);
         DmaPieces dp;
@@ -624,6 +633,7 @@ struct HalfPhase {
 #pragma unroll
             for (int b = 0; b < CB; ++b) chb[b] = nextb[b];
         }
+        return 0.f;
     }
 };
 
@@ -641,24 +651,30 @@ template <int NT, bool SINGLE = false, bool SP = false>
 __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 2], uint32_t (&m)[(NT * 4 + 31) / 32], const SAct& act,
                                                 float fixed, float& bound, float& oscale) {
     constexpr int NW = (NT * 4 + 31) / 32;
-    bound = pose_max(tiles_absmax<NT>(x)) * act.to_true;          // |act(z)| <= |z| (+ ln 2 / beta for softplus)
-    if constexpr (SP) bound += SOFTPLUS_MAX_OFFSET / act.beta;
-    oscale = fixed > 0.f ? fixed : pose_scale(bound);
     if constexpr (SP) {
+        // softplus: activate first (true scale), then MEASURE the produced values: |z| + ln 2 / beta as a bound is loose by
+        // many orders of magnitude for a pose whose units are all saturated low, and the padded units of a narrower
+        // network (bias -1e6, pndf_load_weights) must not enter it; 128 extra multiplies against ~25 instructions per value
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             f32x4 dv;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float dr;
-                x[t][r] = act_softplus(x[t][r] * act.to_true, act.beta, dr) * oscale;
+                x[t][r] = act_softplus(x[t][r] * act.to_true, act.beta, dr);
                 dv[r] = dr;
             }
             *act.sp.slot(act.spslot + t) = dv;
         }
+        bound = pose_max(tiles_absmax<NT>(x));
+        oscale = fixed > 0.f ? fixed : pose_scale(bound);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) x[t] = x[t] * oscale;
 #pragma unroll
         for (int w = 0; w < NW; ++w) m[w] = 0;
     } else {
+        bound = pose_max(tiles_absmax<NT>(x)) * act.to_true;          // |act(z)| <= |z|
+        oscale = fixed > 0.f ? fixed : pose_scale(bound);
         const float cf = act.to_true * oscale;
 #pragma unroll
         for (int w = NW - 1; w >= 0; --w) {
@@ -681,13 +697,17 @@ __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 
 template <int NT, bool SINGLE = false, bool SP = false>
 __device__ __forceinline__ void dact_split_tiles(f32x4 (&gx)[NT], Blk (&out)[NT / 2], const uint32_t (&m)[(NT * 4 + 31) / 32], const SAct& act,
                                                  float& bound, float& oscale) {
+    if constexpr (SP) {       // derivative in (0, 1]: applied BEFORE the bound is measured (a layer saturated low is tiny against |g|)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gx[t] = gx[t] * *act.sp.slot(act.spslot + t);
+    }
     bound = pose_max(tiles_absmax<NT>(gx)) * act.to_true;
     oscale = pose_scale(bound);
     const float cf = act.to_true * oscale, k1 = (1.0f - act.slope) * cf, k0 = act.slope * cf;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if constexpr (SP) {
-            gx[t] = (gx[t] * cf) * *act.sp.slot(act.spslot + t);
+            gx[t] = gx[t] * cf;
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -792,6 +812,9 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
         f32x4 x6[4];
         Blk b4[16];
         float fwd_bound, fwd_sigma;      // per pose: bound (true scale) and operand scale of the last accumulator layer
+        // softplus: per pose, the largest derivative of each chunk layer (x1, x3, x5), measured in the forward epilogues; the
+        // backward pass shrinks the a-priori bound of that layer's gradient by it (SplitPhase::run).  1 for the relu family.
+        float dmax1 = 1.f, dmax3 = 1.f, dmax5 = 1.f;
         {
             Blk b2[16];
             {
@@ -819,7 +842,8 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
 #pragma unroll
                     for (int t = 0; t < 32; ++t) x2[t] = x2[t] * bs;
                 }
-                PhaseSel<TERMS, SP, 4, 2, 8, 32, false>::type::run(b0, x2, ring, lds_bias + BIAS_OFF[0], lds_mask + MASK_BASE[0] * WG_THREADS, layer(SP_SLOT_CHUNK[0], 0, sg_in, sg_ch), g);
+                const float dm = PhaseSel<TERMS, SP, 4, 2, 8, 32, false>::type::run(b0, x2, ring, lds_bias + BIAS_OFF[0], lds_mask + MASK_BASE[0] * WG_THREADS, layer(SP_SLOT_CHUNK[0], 0, sg_in, sg_ch), g);
+                if constexpr (SP) dmax1 = pose_max(dm);
                 tick<TIMING>(rc, 1);
                 act_split_tiles<32, SG, SP>(x2, b2, m2, layer(SP_SLOT_X2, 1, sg_ch, 0.f), 0.f, bnd, sg_in);
                 tick<TIMING>(rc, 2);
@@ -835,7 +859,8 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
 #pragma unroll
                 for (int t = 0; t < 32; ++t) x4[t] = x4[t] * bs;
             }
-            PhaseSel<TERMS, SP, 16, 2, 32, 32, false, TIMING && TERMS == 3 && PNDF_GROUP_STAMPS>::type::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], 2, sg_in, sg_ch), g, &rc);
+            const float dm = PhaseSel<TERMS, SP, 16, 2, 32, 32, false, TIMING && TERMS == 3 && PNDF_GROUP_STAMPS>::type::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], 2, sg_in, sg_ch), g, &rc);
+            if constexpr (SP) dmax3 = pose_max(dm);
             tick<TIMING>(rc, 3);
             act_split_tiles<32, SG, SP>(x4, b4, m4, layer(SP_SLOT_X4, 3, sg_ch, 0.f), 0.f, bnd, sg_in);
             tick<TIMING>(rc, 4);
@@ -848,7 +873,8 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
             const float bs = pow2_rcp(inv_w[5]) * sg_ch;
 #pragma unroll
             for (int t = 0; t < 4; ++t) x6[t] = x6[t] * bs;
-            PhaseSel<TERMS, SP, 16, 4, 4, 4, false>::type::run(b4, x6, ring, lds_bias + BIAS_OFF[4], lds_mask + MASK_BASE[2] * WG_THREADS, layer(SP_SLOT_CHUNK[2], 4, fwd_sigma, sg_ch), g);
+            const float dm = PhaseSel<TERMS, SP, 16, 4, 4, 4, false>::type::run(b4, x6, ring, lds_bias + BIAS_OFF[4], lds_mask + MASK_BASE[2] * WG_THREADS, layer(SP_SLOT_CHUNK[2], 4, fwd_sigma, sg_ch), g);
+            if constexpr (SP) dmax5 = pose_max(dm);
             tick<TIMING>(rc, 5);
             Blk b6[2];
             float bnd6, sg6;
@@ -904,7 +930,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
                         float bnd, sg_in;
                         dact_split_tiles<4, SG, SP>(g6, gb6, m6, seed, bnd, sg_in);
                         tick<TIMING>(rc, 6);
-                        const float sg_ch = pose_scale(nrm[6] * bnd);                         // g5: |W5^T g6| <= ||W5^T|| |g6|
+                        const float sg_ch = pose_scale(nrm[6] * bnd * dmax5);                 // g5: |act' W5^T g6| <= max act' ||W5^T|| |g6|
                         f32x4 g4[32];
 #pragma unroll
                         for (int t = 0; t < 32; ++t) g4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -912,7 +938,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
                         dact_split_tiles<32, SG, SP>(g4, gb4, m4, layer(SP_SLOT_X4, 4, sg_ch, 0.f), bwd_bound, bwd_sigma);
                         tick<TIMING>(rc, 7);
                     }
-                    const float sg_ch = pose_scale(nrm[7] * bwd_bound);                       // g3
+                    const float sg_ch = pose_scale(nrm[7] * bwd_bound * dmax3);               // g3
                     f32x4 g2[32];
 #pragma unroll
                     for (int t = 0; t < 32; ++t) g2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -920,7 +946,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
                     dact_split_tiles<32, SG, SP>(g2, gb2, m2, layer(SP_SLOT_X2, 2, sg_ch, 0.f), bwd_bound, bwd_sigma);
                     tick<TIMING>(rc, 8);
                 }
-                const float sg_ch = pose_scale(nrm[8] * bwd_bound);                           // g1
+                const float sg_ch = pose_scale(nrm[8] * bwd_bound * dmax1);                   // g1
 #pragma unroll
                 for (int t = 0; t < 8; ++t) g0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 PhaseSel<TERMS, SP, 16, 2, 8, 8, true>::type::run(gb2, g0, ring, nullptr, lds_mask + MASK_BASE[0] * WG_THREADS, layer(SP_SLOT_CHUNK[0], 1, bwd_sigma, sg_ch), g);

@@ -450,3 +450,33 @@ def test_narrower_architecture_runs_zero_padded(torch_cuda, act, precision):
     q64, _ = onp.project(qn, sd, steps=5, act=act, dtype=np.float64)
     q32, _ = onp.project(qn, sd, steps=5, act=act)
     outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project5")
+
+
+@pytest.mark.parametrize("hidden", [[1, 1, 1, 1, 1, 1], [17, 33, 65, 31, 15, 1], [256, 512, 1024, 512, 256, 63],
+                                    [255, 511, 1023, 511, 255, 64], [16, 32, 64, 32, 16, 16], [3, 500, 7, 300, 2, 40]],
+                         ids=lambda h: "x".join(map(str, h)))
+@pytest.mark.parametrize("act,precision", [("lrelu", "f16x3"), ("softplus", "f16x3"), ("relu", "fp32")])
+def test_narrower_architecture_width_extremes(torch_cuda, act, precision, hidden):
+    """`model.DFNet.dims` of the amass.yaml depth with arbitrary widths up to those of amass.yaml (net_modules.py:14-28):
+    width 1, widths one short of a tile / of the full layer, wildly unbalanced layers -- against the fp64 oracle."""
+    torch = torch_cuda
+    from oracle import posendf_np as onp
+    from posendf_amd import PoseNDF, amass_config, synth
+    sd = synth.make_weights(6, 2.0, 0.1, dims=(126, *hidden, 1))
+    cfg = amass_config(act, "cuda:0")
+    cfg["model"]["DFNet"]["dims"] = hidden
+    cfg["engine"] = {"precision": precision}
+    net = PoseNDF(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    qn = synth.make_poses(200, seed=43, signed=True)
+    q = torch.from_numpy(qn).cuda().requires_grad_(True)
+    d = net(q, train=False)["dist_pred"]
+    (dq,) = torch.autograd.grad(d.sum(), q)
+    sig_d, sig_g, d64, g64 = fp32_noise(qn, sd, act)
+    pose_gate(d_rows(d.detach().cpu().numpy(), d64), sig_d, "d")
+    pose_gate(rel_err_rows(dq.cpu().numpy(), g64), sig_g, "dq", exempt=kink_exempt(qn, sd, act))
+    qp, dl = net.project(q.detach(), steps=3)
+    q64, _ = onp.project(qn, sd, steps=3, act=act, dtype=np.float64)
+    q32, _ = onp.project(qn, sd, steps=3, act=act)
+    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project3")
