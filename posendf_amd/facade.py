@@ -81,6 +81,9 @@ class PoseNDF(nn.Module):
         self._beta = float(opt["model"]["DFNet"].get("beta", 100.0))
         if self.enc is not None and opt["model"]["StrEnc"]["act"] != self._act:
             raise PndfError("StrEnc.act and DFNet.act differ; the fused kernel uses one activation family")
+        if (self.enc is not None and self._act == "softplus"
+                and float(opt["model"]["StrEnc"].get("beta", self._beta)) != self._beta):
+            raise PndfError("StrEnc.beta and DFNet.beta differ; the fused kernel uses one Softplus beta")
         self._hidden = list(opt["model"]["DFNet"]["dims"])       # net_modules.py:14-28; narrower than amass.yaml: zero padded
         self._engines = {}          # device index -> (Engine, weight fingerprint)
         self._param_list = None     # cached list(self.parameters()): walking the module tree costs 0.15 ms per call

@@ -480,3 +480,88 @@ def test_narrower_architecture_width_extremes(torch_cuda, act, precision, hidden
     q64, _ = onp.project(qn, sd, steps=3, act=act, dtype=np.float64)
     q32, _ = onp.project(qn, sd, steps=3, act=act)
     outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project3")
+
+
+def _rescaled(sd, c):
+    """layer l's outputs scaled by c[l] (W_l' = W_l c_l / c_{l-1}, b_l' = b_l c_l; c_6 = 1): for the positively homogeneous
+    relu family the SAME function, with activations ten thousand times smaller or larger from layer to layer"""
+    out = {k: v.copy() for k, v in sd.items()}
+    prev = 1.0
+    for l in range(7):
+        cl = c[l] if l < 6 else 1.0
+        out[f"dfnet.lin{l}.weight"] = (sd[f"dfnet.lin{l}.weight"].astype(np.float64) * (cl / prev)).astype(np.float32)
+        out[f"dfnet.lin{l}.bias"] = (sd[f"dfnet.lin{l}.bias"].astype(np.float64) * cl).astype(np.float32)
+        prev = cl
+    return out
+
+
+@pytest.mark.parametrize("scales", [(1e-4, 1e3, 1e-3, 1e4, 1e-2, 1e2), (1e4, 1e-3, 1e3, 1e-4, 1e2, 1e-2),
+                                    (1e-6, 1e-6, 1e-6, 1e-6, 1e-6, 1e-6), (1e5, 1e5, 1e5, 1e5, 1e5, 1e5)],
+                         ids=["zigzag", "zagzig", "tiny", "huge"])
+@pytest.mark.parametrize("act,precision", cases(["lrelu", "relu"]))
+def test_layer_scale_extremes(torch_cuda, act, precision, scales):
+    """activations of 1e-6 .. 1e+5 times the usual size, changing by up to 1e7 from one layer to the next: the per-layer
+    weight scale and the per-pose operand scale of the split kernel must keep every operand inside fp16"""
+    torch = torch_cuda
+    from posendf_amd import synth
+    sd = _rescaled(synth.make_weights(0, 2.0, 0.1), scales)
+    net = make_net(torch, act, sd=sd, precision=precision)
+    qn = synth.make_poses(256, seed=47, signed=True)
+    q = torch.from_numpy(qn).cuda().requires_grad_(True)
+    d = net(q, train=False)["dist_pred"]
+    (dq,) = torch.autograd.grad(d.sum(), q)
+    sig_d, sig_g, d64, g64 = fp32_noise(qn, sd, act)
+    pose_gate(d_rows(d.detach().cpu().numpy(), d64), sig_d, "d")
+    pose_gate(rel_err_rows(dq.cpu().numpy(), g64), sig_g, "dq", exempt=kink_exempt(qn, sd, act))
+
+
+@pytest.mark.parametrize("beta", [1.0, 10.0, 1000.0])
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_softplus_beta_range(torch_cuda, precision, beta):
+    """model.DFNet.beta other than amass.yaml's 100 (net_modules.py:39-41): smooth (beta 1: every unit in the transition
+    region, softplus(0) = 0.69) to almost-ReLU (beta 1000)"""
+    torch = torch_cuda
+    from oracle import posendf_np as onp
+    from posendf_amd import PoseNDF, amass_config, synth
+    sd = synth.make_weights(1, 2.0, 0.1)
+    cfg = amass_config("softplus", "cuda:0")
+    cfg["model"]["DFNet"]["beta"] = beta
+    cfg["model"]["StrEnc"]["beta"] = beta
+    cfg["engine"] = {"precision": precision}
+    net = PoseNDF(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    qn = synth.make_poses(256, seed=48, signed=True)
+    q = torch.from_numpy(qn).cuda().requires_grad_(True)
+    d = net(q, train=False)["dist_pred"]
+    (dq,) = torch.autograd.grad(d.sum(), q)
+    d64, g64 = onp.forward_grad(qn, sd, "softplus", beta=beta, dtype=np.float64)
+    sig_d, sig_g = [], []
+    rng = np.random.default_rng(1)
+    for _ in range(8):              # conftest.fp32_noise with this beta
+        qk = (qn * (1 + rng.uniform(-2.0 ** -23, 2.0 ** -23, qn.shape))).astype(np.float32)
+        d32, g32 = onp.forward_grad(qk, sd, "softplus", beta=beta, dtype=np.float32)
+        sig_d.append(d_rows(d32, d64))
+        sig_g.append(rel_err_rows(g32, g64))
+    pose_gate(d_rows(d.detach().cpu().numpy(), d64), np.max(sig_d, axis=0), "d")
+    pose_gate(rel_err_rows(dq.cpu().numpy(), g64), np.max(sig_g, axis=0), "dq")
+
+
+@pytest.mark.parametrize("go", [1e-12, 1e-7, 1e7, -3e9])
+@pytest.mark.parametrize("act,precision", cases(["lrelu", "softplus"]))
+def test_grad_outputs_of_any_magnitude(torch_cuda, act, precision, go):
+    """motion_denoise.py weights the prior by 1e7 c^2 / (1 + it): the upstream gradient reaching forward()'s backward spans
+    many orders of magnitude.  It multiplies the RESULT of the backward pass (never its fp16 operands), so dq(go) equals
+    go * dq(1) to one rounding"""
+    torch = torch_cuda
+    from posendf_amd import synth
+    net = make_net(torch, act, "live", precision=precision)
+    qn = synth.make_poses(500, seed=50, signed=True)
+    q = torch.from_numpy(qn).cuda().requires_grad_(True)
+    d = net(q, train=False)["dist_pred"]
+    (g1,) = torch.autograd.grad(d.sum(), q)
+    q2 = torch.from_numpy(qn).cuda().requires_grad_(True)
+    (g2,) = torch.autograd.grad(net(q2, train=False)["dist_pred"], q2, grad_outputs=torch.full_like(d, go))
+    ref = g1.double() * go
+    err = (g2.double() - ref).abs().amax(dim=(1, 2)) / ref.abs().amax(dim=(1, 2)).clamp_min(1e-300)
+    assert torch.isfinite(g2).all() and float(err.max()) < 3e-7, float(err.max())

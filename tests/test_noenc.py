@@ -78,3 +78,36 @@ def test_engine_ragged_batch_matches_oracle(precision):
     qo, do = onp.project(q_np, sd, steps=3, dtype=np.float64)
     assert np.median(rel_err_rows(qp.cpu().numpy(), qo)) < TOL / 10
     assert d_err(dl.cpu().numpy(), do) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act,precision", [("lrelu", "f16x3"), ("softplus", "f16x3"), ("softplus", "fp32")])
+def test_noenc_narrower_combination(act, precision):
+    """encoder-less AND narrower than amass.yaml at once (in_dim 84, hidden 100-300-520-77-130-33): both are runtime
+    variations of the same kernels; against the fp64 oracle with the per-pose gates"""
+    import torch
+    from conftest import d_rows, fp32_noise, pose_gate
+    from oracle import posendf_np as onp
+    from posendf_amd import PoseNDF, amass_config
+    hidden = [100, 300, 520, 77, 130, 33]
+    sd = synth.make_weights(seed=8, gain=2.0, out_bias=0.1, dims=(84, *hidden, 1))
+    cfg = amass_config(act, "cuda:0")
+    cfg["model"]["StrEnc"]["use"] = False
+    cfg["model"]["DFNet"]["in_dim"] = 84
+    cfg["model"]["DFNet"]["dims"] = hidden
+    cfg["engine"] = {"precision": precision}
+    net = PoseNDF(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    qn = synth.make_poses(300, seed=49, signed=True)
+    q = torch.from_numpy(qn).cuda().requires_grad_(True)
+    d = net(q, train=False)["dist_pred"]
+    (dq,) = torch.autograd.grad(d.sum(), q)
+    sig_d, sig_g, d64, g64 = fp32_noise(qn, sd, act)
+    ex = None if act == "softplus" else onp.kink_margin(qn, sd, act) < 1e-5
+    pose_gate(d_rows(d.detach().cpu().numpy(), d64), sig_d, "d")
+    pose_gate(rel_err_rows(dq.cpu().numpy(), g64), sig_g, "dq", exempt=ex)
+    qp, _ = net.project(q.detach(), steps=5)
+    q64, _ = onp.project(qn, sd, steps=5, act=act, dtype=np.float64)
+    q32, _ = onp.project(qn, sd, steps=5, act=act)
+    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project5")
