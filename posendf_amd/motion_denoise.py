@@ -77,7 +77,8 @@ class MotionDenoise:
     def losses(self, body_pose, init_joints, it):
         loss = {"pose_pr": self.pose_prior_term(body_pose)}
         verts, joints = self._geometry(body_pose)
-        loss["temp"] = self._mean_norm(verts[:, :-1] - verts[:, 1:])                 # :88-89
+        if verts.shape[1] > 1:       # a one-frame "sequence" has no temporal term (the reference's mean over nothing is NaN)
+            loss["temp"] = self._mean_norm(verts[:, :-1] - verts[:, 1:])             # :88-89
         if it > 0:                                                                    # :92 ("for nans")
             loss["data"] = self._mean_norm(joints - init_joints)                      # :93-94
         return loss

@@ -262,3 +262,25 @@ def test_body_model_hook_cpu():
     assert set(loss) == {"pose_pr", "temp", "data"}
     (loss["temp"].sum() + loss["data"].sum()).backward()
     assert pose.grad[..., :63].abs().min().item() > 0 and torch.all(pose.grad[..., 63:] == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [1, 2, 3])
+def test_very_short_sequences(T):
+    """one, two and three frames: no temporal neighbour / one / both; fused step and autograd driver agree and stay finite
+    (a one-frame sequence has no temporal term here; the reference's mean over an empty difference is NaN)"""
+    import torch
+    from posendf_amd import PoseNDF, amass_config, synth
+    from posendf_amd.motion_denoise import MotionDenoise
+    cfg = amass_config("lrelu", "cuda:0")
+    cfg["engine"] = {"precision": "fp32"}
+    net = PoseNDF(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(0, 2.0, 0.1).items()})
+    net.eval()
+    rng = np.random.default_rng(7)
+    noisy = torch.from_numpy(rng.normal(scale=0.3, size=(4, T, 69)).astype(np.float32)).cuda()
+    md = MotionDenoise(net)
+    a, _ = md.optimize(noisy, iterations=2, steps_per_iter=3, fused=False)
+    b, _ = md.optimize(noisy, iterations=2, steps_per_iter=3, fused=True)
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert (a - b).abs().max().item() < 2e-4, (a - b).abs().max().item()
