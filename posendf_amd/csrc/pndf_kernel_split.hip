@@ -226,6 +226,21 @@ __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, 
     }
 }
 
+// Order of the 12 (8) MFMAs of a group of four weight pairs.  The kernel runs at the package power cap, and MFMA power
+// depends on how many operand bits toggle between consecutive instructions (tools/ubench/mfma_power.hip: keeping the A
+// operand for two MFMAs in a row sustains 3.4 % more).  PNDF_MFMA_ORDER
+//   0  term-major (hh x4, hl x4, lh x4): A changes with every MFMA                                     (rounds 1-2)
+//   1  hh_i and hl_i adjacent (they share A = Wh_i), lh last: -2.2 % time, same cycle count
+//   2  (default) as 1, snaking: hh0 hl0 | hl1 hh1 | hh2 hl2 | hl3 hh3 | lh0..3 -- B changes only every second MFMA
+//      too: -2.4 % time (profiles/r02/ab_mfma_order.txt).  Back-to-back MFMAs on one accumulator cost no cycles.
+#ifndef PNDF_MFMA_ORDER
+#define PNDF_MFMA_ORDER 2
+#endif
+constexpr int mfma_term(int M) {
+    return (PNDF_MFMA_ORDER == 0 || M >= 8) ? M / 4 : (PNDF_MFMA_ORDER == 1) ? M % 2 : ((M % 2) ^ ((M / 2) % 2));
+}
+constexpr int mfma_pair(int M) { return (PNDF_MFMA_ORDER != 0 && M < 8) ? M / 2 : M % 4; }
+
 // ------------------------------------------------------------------ one fused layer pair, split precision
 template <int KA2, int CT, int NC, int NB, bool BWD, bool SINGLE = false, bool SP = false, bool GTIME = false, int NT = 3>
 struct SplitPhase {
@@ -257,7 +272,7 @@ struct SplitPhase {
     static __device__ __forceinline__ void a_steps(const Blk (&xin)[KA2], f32x4 (&ch)[3][CT], const Pair (&cur)[4],
                                                    Pair (&nxt)[4], Ring& ring, DmaPieces& dp) {
         if constexpr (M < 4 * NT) {
-            constexpr int term = M / 4, i = M % 4, pi = 4 * GA + i, kb = pi / CT, ci = pi % CT;
+            constexpr int term = mfma_term(M), i = mfma_pair(M), pi = 4 * GA + i, kb = pi / CT, ci = pi % CT;
             constexpr int TN = (8 * (GA + 1)) % SLOT_TILES;
             if constexpr (M == 8) __builtin_amdgcn_s_waitcnt(0xC87F);     // lgkmcnt(8): this group's lo tiles
             const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
@@ -441,7 +456,7 @@ struct SplitPhase {
     static __device__ __forceinline__ void b_steps(const Blk (&chb)[CB], f32x4 (&acc)[NB], const Pair (&cur)[4],
                                                    Pair (&nxt)[4], Ring& ring, DmaPieces& dp, Epi& epi) {
         if constexpr (M < 4 * NT) {
-            constexpr int term = M / 4, i = M % 4, pi = 4 * GB + i, nb = pi / CB, b = pi % CB;
+            constexpr int term = mfma_term(M), i = mfma_pair(M), pi = 4 * GB + i, nb = pi / CB, b = pi % CB;
             constexpr int TN = (A_TILES + 8 * (GB + 1)) % SLOT_TILES;
             constexpr bool LOADED = MORE || (GB + 1 < BG);
             if constexpr (M == 8) {
