@@ -231,15 +231,26 @@ __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, 
 // operand for two MFMAs in a row sustains 3.4 % more).  PNDF_MFMA_ORDER
 //   0  term-major (hh x4, hl x4, lh x4): A changes with every MFMA                                     (rounds 1-2)
 //   1  hh_i and hl_i adjacent (they share A = Wh_i), lh last: -2.2 % time, same cycle count
-//   2  (default) as 1, snaking: hh0 hl0 | hl1 hh1 | hh2 hl2 | hl3 hh3 | lh0..3 -- B changes only every second MFMA
-//      too: -2.4 % time (profiles/r02/ab_mfma_order.txt).  Back-to-back MFMAs on one accumulator cost no cycles.
+//   2  as 1, snaking: hh0 hl0 | hl1 hh1 | hh2 hl2 | hl3 hh3 | lh0..3 -- B changes only every second MFMA too: -2.4 % time
+//      (profiles/r02/ab_mfma_order.txt).  Back-to-back MFMAs on one accumulator cost no cycles.
 #ifndef PNDF_MFMA_ORDER
-#define PNDF_MFMA_ORDER 2
+#define PNDF_MFMA_ORDER 3
 #endif
-constexpr int mfma_term(int M) {
-    return (PNDF_MFMA_ORDER == 0 || M >= 8) ? M / 4 : (PNDF_MFMA_ORDER == 1) ? M % 2 : ((M % 2) ^ ((M / 2) % 2));
+//   3  (default) pair-major: hh_i hl_i lh_i back to back -- A = Wh_i kept for two MFMAs AND chains of three MFMAs on one
+//      accumulator (the micro-benchmark sustains 11 % more when every MFMA accumulates onto the result of a just-issued
+//      one: the accumulator need not come from the register file); needs all eight tiles of a group at its start.
+//      SWAP (part A with two chunk tiles): pairs 0 2 | 1 3, i.e. chains of six.  Another -1.7 % on top of order 2.
+constexpr int mfma_term(int M, int NT = 3) {
+    return (PNDF_MFMA_ORDER == 3) ? M % NT
+           : (PNDF_MFMA_ORDER == 0 || M >= 8) ? M / 4 : (PNDF_MFMA_ORDER == 1) ? M % 2 : ((M % 2) ^ ((M / 2) % 2));
 }
-constexpr int mfma_pair(int M) { return (PNDF_MFMA_ORDER != 0 && M < 8) ? M / 2 : M % 4; }
+constexpr int mfma_pair(int M, int NT = 3, bool SWAP = false) {
+    if (PNDF_MFMA_ORDER == 3) {
+        const int p = M / NT;
+        return SWAP ? ((p == 1) ? 2 : (p == 2) ? 1 : p) : p;
+    }
+    return (PNDF_MFMA_ORDER != 0 && M < 8) ? M / 2 : M % 4;
+}
 
 // ------------------------------------------------------------------ one fused layer pair, split precision
 template <int KA2, int CT, int NC, int NB, bool BWD, bool SINGLE = false, bool SP = false, bool GTIME = false, int NT = 3>
@@ -272,9 +283,9 @@ struct SplitPhase {
     static __device__ __forceinline__ void a_steps(const Blk (&xin)[KA2], f32x4 (&ch)[3][CT], const Pair (&cur)[4],
                                                    Pair (&nxt)[4], Ring& ring, DmaPieces& dp) {
         if constexpr (M < 4 * NT) {
-            constexpr int term = mfma_term(M), i = mfma_pair(M), pi = 4 * GA + i, kb = pi / CT, ci = pi % CT;
+            constexpr int term = mfma_term(M, NT), i = mfma_pair(M, NT, CT == 2), pi = 4 * GA + i, kb = pi / CT, ci = pi % CT;
             constexpr int TN = (8 * (GA + 1)) % SLOT_TILES;
-            if constexpr (M == 8) __builtin_amdgcn_s_waitcnt(0xC87F);     // lgkmcnt(8): this group's lo tiles
+            if constexpr (M == 8 && PNDF_MFMA_ORDER != 3) __builtin_amdgcn_s_waitcnt(0xC87F);     // lgkmcnt(8): this group's lo tiles
             const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
             const f16x8 x = (term == 1) ? xin[kb].l : xin[kb].h;
             if (!((PNDF_ABLATE & 8) && term == 2))      // (energy-model experiment: no third term)
@@ -290,7 +301,7 @@ struct SplitPhase {
                                                   DmaPieces& dp, RegionClock* rc = nullptr) {
         if constexpr (GA < AG) {
             Pair nxt[4];
-            if constexpr (NT == 3) __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt(4): this group's hi tiles
+            if constexpr (NT == 3 && PNDF_MFMA_ORDER != 3) __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt(4): this group's hi tiles
             else __builtin_amdgcn_s_waitcnt(0xC07F);                          // (two terms: nothing younger is in flight)
             __builtin_amdgcn_sched_barrier(0);
             a_steps<GA, 0>(xin, ch, cur, nxt, ring, dp);
@@ -456,10 +467,10 @@ struct SplitPhase {
     static __device__ __forceinline__ void b_steps(const Blk (&chb)[CB], f32x4 (&acc)[NB], const Pair (&cur)[4],
                                                    Pair (&nxt)[4], Ring& ring, DmaPieces& dp, Epi& epi) {
         if constexpr (M < 4 * NT) {
-            constexpr int term = mfma_term(M), i = mfma_pair(M), pi = 4 * GB + i, nb = pi / CB, b = pi % CB;
+            constexpr int term = mfma_term(M, NT), i = mfma_pair(M, NT), pi = 4 * GB + i, nb = pi / CB, b = pi % CB;
             constexpr int TN = (A_TILES + 8 * (GB + 1)) % SLOT_TILES;
             constexpr bool LOADED = MORE || (GB + 1 < BG);
-            if constexpr (M == 8) {
+            if constexpr (M == 8 && PNDF_MFMA_ORDER != 3) {
                 if constexpr (LOADED) __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8)
                 else __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0)
             }
@@ -478,7 +489,7 @@ struct SplitPhase {
                                                   DmaPieces& dp, Epi& epi, RegionClock* rc = nullptr) {
         if constexpr (GB < BG) {
             Pair nxt[4];
-            if constexpr (NT == 3) __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt(4): hi tiles of this group
+            if constexpr (NT == 3 && PNDF_MFMA_ORDER != 3) __builtin_amdgcn_s_waitcnt(0xC47F);        // lgkmcnt(4): hi tiles of this group
             else __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_sched_barrier(0);
             b_steps<MORE, GB, 0>(chb, acc, cur, nxt, ring, dp, epi);

@@ -42,9 +42,13 @@ __global__ void __launch_bounds__(256, 1) k(float* out, unsigned long long* cyc,
 #pragma unroll
         for (int m = 0; m < 32; ++m) {
             constexpr int dummy = 0;
-            const int ia = PAT == 2 ? 0 : PAT == 4 ? (m / 2) % 8 : m % 8;
-            const int ib = PAT == 0 ? (m + m / 8) % 8 : PAT == 1 ? 0 : PAT == 2 ? m % 8 : PAT == 3 ? (m / 4) % 2 : m % 2;
-            if (SHAPE == 16) c4[m % 8] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ia], b[ib], c4[m % 8], 0, 0, 0);
+            // 5: a wave owning 32 poses (A kept for four MFMAs: xh0 xl0 xh1 xl1); 6: pattern 4 with the two MFMAs that share A
+            // also sharing the accumulator (the kernel's hh_i, hl_i); 7: pattern 0 on two alternating accumulators only
+            const int ia = PAT == 2 ? 0 : (PAT == 4 || PAT == 6) ? (m / 2) % 8 : PAT == 5 ? (m / 4) % 8 : m % 8;
+            const int ib = PAT == 0 || PAT == 7 ? (m + m / 8) % 8 : PAT == 1 ? 0 : PAT == 2 ? m % 8 : PAT == 3 ? (m / 4) % 2
+                           : PAT == 5 ? m % 4 : m % 2;
+            const int ic = PAT == 6 ? (m / 2) % 8 : PAT == 7 ? m % 2 : m % 8;
+            if (SHAPE == 16) c4[ic] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ia], b[ib], c4[ic], 0, 0, 0);
             else c16[m % 4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m % 8], b[(m + m / 8) % 8], c16[m % 4], 0, 0, 0);
         }
     }
@@ -94,6 +98,9 @@ int main() {
     run<16, 1, 2>("16x16x32 random, A fixed", out, cyc);
     run<16, 1, 3>("16x16x32 random, B fixed x4", out, cyc);
     run<16, 1, 4>("16x16x32 random, A x2, B alt", out, cyc);
+    run<16, 1, 5>("16x16x32 random, A x4, B cyc4", out, cyc);
+    run<16, 1, 6>("16x16x32 random, A x2 + acc x2", out, cyc);
+    run<16, 1, 7>("16x16x32 random, 2 accumulators", out, cyc);
     run<16, 1, 0>("16x16x32 f16, random (3rd)", out, cyc);
     return 0;
 }
