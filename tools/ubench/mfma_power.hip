@@ -44,10 +44,13 @@ __global__ void __launch_bounds__(256, 1) k(float* out, unsigned long long* cyc,
             constexpr int dummy = 0;
             // 5: a wave owning 32 poses (A kept for four MFMAs: xh0 xl0 xh1 xl1); 6: pattern 4 with the two MFMAs that share A
             // also sharing the accumulator (the kernel's hh_i, hl_i); 7: pattern 0 on two alternating accumulators only
-            const int ia = PAT == 2 ? 0 : (PAT == 4 || PAT == 6) ? (m / 2) % 8 : PAT == 5 ? (m / 4) % 8 : m % 8;
+            const int ia = PAT == 2 ? 0 : (PAT == 4 || PAT == 6) ? (m / 2) % 8 : PAT == 5 ? (m / 4) % 8
+                           : PAT == 20 ? ((m / 3) * 2 + (m % 3 == 2)) % 8 : m % 8;
             const int ib = PAT == 0 || PAT == 7 ? (m + m / 8) % 8 : PAT == 1 ? 0 : PAT == 2 ? m % 8 : PAT == 3 ? (m / 4) % 2
                            : PAT == 5 ? m % 4 : m % 2;
-            const int ic = PAT == 6 ? (m / 2) % 8 : PAT == 7 ? m % 2 : m % 8;
+            // 10 + N: pattern 0 rotating over N accumulators (N = 1 .. 4): how close must the producer of C be?
+            // 20: the kernel's pair-major order (chains of three on one accumulator, A kept for the first two, eight accumulators)
+            const int ic = PAT == 6 ? (m / 2) % 8 : PAT == 7 ? m % 2 : PAT > 10 && PAT < 20 ? m % (PAT - 10) : PAT == 20 ? (m / 3) % 8 : m % 8;
             if (SHAPE == 16) c4[ic] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ia], b[ib], c4[ic], 0, 0, 0);
             else c16[m % 4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m % 8], b[(m + m / 8) % 8], c16[m % 4], 0, 0, 0);
         }
@@ -101,6 +104,10 @@ int main() {
     run<16, 1, 5>("16x16x32 random, A x4, B cyc4", out, cyc);
     run<16, 1, 6>("16x16x32 random, A x2 + acc x2", out, cyc);
     run<16, 1, 7>("16x16x32 random, 2 accumulators", out, cyc);
+    run<16, 1, 11>("16x16x32 random, 1 accumulator", out, cyc);
+    run<16, 1, 13>("16x16x32 random, 3 accumulators", out, cyc);
+    run<16, 1, 14>("16x16x32 random, 4 accumulators", out, cyc);
+    run<16, 1, 20>("16x16x32 random, kernel order 3", out, cyc);
     run<16, 1, 0>("16x16x32 f16, random (3rd)", out, cyc);
     return 0;
 }
