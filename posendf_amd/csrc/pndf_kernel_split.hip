@@ -675,9 +675,11 @@ struct PhaseSel<1, false, KA2, CT, NC, NB, BWD, GTIME> { using type = HalfPhase<
 // their operand scale in `oscale`.
 template <int NT, bool SINGLE = false, bool SP = false>
 __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 2], uint32_t (&m)[(NT * 4 + 31) / 32], const SAct& act,
-                                                float fixed, float& bound, float& oscale) {
+                                                float fixed, float& bound, float& oscale, float& dmax) {
     constexpr int NW = (NT * 4 + 31) / 32;
+    dmax = 1.f;           // softplus: the pose's largest derivative in this layer (bounds its gradient in the backward pass)
     if constexpr (SP) {
+        float dm[4] = {0.f, 0.f, 0.f, 0.f};
         // softplus: activate first (true scale), then MEASURE the produced values: |z| + ln 2 / beta as a bound is loose by
         // many orders of magnitude for a pose whose units are all saturated low, and the padded units of a narrower
         // network (bias -1e6, pndf_load_weights) must not enter it; 128 extra multiplies against ~25 instructions per value
@@ -689,9 +691,11 @@ __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 
                 float dr;
                 x[t][r] = act_softplus(x[t][r] * act.to_true, act.beta, dr);
                 dv[r] = dr;
+                dm[r] = fmaxf(dm[r], dr);
             }
             *act.sp.slot(act.spslot + t) = dv;
         }
+        dmax = pose_max(fmaxf(fmaxf(dm[0], dm[1]), fmaxf(dm[2], dm[3])));
         bound = pose_max(tiles_absmax<NT>(x));
         oscale = fixed > 0.f ? fixed : pose_scale(bound);
 #pragma unroll
@@ -722,18 +726,16 @@ __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 
 // Backward counterpart: gradient accumulators x act' -> B operands, scale measured (|act'| <= 1).
 template <int NT, bool SINGLE = false, bool SP = false>
 __device__ __forceinline__ void dact_split_tiles(f32x4 (&gx)[NT], Blk (&out)[NT / 2], const uint32_t (&m)[(NT * 4 + 31) / 32], const SAct& act,
-                                                 float& bound, float& oscale) {
-    if constexpr (SP) {       // derivative in (0, 1]: applied BEFORE the bound is measured (a layer saturated low is tiny against |g|)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) gx[t] = gx[t] * *act.sp.slot(act.spslot + t);
-    }
-    bound = pose_max(tiles_absmax<NT>(gx)) * act.to_true;
+                                                 float dmax, float& bound, float& oscale) {
+    // |act' g| <= max act' * max |g|: `dmax` is the pose's largest derivative of this layer, measured in the forward pass
+    // (1 for the relu family).  One pass: the parked derivatives stream in while earlier tiles are split.
+    bound = pose_max(tiles_absmax<NT>(gx)) * act.to_true * dmax;
     oscale = pose_scale(bound);
     const float cf = act.to_true * oscale, k1 = (1.0f - act.slope) * cf, k0 = act.slope * cf;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if constexpr (SP) {
-            gx[t] = gx[t] * cf;
+            gx[t] = (gx[t] * cf) * *act.sp.slot(act.spslot + t);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -841,6 +843,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
         // softplus: per pose, the largest derivative of each chunk layer (x1, x3, x5), measured in the forward epilogues; the
         // backward pass shrinks the a-priori bound of that layer's gradient by it (SplitPhase::run).  1 for the relu family.
         float dmax1 = 1.f, dmax3 = 1.f, dmax5 = 1.f;
+        float dmax2 = 1.f, dmax4 = 1.f, dmax6 = 1.f;      // the same for the accumulator layers (act_split_tiles)
         {
             Blk b2[16];
             {
@@ -871,7 +874,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
                 const float dm = PhaseSel<TERMS, SP, 4, 2, 8, 32, false>::type::run(b0, x2, ring, lds_bias + BIAS_OFF[0], lds_mask + MASK_BASE[0] * WG_THREADS, layer(SP_SLOT_CHUNK[0], 0, sg_in, sg_ch), g);
                 if constexpr (SP) dmax1 = pose_max(dm);
                 tick<TIMING>(rc, 1);
-                act_split_tiles<32, SG, SP>(x2, b2, m2, layer(SP_SLOT_X2, 1, sg_ch, 0.f), 0.f, bnd, sg_in);
+                act_split_tiles<32, SG, SP>(x2, b2, m2, layer(SP_SLOT_X2, 1, sg_ch, 0.f), 0.f, bnd, sg_in, dmax2);
                 tick<TIMING>(rc, 2);
                 fwd_bound = bnd;
                 fwd_sigma = sg_in;
@@ -888,7 +891,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
             const float dm = PhaseSel<TERMS, SP, 16, 2, 32, 32, false, TIMING && TERMS == 3 && PNDF_GROUP_STAMPS>::type::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], 2, sg_in, sg_ch), g, &rc);
             if constexpr (SP) dmax3 = pose_max(dm);
             tick<TIMING>(rc, 3);
-            act_split_tiles<32, SG, SP>(x4, b4, m4, layer(SP_SLOT_X4, 3, sg_ch, 0.f), 0.f, bnd, sg_in);
+            act_split_tiles<32, SG, SP>(x4, b4, m4, layer(SP_SLOT_X4, 3, sg_ch, 0.f), 0.f, bnd, sg_in, dmax4);
             tick<TIMING>(rc, 4);
             fwd_bound = bnd;
             fwd_sigma = sg_in;
@@ -904,7 +907,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
             tick<TIMING>(rc, 5);
             Blk b6[2];
             float bnd6, sg6;
-            act_split_tiles<4, SG, SP>(x6, b6, m6, layer(SP_SLOT_X6, 5, sg_ch, 0.f), 1.0f, bnd6, sg6);   // b6 unused; x6 keeps TRUE values for lin6
+            act_split_tiles<4, SG, SP>(x6, b6, m6, layer(SP_SLOT_X6, 5, sg_ch, 0.f), 1.0f, bnd6, sg6, dmax6);   // b6 unused; x6 keeps TRUE values for lin6
         }
 
         // ---------------- lin6 (64 -> 1) + output ReLU, fp32 on the VALU
@@ -954,14 +957,14 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
                         SAct seed = layer(SP_SLOT_X6, 5, 1.0f, 0.f);
                         seed.to_true = 1.0f;                                                  // no accumulator scale to undo
                         float bnd, sg_in;
-                        dact_split_tiles<4, SG, SP>(g6, gb6, m6, seed, bnd, sg_in);
+                        dact_split_tiles<4, SG, SP>(g6, gb6, m6, seed, dmax6, bnd, sg_in);
                         tick<TIMING>(rc, 6);
                         const float sg_ch = pose_scale(nrm[6] * bnd * dmax5);                 // g5: |act' W5^T g6| <= max act' ||W5^T|| |g6|
                         f32x4 g4[32];
 #pragma unroll
                         for (int t = 0; t < 32; ++t) g4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                         PhaseSel<TERMS, SP, 2, 4, 4, 32, true>::type::run(gb6, g4, ring, nullptr, lds_mask + MASK_BASE[2] * WG_THREADS, layer(SP_SLOT_CHUNK[2], 5, sg_in, sg_ch), g);
-                        dact_split_tiles<32, SG, SP>(g4, gb4, m4, layer(SP_SLOT_X4, 4, sg_ch, 0.f), bwd_bound, bwd_sigma);
+                        dact_split_tiles<32, SG, SP>(g4, gb4, m4, layer(SP_SLOT_X4, 4, sg_ch, 0.f), dmax4, bwd_bound, bwd_sigma);
                         tick<TIMING>(rc, 7);
                     }
                     const float sg_ch = pose_scale(nrm[7] * bwd_bound * dmax3);               // g3
@@ -969,7 +972,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
 #pragma unroll
                     for (int t = 0; t < 32; ++t) g2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                     PhaseSel<TERMS, SP, 16, 2, 32, 32, true>::type::run(gb4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], 3, bwd_sigma, sg_ch), g);
-                    dact_split_tiles<32, SG, SP>(g2, gb2, m2, layer(SP_SLOT_X2, 2, sg_ch, 0.f), bwd_bound, bwd_sigma);
+                    dact_split_tiles<32, SG, SP>(g2, gb2, m2, layer(SP_SLOT_X2, 2, sg_ch, 0.f), dmax2, bwd_bound, bwd_sigma);
                     tick<TIMING>(rc, 8);
                 }
                 const float sg_ch = pose_scale(nrm[8] * bwd_bound * dmax1);                   // g1
