@@ -22,11 +22,13 @@ sys.path.insert(0, REPO)
 FLOP_PER_POSE_STEP = 5_450_416      # 2 x 1,362,604 MACs forward + the same for d d/d q
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (not the 2:1-sparse figure)
-# What dense fp16 MFMA actually sustains on this chip under its power limit with random operand data and NO memory
-# traffic (tools/ubench/mfma_power.hip, profiles/r02/mfma_power.txt: 1,676-1,706 TFLOP/s for both instruction shapes;
-# 2,245-2,484 with constant operands).  The split kernel is power-bound, so this -- not the
-# 2.5 PFLOP/s datasheet peak -- is the wall its ISSUED rate (3 MFMAs per product block) runs into.
-SUSTAINED_F16_MFMA_TFLOPS = 1680.0
+# What dense fp16 MFMA SUSTAINS on this chip under its power limit, with random operand data, one wave per SIMD, registers
+# only (tools/ubench/mfma_power.hip, profiles/r02/mfma_power.txt).  It depends on the issue pattern: 1,700 TFLOP/s when the
+# MFMAs rotate over eight accumulators, 2,200 on a single accumulator chain, 2,000 in the pattern the split kernel issues
+# (chains of three on one accumulator, the weight operand kept for two MFMAs); 2,245-2,484 with constant operands.  The
+# split kernel is power-bound, so this -- not the 2.5 PFLOP/s datasheet peak -- is the wall its
+# ISSUED rate (3 MFMAs per product block) runs into.
+SUSTAINED_F16_MFMA_TFLOPS = 2000.0
 KERNELS = {"fp32": ("pndf_fused_relu_kernel", PEAK_FP32_MFMA_TFLOPS, "f32"),
            "f16x3": ("pndf_fused_split_relu_kernel", PEAK_F16_MFMA_TFLOPS,
                      "f16x3 (fp32 operands split into fp16 hi+lo, 3 MFMAs per product block, fp32 accumulate)"),
@@ -358,8 +360,9 @@ def main():
                          "mfma_issued_per_algorithmic_flop": 3 if precision == "f16x3" else 1,
                          **({"issued_tflops": 3 * achieved, "sustained_mfma_wall_tflops": SUSTAINED_F16_MFMA_TFLOPS,
                              "frac_of_sustained_wall": 3 * achieved / SUSTAINED_F16_MFMA_TFLOPS,
-                             "wall_note": "dense fp16 MFMA with random operands sustains 1.68 PFLOP/s under the power limit "
-                                          "(tools/ubench/mfma_power.hip); the kernel is power-bound"}
+                             "wall_note": "dense fp16 MFMA with random operands, issued in the kernel's own pattern, sustains "
+                                          "2.0 PFLOP/s under the power limit (1.7 rotating over eight accumulators, 2.2 on one; "
+                                          "tools/ubench/mfma_power.hip); the kernel is power-bound"}
                             if precision == "f16x3" else {}),
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)",
                          "algorithmic_bytes_per_launch": B * 676 + 10720 * 1024,
