@@ -132,19 +132,19 @@ __device__ __forceinline__ void v32_group(Ring& ring, DmaSrc& src, uint32_t& dst
         acc0 = mf32(wh0, xh[XB], acc0);
         SB();
         group_events<TNEXT>(ring, src, dst);
-        nxt[0] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 4 * half));
+        nxt[0] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT));
         SB();
         acc1 = mf32(wh1, xh[XB + 1], acc1);
         SB();
-        nxt[1] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 4 * half + 1));
+        nxt[1] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 1));
         SB();
         acc0 = mf32(wh0, xl[XB], acc0);
         SB();
-        nxt[2] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 4 * half + 2));
+        nxt[2] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2));
         SB();
         acc1 = mf32(wh1, xl[XB + 1], acc1);
         SB();
-        nxt[3] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 4 * half + 3));
+        nxt[3] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 3));
         SB();
         acc0 = mf32(wl0, xh[XB], acc0);
         SB();
@@ -162,11 +162,11 @@ __device__ __forceinline__ void v32_group(Ring& ring, DmaSrc& src, uint32_t& dst
         a = mf32(wh, xh[XB + i], a);
         SB();
         if (i == 0) group_events<TNEXT>(ring, src, dst);
-        nxt[2 * i] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 4 * half + 2 * i));
+        nxt[2 * i] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2 * i));
         SB();
         a = mf32(wh, xl[XB + i], a);
         SB();
-        nxt[2 * i + 1] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 4 * half + 2 * i + 1));
+        nxt[2 * i + 1] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2 * i + 1));
         SB();
         a = mf32(wl, xh[XB + i], a);
         SB();
@@ -223,6 +223,7 @@ __global__ void __launch_bounds__(256, 1) k32(const char* stream, float* out, in
     ring_start(ring, wave);
     ring_wait_dma();
     __syncthreads();
+    ring.lane = lane + 256 * half;      // tile reads: this wave's four tiles of a half slot start at tile 4 * half (4 KiB = 256 x 16 B)
     f16x8 xh[16], xl[16];                              // this wave's half of the contraction: 16 k-blocks of 16, 32 poses
 #pragma unroll
     for (int i = 0; i < 16; ++i) { xh[i] = rand_operand(s, 1.0f); xl[i] = rand_operand(s, 4e-4f); }
@@ -233,7 +234,7 @@ __global__ void __launch_bounds__(256, 1) k32(const char* stream, float* out, in
     f16x8 yh[2] = {rand_operand(s, 1.0f), rand_operand(s, 1.0f)}, yl[2] = {rand_operand(s, 4e-4f), rand_operand(s, 4e-4f)};
     f16x8 cur[4];
     ring_boundary(ring);
-    for (int i = 0; i < 4; ++i) cur[i] = __builtin_bit_cast(f16x8, ring_tile(ring, 4 * half + i));
+    for (int i = 0; i < 4; ++i) cur[i] = __builtin_bit_cast(f16x8, ring_tile(ring, i));
     DmaSrc src{nullptr, 0u};
     uint32_t dst = 0;
     char* xch = smem + LDS_F;                            // exchange window: [wave][lane][32 B] x 2
@@ -262,7 +263,7 @@ __global__ void __launch_bounds__(256, 1) k32(const char* stream, float* out, in
 // A wave pair shares 32 poses as TWO 16-pose operand sets; a wave reads 8 of the 16 tiles of a slot and uses every weight
 // tile for both pose halves: per pair of tiles hh_p0 hh_p1 hl_p0 hl_p1 (A = Wh kept for FOUR MFMAs) lh_p0 lh_p1, on two
 // alternating accumulators.  Same MFMA count and time per slot as V16 (24 x 16 cycles), half the LDS reads.
-template <int TN, int XB, int NX, int NACC>
+template <int TN, int XB, int NX, int NACC, bool CHAIN = false>
 __device__ __forceinline__ void v32b_group(Ring& ring, DmaSrc& src, uint32_t& dst, f16x8 (&cur)[4], const f16x8 (&xh)[NX][2], const f16x8 (&xl)[NX][2],
                                            f32x4 (&acc)[NACC][2], int a0, int a1, int half) {
     f16x8 nxt[4];
@@ -273,14 +274,42 @@ __device__ __forceinline__ void v32b_group(Ring& ring, DmaSrc& src, uint32_t& ds
     for (int i = 0; i < 2; ++i) {
         const int a = i ? a1 : a0;
         const f16x8 wh = cur[2 * i], wl = cur[2 * i + 1];
+        if constexpr (CHAIN) {        // one pose half after the other: chains of three per accumulator, A = Wh kept for two only;
+                                      // all four tile reads of the next group behind the first four MFMAs of this one
+            acc[a][0] = mf16(wh, xh[XB + i][0], acc[a][0]);
+            SB();
+            if (i == 0) {
+                group_events<TNEXT>(ring, src, dst);
+                nxt[0] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT));
+            }
+            SB();
+            acc[a][0] = mf16(wh, xl[XB + i][0], acc[a][0]);
+            SB();
+            if (i == 0) nxt[1] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 1));
+            SB();
+            acc[a][0] = mf16(wl, xh[XB + i][0], acc[a][0]);
+            SB();
+            if (i == 0) nxt[2] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2));
+            SB();
+            acc[a][1] = mf16(wh, xh[XB + i][1], acc[a][1]);
+            SB();
+            if (i == 0) nxt[3] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 3));
+            if (i == 0) dma_two<TNEXT, 0>(src, dst);
+            else dma_two<TNEXT, 1>(src, dst);
+            SB();
+            acc[a][1] = mf16(wh, xl[XB + i][1], acc[a][1]);
+            acc[a][1] = mf16(wl, xh[XB + i][1], acc[a][1]);
+            SB();
+            continue;
+        }
         acc[a][0] = mf16(wh, xh[XB + i][0], acc[a][0]);
         SB();
         if (i == 0) group_events<TNEXT>(ring, src, dst);
-        nxt[2 * i] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 4 * half + 2 * i));
+        nxt[2 * i] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2 * i));
         SB();
         acc[a][1] = mf16(wh, xh[XB + i][1], acc[a][1]);
         SB();
-        nxt[2 * i + 1] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 4 * half + 2 * i + 1));
+        nxt[2 * i + 1] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2 * i + 1));
         SB();
         acc[a][0] = mf16(wh, xl[XB + i][0], acc[a][0]);
         acc[a][1] = mf16(wh, xl[XB + i][1], acc[a][1]);
@@ -295,14 +324,14 @@ __device__ __forceinline__ void v32b_group(Ring& ring, DmaSrc& src, uint32_t& ds
 #pragma unroll
     for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
 }
-template <int SL>
+template <int SL, bool CHAIN>
 __device__ __forceinline__ void v32b_slots(Ring& ring, DmaSrc& src, uint32_t& dst, f16x8 (&cur)[4], const f16x8 (&xh)[8][2], const f16x8 (&xl)[8][2],
                                            const f16x8 (&yh)[1][2], const f16x8 (&yl)[1][2], f32x4 (&ch)[2][2], f32x4 (&acc)[16][2],
                                            char* mine, const char* theirs, int half, int& slot) {
     if constexpr (SL < 8) {
         if constexpr (SL < 4) {       // part A: this wave's 8 k-blocks, two chunk tiles x two pose halves
-            v32b_group<0, (SL & 3) * 2, 8, 2>(ring, src, dst, cur, xh, xl, ch, 0, 1, half);
-            v32b_group<8, (SL & 3) * 2, 8, 2>(ring, src, dst, cur, xh, xl, ch, 0, 1, half);
+            v32b_group<0, (SL & 3) * 2, 8, 2, CHAIN>(ring, src, dst, cur, xh, xl, ch, 0, 1, half);
+            v32b_group<8, (SL & 3) * 2, 8, 2, CHAIN>(ring, src, dst, cur, xh, xl, ch, 0, 1, half);
         } else {                      // part B: this wave's 16 output tiles, one chunk k-block
             if constexpr (SL == 4) {  // exchange: partial chunk sums out, partner's in (stand-in for the epilogue)
                 *(f32x4*)(mine) = ch[1][0];
@@ -319,13 +348,14 @@ __device__ __forceinline__ void v32b_slots(Ring& ring, DmaSrc& src, uint32_t& ds
                 ch[1][0] = t * 1e-6f;
                 ch[1][1] = t * 1e-6f;
             }
-            v32b_group<0, 0, 1, 16>(ring, src, dst, cur, yh, yl, acc, (SL - 4) * 4, (SL - 4) * 4 + 1, half);
-            v32b_group<8, 0, 1, 16>(ring, src, dst, cur, yh, yl, acc, (SL - 4) * 4 + 2, (SL - 4) * 4 + 3, half);
+            v32b_group<0, 0, 1, 16, CHAIN>(ring, src, dst, cur, yh, yl, acc, (SL - 4) * 4, (SL - 4) * 4 + 1, half);
+            v32b_group<8, 0, 1, 16, CHAIN>(ring, src, dst, cur, yh, yl, acc, (SL - 4) * 4 + 2, (SL - 4) * 4 + 3, half);
         }
         if (++slot == STEP_SLOTS) { slot = 0; ring_next_step(ring); }
-        v32b_slots<SL + 1>(ring, src, dst, cur, xh, xl, yh, yl, ch, acc, mine, theirs, half, slot);
+        v32b_slots<SL + 1, CHAIN>(ring, src, dst, cur, xh, xl, yh, yl, ch, acc, mine, theirs, half, slot);
     }
 }
+template <bool CHAIN>
 __global__ void __launch_bounds__(256, 1) k32b(const char* stream, float* out, int nchunks, unsigned long long* cyc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -335,6 +365,7 @@ __global__ void __launch_bounds__(256, 1) k32b(const char* stream, float* out, i
     ring_start(ring, wave);
     ring_wait_dma();
     __syncthreads();
+    ring.lane = lane + 256 * half;      // tile reads: this wave's four tiles of a half slot start at tile 4 * half (4 KiB = 256 x 16 B)
     f16x8 xh[8][2], xl[8][2], yh[1][2], yl[1][2];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -350,7 +381,7 @@ __global__ void __launch_bounds__(256, 1) k32b(const char* stream, float* out, i
     f16x8 cur[4];
     ring_boundary(ring);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cur[i] = __builtin_bit_cast(f16x8, ring_tile(ring, 4 * half + i));
+    for (int i = 0; i < 4; ++i) cur[i] = __builtin_bit_cast(f16x8, ring_tile(ring, i));
     DmaSrc src{nullptr, 0u};
     uint32_t dst = 0;
     char* xch = smem + LDS_F;
@@ -358,7 +389,7 @@ __global__ void __launch_bounds__(256, 1) k32b(const char* stream, float* out, i
     const char* theirs = xch + (wave ^ 1) * 4096 + lane * 32;
     int slot = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (int c = 0; c < nchunks; ++c) v32b_slots<0>(ring, src, dst, cur, xh, xl, yh, yl, ch, acc, mine, theirs, half, slot);
+    for (int c = 0; c < nchunks; ++c) v32b_slots<0, CHAIN>(ring, src, dst, cur, xh, xl, yh, yl, ch, acc, mine, theirs, half, slot);
     if (threadIdx.x == 0) cyc[blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
     float r = ch[0][0][0] + ch[1][1][1];
 #pragma unroll
@@ -406,8 +437,9 @@ int main() {
         const float a = run(k16, "V16 (16 poses per wave)", stream, out, nchunks);
         const float b = run(k32<false>, "V32 pair-major chains", stream, out, nchunks);
         const float c = run(k32<true>, "V32 two accumulators interleaved", stream, out, nchunks);
-        const float d = run(k32b, "V32b 16x16x32, weight tile x2 halves", stream, out, nchunks);
-        printf("   time vs V16: V32 chains %.3f  V32 interleaved %.3f  V32b %.3f\n", b / a, c / a, d / a);
+        const float d = run(k32b<false>, "V32b 16x16x32, Wh kept x4", stream, out, nchunks);
+        const float e = run(k32b<true>, "V32b 16x16x32, chains of three", stream, out, nchunks);
+        printf("   time vs V16: V32 chains %.3f  V32 interleaved %.3f  V32b %.3f  V32b chains %.3f\n", b / a, c / a, d / a, e / a);
     }
     return 0;
 }
