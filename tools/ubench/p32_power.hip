@@ -47,7 +47,7 @@ __device__ __forceinline__ void dma_two(const DmaSrc& src, uint32_t dst) {
 }  // namespace
 
 // ------------------------------------------------------------------ V16
-template <int TN, int XB, int BASE, bool PART_A>
+template <int TN, int XB, int BASE, bool PART_A, bool HALFREADS = false>
 __device__ __forceinline__ void v16_group(Ring& ring, DmaSrc& src, uint32_t& dst, f16x8 (&cur)[8], const f16x8 (&xh)[16], const f16x8 (&xl)[16],
                                           f32x4 (&acc)[32]) {
     f16x8 nxt[8];
@@ -62,11 +62,13 @@ __device__ __forceinline__ void v16_group(Ring& ring, DmaSrc& src, uint32_t& dst
         acc[a] = mf16(wh, xh[XB + i], acc[a]);
         SB();
         if (i == 0) group_events<TNEXT>(ring, src, dst);
-        nxt[2 * i] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2 * i));
+        if (!HALFREADS || i < 2) nxt[2 * i] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2 * i));
+        else nxt[2 * i] = nxt[2 * i - 4];                 // (diagnostic arm: V16's MFMA structure with pair-32's read volume)
         SB();
         acc[a] = mf16(wh, xl[XB + i], acc[a]);
         SB();
-        nxt[2 * i + 1] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2 * i + 1));
+        if (!HALFREADS || i < 2) nxt[2 * i + 1] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2 * i + 1));
+        else nxt[2 * i + 1] = nxt[2 * i - 3];
         SB();
         acc[a] = mf16(wl, xh[XB + i], acc[a]);
         SB();
@@ -78,17 +80,18 @@ __device__ __forceinline__ void v16_group(Ring& ring, DmaSrc& src, uint32_t& dst
     for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
 }
 
-template <int SL>
+template <int SL, bool HR>
 __device__ __forceinline__ void v16_slots(Ring& ring, DmaSrc& src, uint32_t& dst, f16x8 (&cur)[8], const f16x8 (&xh)[16], const f16x8 (&xl)[16],
                                           f32x4 (&acc)[32], int& slot) {
     if constexpr (SL < 8) {
-        v16_group<0, (SL & 3) * 4, SL * 8, (SL < 4)>(ring, src, dst, cur, xh, xl, acc);
-        v16_group<8, (SL & 3) * 4, SL * 8 + 4, (SL < 4)>(ring, src, dst, cur, xh, xl, acc);
+        v16_group<0, (SL & 3) * 4, SL * 8, (SL < 4), HR>(ring, src, dst, cur, xh, xl, acc);
+        v16_group<8, (SL & 3) * 4, SL * 8 + 4, (SL < 4), HR>(ring, src, dst, cur, xh, xl, acc);
         if (++slot == STEP_SLOTS) { slot = 0; ring_next_step(ring); }
-        v16_slots<SL + 1>(ring, src, dst, cur, xh, xl, acc, slot);
+        v16_slots<SL + 1, HR>(ring, src, dst, cur, xh, xl, acc, slot);
     }
 }
 
+template <bool HR>
 __global__ void __launch_bounds__(256, 1) k16(const char* stream, float* out, int nchunks, unsigned long long* cyc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -110,7 +113,7 @@ __global__ void __launch_bounds__(256, 1) k16(const char* stream, float* out, in
     uint32_t dst = 0;
     int slot = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (int c = 0; c < nchunks; ++c) v16_slots<0>(ring, src, dst, cur, xh, xl, acc, slot);
+    for (int c = 0; c < nchunks; ++c) v16_slots<0, HR>(ring, src, dst, cur, xh, xl, acc, slot);
     if (threadIdx.x == 0) cyc[blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
     float r = 0;
     for (int i = 0; i < 32; ++i) r += acc[i][0] + acc[i][3];
@@ -434,7 +437,8 @@ int main() {
     hipMemcpy(stream, h, bytes, hipMemcpyHostToDevice);
     const int nchunks = 3200;                                 // = 100 steps of the 32-chunk phase
     for (int rep = 0; rep < 2; ++rep) {
-        const float a = run(k16, "V16 (16 poses per wave)", stream, out, nchunks);
+        const float a = run(k16<false>, "V16 (16 poses per wave)", stream, out, nchunks);
+        run(k16<true>, "V16 with half the tile reads (diag)", stream, out, nchunks);
         const float b = run(k32<false>, "V32 pair-major chains", stream, out, nchunks);
         const float c = run(k32<true>, "V32 two accumulators interleaved", stream, out, nchunks);
         const float d = run(k32b<false>, "V32b 16x16x32, Wh kept x4", stream, out, nchunks);
