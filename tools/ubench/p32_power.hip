@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(256, 1) k32(const char* stream, float* out, in
 // A wave pair shares 32 poses as TWO 16-pose operand sets; a wave reads 8 of the 16 tiles of a slot and uses every weight
 // tile for both pose halves: per pair of tiles hh_p0 hh_p1 hl_p0 hl_p1 (A = Wh kept for FOUR MFMAs) lh_p0 lh_p1, on two
 // alternating accumulators.  Same MFMA count and time per slot as V16 (24 x 16 cycles), half the LDS reads.
-template <int TN, int XB, int NX, int NACC, bool CHAIN = false>
+template <int TN, int XB, int NX, int NACC, bool CHAIN = false, int DIAG = 0>
 __device__ __forceinline__ void v32b_group(Ring& ring, DmaSrc& src, uint32_t& dst, f16x8 (&cur)[4], const f16x8 (&xh)[NX][2], const f16x8 (&xl)[NX][2],
                                            f32x4 (&acc)[NACC][2], int a0, int a1, int half) {
     f16x8 nxt[4];
@@ -294,14 +294,16 @@ __device__ __forceinline__ void v32b_group(Ring& ring, DmaSrc& src, uint32_t& ds
             SB();
             if (i == 0) nxt[2] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2));
             SB();
-            acc[a][1] = mf16(wh, xh[XB + i][1], acc[a][1]);
+            constexpr int P1 = (DIAG == 1) ? 0 : 1;       // (diag 1: the second pose half reuses the first one's operands)
+            constexpr int A1 = (DIAG == 2) ? 0 : 1;       // (diag 2: both pose halves accumulate onto one accumulator)
+            acc[a][A1] = mf16(wh, xh[XB + i][P1], acc[a][A1]);
             SB();
             if (i == 0) nxt[3] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 3));
             if (i == 0) dma_two<TNEXT, 0>(src, dst);
             else dma_two<TNEXT, 1>(src, dst);
             SB();
-            acc[a][1] = mf16(wh, xl[XB + i][1], acc[a][1]);
-            acc[a][1] = mf16(wl, xh[XB + i][1], acc[a][1]);
+            acc[a][A1] = mf16(wh, xl[XB + i][P1], acc[a][A1]);
+            acc[a][A1] = mf16(wl, xh[XB + i][P1], acc[a][A1]);
             SB();
             continue;
         }
@@ -327,14 +329,14 @@ __device__ __forceinline__ void v32b_group(Ring& ring, DmaSrc& src, uint32_t& ds
 #pragma unroll
     for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
 }
-template <int SL, bool CHAIN>
+template <int SL, bool CHAIN, int DIAG>
 __device__ __forceinline__ void v32b_slots(Ring& ring, DmaSrc& src, uint32_t& dst, f16x8 (&cur)[4], const f16x8 (&xh)[8][2], const f16x8 (&xl)[8][2],
                                            const f16x8 (&yh)[1][2], const f16x8 (&yl)[1][2], f32x4 (&ch)[2][2], f32x4 (&acc)[16][2],
                                            char* mine, const char* theirs, int half, int& slot) {
     if constexpr (SL < 8) {
         if constexpr (SL < 4) {       // part A: this wave's 8 k-blocks, two chunk tiles x two pose halves
-            v32b_group<0, (SL & 3) * 2, 8, 2, CHAIN>(ring, src, dst, cur, xh, xl, ch, 0, 1, half);
-            v32b_group<8, (SL & 3) * 2, 8, 2, CHAIN>(ring, src, dst, cur, xh, xl, ch, 0, 1, half);
+            v32b_group<0, (SL & 3) * 2, 8, 2, CHAIN, DIAG>(ring, src, dst, cur, xh, xl, ch, 0, 1, half);
+            v32b_group<8, (SL & 3) * 2, 8, 2, CHAIN, DIAG>(ring, src, dst, cur, xh, xl, ch, 0, 1, half);
         } else {                      // part B: this wave's 16 output tiles, one chunk k-block
             if constexpr (SL == 4) {  // exchange: partial chunk sums out, partner's in (stand-in for the epilogue)
                 *(f32x4*)(mine) = ch[1][0];
@@ -351,14 +353,14 @@ __device__ __forceinline__ void v32b_slots(Ring& ring, DmaSrc& src, uint32_t& ds
                 ch[1][0] = t * 1e-6f;
                 ch[1][1] = t * 1e-6f;
             }
-            v32b_group<0, 0, 1, 16, CHAIN>(ring, src, dst, cur, yh, yl, acc, (SL - 4) * 4, (SL - 4) * 4 + 1, half);
-            v32b_group<8, 0, 1, 16, CHAIN>(ring, src, dst, cur, yh, yl, acc, (SL - 4) * 4 + 2, (SL - 4) * 4 + 3, half);
+            v32b_group<0, 0, 1, 16, CHAIN, DIAG>(ring, src, dst, cur, yh, yl, acc, (SL - 4) * 4, (SL - 4) * 4 + 1, half);
+            v32b_group<8, 0, 1, 16, CHAIN, DIAG>(ring, src, dst, cur, yh, yl, acc, (SL - 4) * 4 + 2, (SL - 4) * 4 + 3, half);
         }
         if (++slot == STEP_SLOTS) { slot = 0; ring_next_step(ring); }
-        v32b_slots<SL + 1, CHAIN>(ring, src, dst, cur, xh, xl, yh, yl, ch, acc, mine, theirs, half, slot);
+        v32b_slots<SL + 1, CHAIN, DIAG>(ring, src, dst, cur, xh, xl, yh, yl, ch, acc, mine, theirs, half, slot);
     }
 }
-template <bool CHAIN>
+template <bool CHAIN, int DIAG = 0>
 __global__ void __launch_bounds__(256, 1) k32b(const char* stream, float* out, int nchunks, unsigned long long* cyc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -392,7 +394,7 @@ __global__ void __launch_bounds__(256, 1) k32b(const char* stream, float* out, i
     const char* theirs = xch + (wave ^ 1) * 4096 + lane * 32;
     int slot = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (int c = 0; c < nchunks; ++c) v32b_slots<0, CHAIN>(ring, src, dst, cur, xh, xl, yh, yl, ch, acc, mine, theirs, half, slot);
+    for (int c = 0; c < nchunks; ++c) v32b_slots<0, CHAIN, DIAG>(ring, src, dst, cur, xh, xl, yh, yl, ch, acc, mine, theirs, half, slot);
     if (threadIdx.x == 0) cyc[blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
     float r = ch[0][0][0] + ch[1][1][1];
 #pragma unroll
@@ -443,6 +445,8 @@ int main() {
         const float c = run(k32<true>, "V32 two accumulators interleaved", stream, out, nchunks);
         const float d = run(k32b<false>, "V32b 16x16x32, Wh kept x4", stream, out, nchunks);
         const float e = run(k32b<true>, "V32b 16x16x32, chains of three", stream, out, nchunks);
+        run(k32b<true, 1>, "  diag: same B for both halves", stream, out, nchunks);
+        run(k32b<true, 2>, "  diag: one accumulator per pair", stream, out, nchunks);
         printf("   time vs V16: V32 chains %.3f  V32 interleaved %.3f  V32b %.3f  V32b chains %.3f\n", b / a, c / a, d / a, e / a);
     }
     return 0;
