@@ -47,7 +47,7 @@ __device__ __forceinline__ void dma_two(const DmaSrc& src, uint32_t dst) {
 }  // namespace
 
 // ------------------------------------------------------------------ V16
-template <int TN, int XB, int BASE, bool PART_A, bool HALFREADS = false>
+template <int TN, int XB, int BASE, bool PART_A, bool HALFREADS = false, bool CHAIN6 = false>
 __device__ __forceinline__ void v16_group(Ring& ring, DmaSrc& src, uint32_t& dst, f16x8 (&cur)[8], const f16x8 (&xh)[16], const f16x8 (&xl)[16],
                                           f32x4 (&acc)[32]) {
     f16x8 nxt[8];
@@ -57,7 +57,8 @@ __device__ __forceinline__ void v16_group(Ring& ring, DmaSrc& src, uint32_t& dst
     SB();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int a = PART_A ? (i & 1) : ((BASE + i) & 31);
+        // CHAIN6 (diagnostic): part B visits every accumulator for two pairs in a row, as chunks of four tiles would
+        const int a = PART_A ? (i & 1) : CHAIN6 ? (((BASE + i) >> 1) & 31) : ((BASE + i) & 31);
         const f16x8 wh = cur[2 * i], wl = cur[2 * i + 1];
         acc[a] = mf16(wh, xh[XB + i], acc[a]);
         SB();
@@ -80,18 +81,18 @@ __device__ __forceinline__ void v16_group(Ring& ring, DmaSrc& src, uint32_t& dst
     for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
 }
 
-template <int SL, bool HR>
+template <int SL, bool HR, bool C6 = false>
 __device__ __forceinline__ void v16_slots(Ring& ring, DmaSrc& src, uint32_t& dst, f16x8 (&cur)[8], const f16x8 (&xh)[16], const f16x8 (&xl)[16],
                                           f32x4 (&acc)[32], int& slot) {
     if constexpr (SL < 8) {
-        v16_group<0, (SL & 3) * 4, SL * 8, (SL < 4), HR>(ring, src, dst, cur, xh, xl, acc);
-        v16_group<8, (SL & 3) * 4, SL * 8 + 4, (SL < 4), HR>(ring, src, dst, cur, xh, xl, acc);
+        v16_group<0, (SL & 3) * 4, SL * 8, (SL < 4), HR, C6>(ring, src, dst, cur, xh, xl, acc);
+        v16_group<8, (SL & 3) * 4, SL * 8 + 4, (SL < 4), HR, C6>(ring, src, dst, cur, xh, xl, acc);
         if (++slot == STEP_SLOTS) { slot = 0; ring_next_step(ring); }
-        v16_slots<SL + 1, HR>(ring, src, dst, cur, xh, xl, acc, slot);
+        v16_slots<SL + 1, HR, C6>(ring, src, dst, cur, xh, xl, acc, slot);
     }
 }
 
-template <bool HR>
+template <bool HR, bool C6 = false>
 __global__ void __launch_bounds__(256, 1) k16(const char* stream, float* out, int nchunks, unsigned long long* cyc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(256, 1) k16(const char* stream, float* out, in
     uint32_t dst = 0;
     int slot = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (int c = 0; c < nchunks; ++c) v16_slots<0, HR>(ring, src, dst, cur, xh, xl, acc, slot);
+    for (int c = 0; c < nchunks; ++c) v16_slots<0, HR, C6>(ring, src, dst, cur, xh, xl, acc, slot);
     if (threadIdx.x == 0) cyc[blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
     float r = 0;
     for (int i = 0; i < 32; ++i) r += acc[i][0] + acc[i][3];
@@ -441,6 +442,7 @@ int main() {
     for (int rep = 0; rep < 2; ++rep) {
         const float a = run(k16<false>, "V16 (16 poses per wave)", stream, out, nchunks);
         run(k16<true>, "V16 with half the tile reads (diag)", stream, out, nchunks);
+        run(k16<false, true>, "V16, part B chains of six (diag)", stream, out, nchunks);
         const float b = run(k32<false>, "V32 pair-major chains", stream, out, nchunks);
         const float c = run(k32<true>, "V32 two accumulators interleaved", stream, out, nchunks);
         const float d = run(k32b<false>, "V32b 16x16x32, Wh kept x4", stream, out, nchunks);
