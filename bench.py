@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpu-torch-baseline", action="store_true")
+    ap.add_argument("--no-parity-sample", action="store_true", help="skip the oracle check of a sample of the timed result")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)                                       # does not return
@@ -237,6 +238,30 @@ def main():
         k = torch.tensor([kern_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         kern_ms = float(k.item())
+
+    # What was timed is also CHECKED: a sample of the projected poses of the last timed pass against the oracle's fp64
+    # trajectory of the same inputs, with the reference arithmetic's own fp32 trajectory beside it (outside the timed region;
+    # rank 0 only, like the cpu_baseline leg).
+    def parity_sample(n=128):
+        from oracle import posendf_np as onp
+        idx = np.random.default_rng(0).choice(B, min(n, B), replace=False)
+        q_in = q0[idx].cpu().numpy()
+        q64, _ = onp.project(q_in, sd, steps=args.proj_steps, act=args.act, dtype=np.float64)
+        q32, _ = onp.project(q_in, sd, steps=args.proj_steps, act=args.act)
+
+        def rows(a):
+            a = np.asarray(a, np.float64).reshape(len(idx), -1)
+            b = q64.reshape(len(idx), -1)
+            return np.abs(a - b).max(1) / np.maximum(np.abs(b).max(1), 1e-30)
+
+        mine, ref = rows(qp[idx].cpu().numpy()), rows(q32)
+        return {"what": f"{len(idx)} poses of the last timed pass vs the numpy oracle's fp64 {args.proj_steps}-step trajectory "
+                        "(per-pose max |dq| / max |q|); `reference_fp32` = the reference arithmetic's own fp32 trajectory",
+                "median": float(np.median(mine)), "p95": float(np.percentile(mine, 95)), "max": float(mine.max()),
+                "reference_fp32": {"median": float(np.median(ref)), "p95": float(np.percentile(ref, 95)), "max": float(ref.max())},
+                "tolerance": 1e-4, "within_tolerance_frac": float((mine <= 1e-4).mean())}
+
+    parity = parity_sample() if (rank == 0 and not args.no_parity_sample) else None
 
     # the exact-fp32 and the plain-fp16 kernels beside the split-precision one (same inputs, short runs, outside the
     # timed region): the three points of BASELINE.json configs[2] "fp32 vs bf16"
@@ -327,11 +352,15 @@ def main():
         kname = net._engine_for(dev).kernel_name()
         # HBM traffic of the dominant kernel: from the committed PMC passes of the same command
         # (tools/gpu_profile.sh -> profiles/traffic.json); bench.py itself cannot run rocprofv3
-        traffic = None
+        traffic, traffic_stale = None, None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
         if os.path.exists(tpath) and B == 65536 and args.proj_steps == 100:
+            from posendf_amd.build_id import source_id
             with open(tpath) as f:
-                traffic = (json.load(f).get(kname) or {}).get("hbm_bytes_per_launch")
+                entry = json.load(f).get(kname) or {}
+            traffic = entry.get("hbm_bytes_per_launch")
+            # the PMC passes are a separate rocprofv3 run (tools/gpu_profile.sh): tie them to the sources that run now
+            traffic_stale = entry.get("source_id") != source_id()
         total = B * world * args.steps
         achieved = B * args.proj_steps * FLOP_PER_POSE_STEP / (kern_ms * 1e-3) / 1e12
         out = {
@@ -356,7 +385,7 @@ def main():
                        "global_batch": B * world, "proj_steps": args.proj_steps,
                        "parallelism": f"batch-sharded x{world}, final RCCL all_gather" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_stale": traffic_stale,
                          "mfma_issued_per_algorithmic_flop": 3 if precision == "f16x3" else 1,
                          **({"issued_tflops": 3 * achieved, "sustained_mfma_wall_tflops": SUSTAINED_F16_MFMA_TFLOPS,
                              "frac_of_sustained_wall": 3 * achieved / SUSTAINED_F16_MFMA_TFLOPS,
@@ -370,6 +399,8 @@ def main():
                          "kernel_ms_median": float(np.median([a.elapsed_time(b) for a, b in ev])) if args.steps else None,
                          "algorithmic_flop_per_launch": B * args.proj_steps * FLOP_PER_POSE_STEP},
         }
+        if parity is not None:
+            out["parity_sample"] = parity
         if host_ms is not None:
             out["host_boundary"] = {"what": "pinned host poses -> device, project(), device -> pinned host (median of 3)",
                                     "ms": host_ms, "poses_per_s": B / (host_ms * 1e-3)}

@@ -142,6 +142,14 @@ int pndf_denoise_update(const float* theta_in, float* theta_out, const float* th
                         float* m, float* v, float* q_next, int32_t S, int32_t T, int32_t it, int32_t adam_step, float lr,
                         void* stream);
 
+/* The same Adam step with the gradient of the BODY-MODEL terms (SMPL vertex temporal term + joint data term,
+ * motion_denoise.py:86-94) in place of the pose-space surrogates: g_body [S,T,69] = d(weighted temp + data terms)/d theta as
+ * produced by pndf_lbs_terms_grad (below).  All 23 joints of the body pose are updated (the surrogates leave the two hand
+ * joints alone; the body model moves vertices with them). */
+int pndf_denoise_update_body(const float* theta_in, float* theta_out, const float* theta0, const float* d, const float* dq,
+                             const float* g_body, float* m, float* v, float* q_next, int32_t S, int32_t T, int32_t it,
+                             int32_t adam_step, float lr, void* stream);
+
 /* ---- quaternion pose distance + k nearest candidates (data/dist_utils.py:9-50, classes euc / geo; caller
  * data/prepare_traindata.py:159).  noise [B,21,4], valid [B,K,21,4] (device, 16-byte aligned);
  * metric 0 = geo: sum_j w_j (1 - |<q_valid_j, q_noise_j>|), 1 = euc: sum_j w_j ||q_noise_j - q_valid_j||;

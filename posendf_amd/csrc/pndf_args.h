@@ -1,0 +1,59 @@
+// The ONE definition of every kernel-argument struct of the library.  Each struct is filled by a C-ABI entry point
+// (pndf_capi.hip, pndf_denoise.hip, pndf_quatdist.hip, pndf_lbs.hip) and read by a __global__ function that may live in
+// another translation unit: both sides include this header, and the static_asserts pin the layout the kernels were
+// written against (a silent mismatch between two copies would corrupt every launch).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+enum { MODE_FORWARD = 0, MODE_FORWARD_GRAD = 1, MODE_PROJECT = 2 };
+
+struct PndfKernelArgs {
+    const float* q_in;      // [B,84]
+    float* q_out;           // [B,84]  projected poses (PROJECT) or dd/dq * grad_out (FORWARD_GRAD)
+    float* d_out;           // [B]
+    const float* grad_out;  // [B] or null (FORWARD_GRAD only)
+    const char* stream;     // packed trunk weights, STEP_TILES KiB (+ a replica of the first ring slots)
+    const float* bias;      // BIAS_FLOATS
+    float* dbg;             // null, or DBG_TOTAL*256 floats written by workgroup 0 (first step) / timing stamps
+    long long B;
+    int steps;
+    int mode;               // MODE_FORWARD / MODE_FORWARD_GRAD / MODE_PROJECT (pndf_device.h)
+    float slope;            // 0 = relu, 0.01 = lrelu
+    float beta;             // softplus beta
+    float* scratch;         // softplus: gridDim.x * SP_WG_FLOATS floats of derivative scratch, else null
+    int reserved0;
+    int noenc;              // 1 = model.StrEnc.use False: the trunk sees the normalised quaternions (in_dim 84)
+};
+static_assert(sizeof(PndfKernelArgs) == 96, "PndfKernelArgs layout");
+static_assert(offsetof(PndfKernelArgs, stream) == 32 && offsetof(PndfKernelArgs, B) == 56 &&
+              offsetof(PndfKernelArgs, steps) == 64 && offsetof(PndfKernelArgs, slope) == 72 &&
+              offsetof(PndfKernelArgs, scratch) == 80 && offsetof(PndfKernelArgs, noenc) == 92, "PndfKernelArgs layout");
+
+struct PndfDenoiseArgs {
+    const float* theta_in; // [S,T,69] current poses (read: a frame's neighbours belong to other threads / workgroups)
+    float* theta_out;      // [S,T,69] updated poses (the caller swaps the two buffers every step)
+    const float* theta0;   // [S,T,69] the noisy input (data term of the pose-space surrogate)
+    const float* d;        // [S*T] engine distances of the current theta
+    const float* dq;       // [S*T,84] engine d d / d q (unit grad_outputs)
+    float* m;              // Adam first moment  [S,T,69]
+    float* v;              // Adam second moment [S,T,69]
+    float* q_next;         // [S*T,84] quaternions of the UPDATED theta
+    const float* g_extra;  // null, or [S,T,69]: gradient of the body-model terms (pndf_lbs_terms_grad), already weighted;
+                           //   when given, the pose-space surrogate terms are NOT added
+    int S, T, it, adam_step;
+    float lr, beta1, beta2, eps;
+};
+static_assert(sizeof(PndfDenoiseArgs) == 104 && offsetof(PndfDenoiseArgs, g_extra) == 64 &&
+              offsetof(PndfDenoiseArgs, S) == 72 && offsetof(PndfDenoiseArgs, lr) == 88, "PndfDenoiseArgs layout");
+
+struct PndfQuatDistArgs {
+    const float* noise;    // [B,21,4]
+    const float* valid;    // [B,K,21,4]
+    float* vals;           // [B,k]
+    long long* idx;        // [B,k]
+    int K, k, metric;      // metric 0 = geo, 1 = euc
+    float w[21];           // joint weights (1/21 each when unweighted)
+};
+static_assert(sizeof(PndfQuatDistArgs) == 128 && offsetof(PndfQuatDistArgs, K) == 32 &&
+              offsetof(PndfQuatDistArgs, w) == 44, "PndfQuatDistArgs layout");

@@ -12,28 +12,11 @@
 
 #include "../../include/posendf_amd.h"
 #include "pndf_layout.h"
+#include "pndf_args.h"
 #include "pndf_host.h"
 
 using namespace pndf;
 
-// must match pndf_kernel.hip
-struct PndfKernelArgs {
-    const float* q_in;
-    float* q_out;
-    float* d_out;
-    const float* grad_out;
-    const char* stream;
-    const float* bias;
-    float* dbg;
-    long long B;
-    int steps;
-    int mode;
-    float slope;
-    float beta;
-    float* scratch;
-    int reserved0;
-    int noenc;
-};
 extern "C" __global__ void pndf_fused_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_softplus_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_split_relu_kernel(PndfKernelArgs args);
@@ -51,7 +34,6 @@ extern "C" __global__ void pndf_fused_relu_kernel_dbg(PndfKernelArgs args);
 extern "C" int pndf_kernel_lds_bytes();
 extern "C" int pndf_kernel_dbg_floats();
 
-enum { MODE_FORWARD = 0, MODE_FORWARD_GRAD = 1, MODE_PROJECT = 2 };
 
 struct pndf_engine {
     pndf_config cfg;
@@ -146,7 +128,11 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
     pndf_engine* h = new pndf_engine();
     h->cfg = *cfg;
     h->device = device;
-    h->resident_wgs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (prop.multiProcessorCount <= 0) {
+        delete h;
+        return fail(nullptr, PNDF_ERR_HIP, "the device reports no compute units (multiProcessorCount <= 0)");
+    }
+    h->resident_wgs = prop.multiProcessorCount;
     hipError_t e = hipMalloc((void**)&h->d_stream, (size_t)(STEP_TILES + STREAM_PAD_SLOTS * SLOT_TILES) * TILE_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias, BIAS_FLOATS * sizeof(float));
     if (e == hipSuccess && cfg->act == PNDF_ACT_SOFTPLUS) {
@@ -511,6 +497,14 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
     if (!guard.ok) return fail(h, PNDF_ERR_HIP, "hipSetDevice failed");
     const bool softplus = h->cfg.act == PNDF_ACT_SOFTPLUS;
     if (a.noenc && dbg && !timing) return fail(h, PNDF_ERR_UNSUPPORTED, "the stage-dump kernel expects the structure encoder");
+    // the instrumented kernels exist for the three-term split kernels (relu family and softplus), the plain-f16 and the fp32
+    // relu-family kernel: refuse everything else rather than time another kernel than pndf_kernel_name() reports
+    if (timing && h->cfg.precision == PNDF_PREC_F16X3 && h->lo_all_zero)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "no instrumented build of the two-term split kernels (set PNDF_THREE_TERMS=1 to time the three-term ones)");
+    if (timing && softplus && h->cfg.precision != PNDF_PREC_F16X3)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "softplus timing kernel: f16x3 only");
+    if (timing && softplus && B > (int64_t)WG_POSES * h->resident_wgs)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "softplus timing kernel: at most one 64-pose block per compute unit");
     if (softplus && dbg && !(timing && h->cfg.precision == PNDF_PREC_F16X3))
         return fail(h, PNDF_ERR_UNSUPPORTED, "the debug dump exists for the relu-family kernel only");
     if (mode == MODE_PROJECT && steps == 0) {
@@ -591,7 +585,5 @@ extern "C" int pndf_debug_timing_regions(void) { return pndf_kernel_timing_regio
 extern "C" int pndf_debug_project_timing(pndf_handle h, const float* q_in, float* q_out, int64_t B, int steps,
                                          unsigned long long* cycles, void* stream) {
     if (!cycles) return fail(h, PNDF_ERR_BAD_ARG, "cycles is null");
-    if (h && h->cfg.act == PNDF_ACT_SOFTPLUS && (h->cfg.precision != PNDF_PREC_F16X3 || B > (int64_t)WG_POSES * h->resident_wgs))
-        return fail(h, PNDF_ERR_UNSUPPORTED, "softplus timing kernel: f16x3 only, at most one 64-pose block per compute unit");
     return launch(h, MODE_PROJECT, q_in, nullptr, q_out, nullptr, B, steps, (float*)cycles, stream, true);
 }

@@ -13,12 +13,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pndf_args.h"
 #include "pndf_host.h"
 
 namespace {
 
 constexpr int NJ = 21, NJ_ALL = 23, TH = 69, NQ = 84;
-constexpr int FRAMES_PER_WG = 12, WG = 256;
+constexpr int FRAMES_PER_WG = 11, WG = 256;      // 11 frames x 23 joints = 253 threads
 
 // pytorch3d.transforms.axis_angle_to_quaternion restated from its documented convention (parity unpinned)
 __device__ __forceinline__ void aa2quat(float ax, float ay, float az, float& k, float& angle, float (&q)[4]) {
@@ -46,19 +47,6 @@ extern "C" __global__ void __launch_bounds__(256) pndf_aa2quat_kernel(const floa
     *(float4*)(q + n * NQ + 4 * j) = make_float4(qq[0], qq[1], qq[2], qq[3]);
 }
 
-struct PndfDenoiseArgs {
-    const float* theta_in; // [S,T,69] current poses (read: a frame's neighbours belong to other threads / workgroups)
-    float* theta_out;      // [S,T,69] updated poses (the caller swaps the two buffers every step)
-    const float* theta0;   // [S,T,69] the noisy input (data term)
-    const float* d;        // [S*T] engine distances of the current theta
-    const float* dq;       // [S*T,84] engine d d / d q (unit grad_outputs)
-    float* m;              // Adam first moment  [S,T,69]
-    float* v;              // Adam second moment [S,T,69]
-    float* q_next;         // [S*T,84] quaternions of the UPDATED theta
-    int S, T, it, adam_step;
-    float lr, beta1, beta2, eps;
-};
-
 extern "C" __global__ void __launch_bounds__(WG) pndf_denoise_update_kernel(PndfDenoiseArgs a) {
     __shared__ float red[WG];
     const int s = blockIdx.y, tid = threadIdx.x;
@@ -74,50 +62,62 @@ extern "C" __global__ void __launch_bounds__(WG) pndf_denoise_update_kernel(Pndf
     }
     const float c = red[0] / (float)T;
 
-    const int f = tid / NJ, j = tid - f * NJ;
+    // one thread per (frame, joint of the 23 of SMPL's body pose); the pose prior and the pose-space surrogates see the
+    // first 21 (motion_denoise.py:81), the body-model terms (g_extra) all 23
+    const int f = tid / NJ_ALL, j = tid - f * NJ_ALL;
     const int t = blockIdx.x * FRAMES_PER_WG + f;
     if (f >= FRAMES_PER_WG || t >= T) return;
     const long long n = (long long)s * T + t;
     const float* th = a.theta_in + n * TH + 3 * j;
     const float x = th[0], y = th[1], z = th[2];
+    float gx = 0.f, gy = 0.f, gz = 0.f;
 
-    // ---- pose prior: d/d theta of 1e7 c^2 / (1+it)  =  2e7 c / ((1+it) T) * J^T(theta) d d/d q
-    float k, angle, qq[4];
-    aa2quat(x, y, z, k, angle, qq);
-    const float4 g4 = *(const float4*)(a.dq + n * NQ + 4 * j);
-    // k'(angle) / angle: (cos(angle/2)/2 - k) / angle^2, series -1/24 below the small-angle switch
-    const float kp = (angle < 1e-6f) ? (-1.0f / 24.0f) : ((0.5f * qq[0] - k) / (angle * angle));
-    const float gv_dot_a = g4.y * x + g4.z * y + g4.w * z;
-    const float common = -0.5f * k * g4.x + kp * gv_dot_a;
-    const float wp = 2.0e7f * c / ((float)(1 + a.it) * (float)T);
-    float gx = wp * (common * x + k * g4.y);
-    float gy = wp * (common * y + k * g4.z);
-    float gz = wp * (common * z + k * g4.w);
-
-    // ---- temporal surrogate: 10 (1+it) * mean_{t<T-1, j} sqrt(|th_t - th_t+1|^2 + 1e-20)
-    if (T > 1) {
-        const float wt = 10.0f * (float)(1 + a.it) / ((float)(T - 1) * (float)NJ);
-        if (t + 1 < T) {
-            const float* nx = th + TH;
-            const float dx = x - nx[0], dy = y - nx[1], dz = z - nx[2];
-            const float r = wt / sqrtf(dx * dx + dy * dy + dz * dz + 1e-20f);
+    if (j < NJ) {
+        // ---- pose prior: d/d theta of 1e7 c^2 / (1+it)  =  2e7 c / ((1+it) T) * J^T(theta) d d/d q
+        float k, angle, qq[4];
+        aa2quat(x, y, z, k, angle, qq);
+        const float4 g4 = *(const float4*)(a.dq + n * NQ + 4 * j);
+        // k'(angle) / angle: (cos(angle/2)/2 - k) / angle^2, series -1/24 below the small-angle switch
+        const float kp = (angle < 1e-6f) ? (-1.0f / 24.0f) : ((0.5f * qq[0] - k) / (angle * angle));
+        const float gv_dot_a = g4.y * x + g4.z * y + g4.w * z;
+        const float common = -0.5f * k * g4.x + kp * gv_dot_a;
+        const float wp = 2.0e7f * c / ((float)(1 + a.it) * (float)T);
+        gx = wp * (common * x + k * g4.y);
+        gy = wp * (common * y + k * g4.z);
+        gz = wp * (common * z + k * g4.w);
+    }
+    if (a.g_extra) {
+        // ---- body-model terms (SMPL vertex temporal + joint data term, motion_denoise.py:86-94): their weighted gradient
+        // comes from pndf_lbs_terms_grad (pndf_lbs.hip); the order of the sum is pose prior first, as stacked at :37-45
+        const float* ge = a.g_extra + n * TH + 3 * j;
+        gx += ge[0]; gy += ge[1]; gz += ge[2];
+    } else if (j < NJ) {
+        // ---- temporal surrogate: 10 (1+it) * mean_{t<T-1, j} sqrt(|th_t - th_t+1|^2 + 1e-20)
+        if (T > 1) {
+            const float wt = 10.0f * (float)(1 + a.it) / ((float)(T - 1) * (float)NJ);
+            if (t + 1 < T) {
+                const float* nx = th + TH;
+                const float dx = x - nx[0], dy = y - nx[1], dz = z - nx[2];
+                const float r = wt / sqrtf(dx * dx + dy * dy + dz * dz + 1e-20f);
+                gx += r * dx; gy += r * dy; gz += r * dz;
+            }
+            if (t > 0) {
+                const float* pv = th - TH;
+                const float dx = pv[0] - x, dy = pv[1] - y, dz = pv[2] - z;
+                const float r = wt / sqrtf(dx * dx + dy * dy + dz * dz + 1e-20f);
+                gx -= r * dx; gy -= r * dy; gz -= r * dz;
+            }
+        }
+        // ---- data surrogate (it > 0): 100 / (1+it) * mean_{t, j} sqrt(|th - th0|^2 + 1e-20)
+        if (a.it > 0) {
+            const float* t0 = a.theta0 + n * TH + 3 * j;
+            const float dx = x - t0[0], dy = y - t0[1], dz = z - t0[2];
+            const float r = 100.0f / (float)(1 + a.it) / ((float)T * (float)NJ) / sqrtf(dx * dx + dy * dy + dz * dz + 1e-20f);
             gx += r * dx; gy += r * dy; gz += r * dz;
         }
-        if (t > 0) {
-            const float* pv = th - TH;
-            const float dx = pv[0] - x, dy = pv[1] - y, dz = pv[2] - z;
-            const float r = wt / sqrtf(dx * dx + dy * dy + dz * dz + 1e-20f);
-            gx -= r * dx; gy -= r * dy; gz -= r * dz;
-        }
     }
-    // ---- data surrogate (it > 0): 100 / (1+it) * mean_{t, j} sqrt(|th - th0|^2 + 1e-20)
-    if (a.it > 0) {
-        const float* t0 = a.theta0 + n * TH + 3 * j;
-        const float dx = x - t0[0], dy = y - t0[1], dz = z - t0[2];
-        const float r = 100.0f / (float)(1 + a.it) / ((float)T * (float)NJ) / sqrtf(dx * dx + dy * dy + dz * dz + 1e-20f);
-        gx += r * dx; gy += r * dy; gz += r * dz;
-    }
-    // ---- Adam (torch.optim.Adam defaults: no amsgrad, no weight decay)
+    // ---- Adam (torch.optim.Adam defaults: no amsgrad, no weight decay).  The two hand joints have a zero gradient
+    // without a body model: m = v = 0 and the step is exactly 0, as in torch.
     const float bc1 = 1.0f - powf(a.beta1, (float)a.adam_step);
     const float bc2 = 1.0f - powf(a.beta2, (float)a.adam_step);
     const float step = a.lr / bc1, rs = 1.0f / sqrtf(bc2);
@@ -134,15 +134,13 @@ extern "C" __global__ void __launch_bounds__(WG) pndf_denoise_update_kernel(Pndf
         vv[e] = v1;
         nw[e] = cur[e] - step * m1 / (sqrtf(v1) * rs + a.eps);
     }
-    float k2, ang2, q2[4];
-    aa2quat(nw[0], nw[1], nw[2], k2, ang2, q2);
-    *(float4*)(a.q_next + n * NQ + 4 * j) = make_float4(q2[0], q2[1], q2[2], q2[3]);
+    if (j < NJ) {
+        float k2, ang2, q2[4];
+        aa2quat(nw[0], nw[1], nw[2], k2, ang2, q2);
+        *(float4*)(a.q_next + n * NQ + 4 * j) = make_float4(q2[0], q2[1], q2[2], q2[3]);
+    }
     float* out = a.theta_out + n * TH + 3 * j;
     out[0] = nw[0]; out[1] = nw[1]; out[2] = nw[2];
-    if (j == NJ - 1) {      // the two hand joints carry no term here: zero gradient, Adam leaves them where they are
-#pragma unroll
-        for (int e = 3; e < 3 + 3 * (NJ_ALL - NJ); ++e) out[e] = th[e];
-    }
 }
 
 // ------------------------------------------------------------------ C ABI (include/posendf_amd.h)
@@ -158,9 +156,9 @@ extern "C" int pndf_aa2quat(const float* theta, float* q, int64_t N, void* strea
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-extern "C" int pndf_denoise_update(const float* theta_in, float* theta_out, const float* theta0, const float* d,
-                                   const float* dq, float* m, float* v, float* q_next, int32_t S, int32_t T, int32_t it,
-                                   int32_t adam_step, float lr, void* stream) {
+static int denoise_update(const float* theta_in, float* theta_out, const float* theta0, const float* d, const float* dq,
+                          float* m, float* v, float* q_next, const float* g_extra, int32_t S, int32_t T, int32_t it,
+                          int32_t adam_step, float lr, void* stream) {
     if (S < 0 || T < 0 || it < 0 || adam_step < 1) return -1;
     if (S == 0 || T == 0) return 0;
     if (!theta_in || !theta_out || !theta0 || !d || !dq || !m || !v || !q_next || theta_in == theta_out) return -1;
@@ -169,9 +167,22 @@ extern "C" int pndf_denoise_update(const float* theta_in, float* theta_out, cons
     if (!guard.ok) return -3;
     PndfDenoiseArgs a;
     a.theta_in = theta_in; a.theta_out = theta_out; a.theta0 = theta0; a.d = d; a.dq = dq; a.m = m; a.v = v;
-    a.q_next = q_next; a.S = S; a.T = T; a.it = it; a.adam_step = adam_step;
+    a.q_next = q_next; a.g_extra = g_extra; a.S = S; a.T = T; a.it = it; a.adam_step = adam_step;
     a.lr = lr; a.beta1 = 0.9f; a.beta2 = 0.999f; a.eps = 1e-8f;       // motion_denoise.py:70, torch.optim.Adam defaults
     const dim3 grid((unsigned)((T + FRAMES_PER_WG - 1) / FRAMES_PER_WG), (unsigned)S);
     hipLaunchKernelGGL(pndf_denoise_update_kernel, grid, dim3(WG), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+extern "C" int pndf_denoise_update(const float* theta_in, float* theta_out, const float* theta0, const float* d,
+                                   const float* dq, float* m, float* v, float* q_next, int32_t S, int32_t T, int32_t it,
+                                   int32_t adam_step, float lr, void* stream) {
+    return denoise_update(theta_in, theta_out, theta0, d, dq, m, v, q_next, nullptr, S, T, it, adam_step, lr, stream);
+}
+
+extern "C" int pndf_denoise_update_body(const float* theta_in, float* theta_out, const float* theta0, const float* d,
+                                        const float* dq, const float* g_body, float* m, float* v, float* q_next, int32_t S,
+                                        int32_t T, int32_t it, int32_t adam_step, float lr, void* stream) {
+    if (!g_body) return -1;
+    return denoise_update(theta_in, theta_out, theta0, d, dq, m, v, q_next, g_body, S, T, it, adam_step, lr, stream);
 }

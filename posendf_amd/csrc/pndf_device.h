@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "pndf_layout.h"
+#include "pndf_args.h"
 
 using namespace pndf;
 
@@ -33,7 +34,6 @@ static_assert(LDS_BIAS % 16 == 0 && LDS_MASK % 16 == 0 && LDS_Q % 16 == 0 && LDS
 static_assert(NQ <= FSTRIDE, "GN aliases the feature rows");
 static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
 
-enum { MODE_FORWARD = 0, MODE_FORWARD_GRAD = 1, MODE_PROJECT = 2 };
 
 // debug dump stage offsets (floats per thread)
 enum {
@@ -661,22 +661,3 @@ __device__ __forceinline__ void dump_tiles(float* dbg, int off, const f32x4 (&x)
 }
 
 }  // namespace
-
-struct PndfKernelArgs {
-    const float* q_in;      // [B,84]
-    float* q_out;           // [B,84]  projected poses (PROJECT) or dd/dq * grad_out (FORWARD_GRAD)
-    float* d_out;           // [B]
-    const float* grad_out;  // [B] or null (FORWARD_GRAD only)
-    const char* stream;     // packed trunk weights, STEP_TILES KiB
-    const float* bias;      // BIAS_FLOATS
-    float* dbg;             // null, or DBG_TOTAL*256 floats written by workgroup 0 (first step)
-    long long B;
-    int steps;
-    int mode;
-    float slope;            // 0 = relu, 0.01 = lrelu
-    float beta;             // softplus beta
-    float* scratch;         // softplus: gridDim.x * SP_WG_FLOATS floats of derivative scratch, else null
-    int reserved0;
-    int noenc;              // 1 = model.StrEnc.use False: the trunk sees the normalised quaternions (in_dim 84)
-};
-

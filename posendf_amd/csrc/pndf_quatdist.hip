@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pndf_args.h"
 #include "pndf_host.h"
 
 namespace {
@@ -20,15 +21,6 @@ __device__ __forceinline__ void argmin_pair(float& v, int& i, float ov, int oi) 
     if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
 }  // namespace
-
-struct PndfQuatDistArgs {
-    const float* noise;    // [B,21,4]
-    const float* valid;    // [B,K,21,4]
-    float* vals;           // [B,k]
-    long long* idx;        // [B,k]
-    int K, k, metric;      // metric 0 = geo, 1 = euc
-    float w[NJ];           // joint weights (1/21 each when unweighted)
-};
 
 extern "C" __global__ void __launch_bounds__(WG) pndf_quat_topk_kernel(PndfQuatDistArgs a) {
     extern __shared__ float smem[];                   // terms[K*21] | dist[K] | q[21*4] | w[21] | partials
@@ -115,15 +107,10 @@ extern "C" int pndf_quat_topk(const float* noise, const float* valid, int64_t B,
     if (lds > 160 * 1024) return -4;                  // K <= ~1,850 candidates per query
     DeviceGuard guard(pndf_pointer_device(valid));
     if (!guard.ok) return -3;
-    // the dynamic-LDS limit is a per-device function attribute: remember which devices have it
-    static bool attr_set[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -3;
-    if (!attr_set[dev]) {
-        if (hipFuncSetAttribute((const void*)pndf_quat_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return -3;
-        attr_set[dev] = true;
-    }
+    // the dynamic-LDS limit is a per-device function attribute; setting it is a host-side table write (no device work), so
+    // it is simply set on every call: no shared state between threads, no bound on the device index
+    if (hipFuncSetAttribute((const void*)pndf_quat_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return -3;
     PndfQuatDistArgs a;
     a.noise = noise; a.valid = valid; a.vals = vals; a.idx = idx; a.K = K; a.k = k; a.metric = metric;
     for (int j = 0; j < NJ; ++j) a.w[j] = weights ? weights[j] : 1.0f / (float)NJ;

@@ -63,6 +63,8 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.pndf_aa2quat.restype = c_int
     lib.pndf_denoise_update.argtypes = [c_void_p] * 8 + [c_int32] * 4 + [c_float, c_void_p]
     lib.pndf_denoise_update.restype = c_int
+    lib.pndf_denoise_update_body.argtypes = [c_void_p] * 9 + [c_int32] * 4 + [c_float, c_void_p]
+    lib.pndf_denoise_update_body.restype = c_int
     lib.pndf_quat_topk.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p,
                                    c_void_p, c_void_p]
     lib.pndf_quat_topk.restype = c_int
@@ -80,7 +82,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
 EXPORTS = ("pndf_default_config", "pndf_create", "pndf_destroy", "pndf_load_weights", "pndf_forward",
            "pndf_forward_grad", "pndf_project", "pndf_debug_forward_grad", "pndf_debug_floats",
            "pndf_debug_project_timing", "pndf_debug_timing_regions",
-           "pndf_packed_sizes", "pndf_pack_host", "pndf_pack_host_split", "pndf_aa2quat", "pndf_denoise_update", "pndf_quat_topk",
+           "pndf_packed_sizes", "pndf_pack_host", "pndf_pack_host_split", "pndf_aa2quat", "pndf_denoise_update", "pndf_denoise_update_body", "pndf_quat_topk",
            "pndf_last_error", "pndf_version", "pndf_kernel_name")
 
 

@@ -95,9 +95,23 @@ class PoseNDF(nn.Module):
 
     # ---- engine plumbing -----------------------------------------------------------------------
     def _fingerprint(self):
-        if self._param_list is None:
-            self._param_list = list(self.parameters())
-        return tuple((p.data_ptr(), p._version) for p in self._param_list)
+        """(storage, version) of every parameter.  Walking the module tree costs 0.15 ms per call, so the walk is cached as
+        (owner module, name, Parameter) triples plus the (parent, name, child) links of the tree -- and VALIDATED by identity
+        on every call (~140 dict lookups): a Parameter or submodule replaced by attribute assignment
+        (`net.dfnet.lin0.weight = nn.Parameter(...)`, `net.dfnet = DFNet(...)`) rebuilds the cache and so re-packs."""
+        c = self._param_list
+        if c is not None:
+            links, leaves = c
+            if not (all(par._modules.get(n) is ch for par, n, ch in links)
+                    and all(m._parameters.get(n) is p for m, n, p in leaves)):
+                c = None
+        if c is None:
+            links = [(par, n, ch) for par in self.modules() for n, ch in par._modules.items()]
+            leaves = [(m, n, p) for m in self.modules() for n, p in m._parameters.items() if p is not None]
+            if len(leaves) != len(list(self.parameters())):      # shared / parametrised tensors: no cache, full walk
+                return tuple((p.data_ptr(), p._version) for p in self.parameters())
+            c = self._param_list = (links, leaves)
+        return tuple((p.data_ptr(), p._version) for _, _, p in c[1])
 
     def _apply(self, fn, *args, **kwargs):          # .to() / .float() / .cuda(): parameters may be replaced
         self._param_list = None

@@ -61,3 +61,36 @@ def denoise_sharded(optimize_fn, theta_shard: torch.Tensor, total_sequences: int
     the final gather of the denoised poses.  optimize_fn(theta_shard [S_r,T,69]) -> denoised [S_r,T,69]."""
     out = optimize_fn(theta_shard)
     return all_gather_blocks(out, total_sequences, group)
+
+
+def run_virtual_shards(fn, x_all: torch.Tensor, shards: int, group=None, out=None):
+    """One-device rehearsal of an N-rank job (SURVEY.md section 4 "8 virtual shards"): `fn` runs on every contiguous block
+    of `x_all` in rank order -- exactly what rank r of a `shards`-rank job would run on its shard -- and each block's
+    outputs are placed where the final all-gather puts that rank's block.  When a process group exists (a single forced
+    rank on a one-GPU box) every block goes through the SAME collective the N-rank job uses, `all_gather_into_tensor`
+    straight into its window of the preallocated receive buffer, so the collective sees the message sizes of the real
+    job.  fn(block) -> tensor or tuple of tensors whose leading dimension is the block's.  Returns the gathered tensor(s)
+    with leading dimension len(x_all)."""
+    import torch.distributed as dist
+    total = x_all.shape[0]
+    use_dist = dist.is_available() and dist.is_initialized()
+    if use_dist and dist.get_world_size(group) != 1:
+        raise ValueError("run_virtual_shards emulates the ranks of a job on ONE process; use project_sharded / "
+                         "denoise_sharded on a real multi-rank group")
+    outs = None
+    for r in range(shards):
+        lo, hi = shard_bounds(total, r, shards)
+        res = fn(x_all[lo:hi])
+        single = not isinstance(res, (tuple, list))
+        res = (res,) if single else tuple(res)
+        if outs is None:
+            outs = out if out is not None else tuple(y.new_empty((total,) + tuple(y.shape[1:])) for y in res)
+            outs = (outs,) if isinstance(outs, torch.Tensor) else tuple(outs)
+        for dst, y in zip(outs, res):
+            if hi == lo:
+                continue
+            if use_dist:
+                dist.all_gather_into_tensor(dst[lo:hi], y.contiguous(), group=group)
+            else:
+                dst[lo:hi].copy_(y)
+    return outs[0] if len(outs) == 1 else outs

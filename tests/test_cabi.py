@@ -187,3 +187,29 @@ def test_header_is_plain_c(tmp_path):
     r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(REPO, "include"),
                         str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_weight_fingerprint_sees_replaced_parameters_and_modules():
+    """The facade re-packs the engine's weights when the fingerprint changes.  Its cached walk of the module tree is validated
+    by identity on every call: in-place updates, a Parameter replaced by attribute assignment, a swapped submodule and
+    load_state_dict(assign=True) all change it (the cache used to go stale on the middle two)."""
+    import torch
+    import torch.nn as nn
+    from posendf_amd import PoseNDF, amass_config
+    net = PoseNDF(amass_config("lrelu", "cpu"))
+    f = [net._fingerprint()]
+    assert net._fingerprint() == f[0]
+    with torch.no_grad():
+        net.dfnet.lin6.bias.add_(1.0)
+    f.append(net._fingerprint())
+    net.dfnet.lin0.weight = nn.Parameter(net.dfnet.lin0.weight.detach().clone())
+    f.append(net._fingerprint())
+    old = net.dfnet.lin3
+    net.dfnet.lin3 = nn.Linear(old.in_features, old.out_features)
+    f.append(net._fingerprint())
+    net.enc.net[4].net[0].bias = nn.Parameter(torch.zeros(10))
+    f.append(net._fingerprint())
+    net.load_state_dict({k: v.clone() for k, v in net.state_dict().items()}, assign=True)
+    f.append(net._fingerprint())
+    assert len(set(f)) == len(f)
+    assert len(f[-1]) == 98
