@@ -144,7 +144,7 @@ int pndf_denoise_update(const float* theta_in, float* theta_out, const float* th
 
 /* The same Adam step with the gradient of the BODY-MODEL terms (SMPL vertex temporal term + joint data term,
  * motion_denoise.py:86-94) in place of the pose-space surrogates: g_body [S,T,69] = d(weighted temp + data terms)/d theta as
- * produced by pndf_lbs_terms_grad (below).  All 23 joints of the body pose are updated (the surrogates leave the two hand
+ * produced by the body-model entry points below.  All 23 joints of the body pose are updated (the surrogates leave the two hand
  * joints alone; the body model moves vertices with them). */
 int pndf_denoise_update_body(const float* theta_in, float* theta_out, const float* theta0, const float* d, const float* dq,
                              const float* g_body, float* m, float* v, float* q_next, int32_t S, int32_t T, int32_t it,
