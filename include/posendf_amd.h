@@ -144,11 +144,52 @@ int pndf_denoise_update(const float* theta_in, float* theta_out, const float* th
 
 /* The same Adam step with the gradient of the BODY-MODEL terms (SMPL vertex temporal term + joint data term,
  * motion_denoise.py:86-94) in place of the pose-space surrogates: g_body [S,T,69] = d(weighted temp + data terms)/d theta as
- * produced by the body-model entry points below.  All 23 joints of the body pose are updated (the surrogates leave the two hand
+ * produced by pndf_lbs_terms_grad below.  All 23 joints of the body pose are updated (the surrogates leave the two hand
  * joints alone; the body model moves vertices with them). */
 int pndf_denoise_update_body(const float* theta_in, float* theta_out, const float* theta0, const float* d, const float* dq,
                              const float* g_body, float* m, float* v, float* q_next, int32_t S, int32_t T, int32_t it,
                              int32_t adam_step, float lr, void* stream);
+
+/* ---- SMPL-shaped body model: linear-blend skinning and the body-model terms of the motion-denoise objective
+ * (SURVEY 8f-3).  Replaces experiments/body_model.py:27-40 (smplx.SMPL called with betas, body_pose, global_orient = None)
+ * and experiments/motion_denoise.py:86-94 (vertex temporal term, joint data term) with their reverse pass.  smplx and the
+ * SMPL model files are third-party and absent from the reference: the published lbs() algorithm is restated, parity
+ * unpinned.  The model is supplied by the caller as plain arrays (HOST pointers, fp32, the shapes of the SMPL model file):
+ *   v_template [V,3]; shapedirs [V,3,NB] and betas [NB] (fixed during the optimisation, motion_denoise.py:27,67; NB may be 0);
+ *   posedirs [207, 3V] (row k = entry k of the pose feature (R_1..R_23 - I), as smplx stores it); J_regressor [24,V];
+ *   parents [24] (parents[0] = -1, every parent before its children); lbs_weights [V,24];
+ *   extra_joint_vertex [n_extra <= 32]: joints picked from vertices (smplx VertexJointSelector; SMPL: 21 -> 45 joints).
+ * Compute calls take DEVICE pointers, enqueue on `stream`, allocate nothing: scratch comes from the caller
+ * (`workspace`: pndf_lbs_workspace_floats(h, S, T) floats, 16-byte aligned, for S sequences of T frames; the flat calls
+ * with N frames use S = 1, T = N). */
+typedef struct pndf_lbs_model* pndf_lbs_handle;
+int pndf_lbs_create(pndf_lbs_handle* out, int32_t V, int32_t NB, const float* v_template, const float* shapedirs,
+                    const float* betas, const float* posedirs, const float* J_regressor, const int32_t* parents,
+                    const float* lbs_weights, const int32_t* extra_joint_vertex, int32_t n_extra, int device);
+int pndf_lbs_destroy(pndf_lbs_handle h);
+int32_t pndf_lbs_num_joints(pndf_lbs_handle h);        /* 24 + n_extra */
+int32_t pndf_lbs_num_vertices(pndf_lbs_handle h);
+int64_t pndf_lbs_workspace_floats(pndf_lbs_handle h, int32_t S, int32_t T);
+/* BodyModel.forward(pose_body = theta, betas) (body_model.py:33-52): theta [N,69] -> verts [N,V,3] (may be NULL),
+ * joints [N, 24 + n_extra, 3] (may be NULL; `Jtr` of the reference). */
+int pndf_lbs_forward(pndf_lbs_handle h, const float* theta, int64_t N, float* verts, float* joints, void* workspace,
+                     void* stream);
+/* d / d theta of  10 (1 + it) mean_{t,v} |V[t,v] - V[t+1,v]|  +  [it > 0] 100 / (1 + it) mean_{t,j} |Jtr[t,j] - joints0[t,j]|
+ * (motion_denoise.py:31-32,88-89,92-94) per sequence: theta, g_theta [S,T,69]; joints0 [S,T,24 + n_extra,3] (may be NULL
+ * when it == 0).  One fused pass: vertices never reach HBM.  Like the reference there is no epsilon under the roots
+ * (identical consecutive vertices give NaN). */
+int pndf_lbs_terms_grad(pndf_lbs_handle h, const float* theta, const float* joints0, int32_t S, int32_t T, int32_t it,
+                        float* g_theta, void* workspace, void* stream);
+/* General reverse pass: g_theta [N,69] = d (<g_verts, verts> + <g_joints, joints>) / d theta (either may be NULL). */
+int pndf_lbs_backward(pndf_lbs_handle h, const float* theta, const float* g_verts, const float* g_joints, int64_t N,
+                      float* g_theta, void* workspace, void* stream);
+/* Host-only model packer (what pndf_lbs_create uploads; needs no device): `blob` takes pndf_lbs_packed_floats(V) floats in
+ * MFMA tile order, J_out / rel_out (72 floats each, may be NULL) the rest joints and their parent-relative offsets. */
+int64_t pndf_lbs_packed_floats(int32_t V);
+int pndf_lbs_pack_host(int32_t V, int32_t NB, const float* v_template, const float* shapedirs, const float* betas,
+                       const float* posedirs, const float* J_regressor, const int32_t* parents, const float* lbs_weights,
+                       const int32_t* extra_joint_vertex, int32_t n_extra, float* blob, float* J_out, float* rel_out);
+const char* pndf_lbs_last_error(pndf_lbs_handle h);    /* h may be NULL: last error of a failed pndf_lbs_create */
 
 /* ---- quaternion pose distance + k nearest candidates (data/dist_utils.py:9-50, classes euc / geo; caller
  * data/prepare_traindata.py:159).  noise [B,21,4], valid [B,K,21,4] (device, 16-byte aligned);

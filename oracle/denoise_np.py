@@ -42,8 +42,10 @@ def aa2quat_vjp(a, gq):
     return common * a + k * gq[..., 1:]
 
 
-def step_gradient(theta, theta0, sd, it, act="lrelu", beta=100.0, dtype=np.float64):
-    """d (total weighted loss) / d theta for ONE sequence theta [T,69]; returns (grad [T,69], weighted terms dict)."""
+def step_gradient(theta, theta0, sd, it, act="lrelu", beta=100.0, dtype=np.float64, body=None):
+    """d (total weighted loss) / d theta for ONE sequence theta [T,69]; returns (grad [T,69], weighted terms dict).
+    body = (model dict of oracle/lbs_np.py, joints0 [T, n_joints, 3]): the reference's SMPL vertex temporal term and joint
+    data term (motion_denoise.py:86-94; oracle/lbs_np.body_terms, parity unpinned) instead of the pose-space surrogates."""
     theta = np.asarray(theta, dtype)
     T = theta.shape[0]
     a = theta.reshape(T, 23, 3)[:, :NJ]
@@ -53,6 +55,14 @@ def step_gradient(theta, theta0, sd, it, act="lrelu", beta=100.0, dtype=np.float
     terms = {"pose_pr": dtype(1e7) * c * c / dtype(1 + it)}
     g = np.zeros((T, 23, 3), dtype)
     g[:, :NJ] = aa2quat_vjp(a, dq * (dtype(2e7) * c / (dtype(1 + it) * dtype(T))))
+    if body is not None:
+        from . import lbs_np
+        gb, bt = lbs_np.body_terms(theta, body[1], body[0], it, dtype)
+        if "temp" in bt:
+            terms["temp"] = dtype(10.0 * (1 + it)) * bt["temp"]
+        if "data" in bt:
+            terms["data"] = dtype(100.0 / (1 + it)) * bt["data"]
+        return g.reshape(T, 69) + gb, terms
     if T > 1:
         diff = a[:-1] - a[1:]
         nrm = np.sqrt((diff * diff).sum(-1, keepdims=True) + dtype(SURROGATE_EPS))
@@ -69,20 +79,24 @@ def step_gradient(theta, theta0, sd, it, act="lrelu", beta=100.0, dtype=np.float
 
 
 def optimize(theta0, sd, iterations=10, steps_per_iter=50, lr=0.02, act="lrelu", beta=100.0, dtype=np.float64,
-             trace=False):
+             trace=False, body_model=None):
     """The loop of MotionDenoise.optimize (:70-99) for one sequence [T,69] or a batch of independent ones [S,T,69]."""
     theta0 = np.asarray(theta0, dtype)
     single = theta0.ndim == 2
     th0 = theta0[None] if single else theta0
     th = th0.copy()
     m, v = np.zeros_like(th), np.zeros_like(th)
+    bodies = [None] * th.shape[0]
+    if body_model is not None:          # smpl_init.Jtr of the noisy poses (motion_denoise.py:60,63)
+        from . import lbs_np
+        bodies = [(body_model, lbs_np.lbs(th0[s], body_model, dtype)[1]) for s in range(th.shape[0])]
     b1, b2, eps = dtype(0.9), dtype(0.999), dtype(1e-8)
     k = 0
     hist = []
     for it in range(iterations):
         for _ in range(steps_per_iter):
             k += 1
-            g = np.stack([step_gradient(th[s], th0[s], sd, it, act, beta, dtype)[0] for s in range(th.shape[0])])
+            g = np.stack([step_gradient(th[s], th0[s], sd, it, act, beta, dtype, bodies[s])[0] for s in range(th.shape[0])])
             m = b1 * m + (1 - b1) * g
             v = b2 * v + (1 - b2) * g * g
             bc1, bc2 = 1 - b1 ** k, 1 - b2 ** k

@@ -10,7 +10,10 @@ def __getattr__(name):   # torch is imported lazily so that numpy-only users (or
     if name in ("PoseNDF", "gradient"):
         from . import facade
         return getattr(facade, name)
+    if name == "BodyModel":
+        from .body_model import BodyModel
+        return BodyModel
     raise AttributeError(name)
 
 
-__all__ = ["PoseNDF", "gradient", "amass_config", "load_config", "synth"]
+__all__ = ["PoseNDF", "gradient", "BodyModel", "amass_config", "load_config", "synth"]

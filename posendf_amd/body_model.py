@@ -1,0 +1,176 @@
+"""`BodyModel` -- the SMPL body model behind the interface of the reference's wrapper (reference
+experiments/body_model.py:11-53: `BodyModel(bm_path, num_betas, batch_size, model_type='smpl')`, `forward(root_orient=None,
+pose_body=None, betas=None)` returning an object with `.vertices`, `.Jtr`, `.faces`, `.body_pose`, `.betas`), running on
+the HIP linear-blend-skinning kernels of posendf_amd/csrc/pndf_lbs.hip through the C ABI (include/posendf_amd.h,
+`pndf_lbs_*`).
+
+The reference builds `smplx.SMPL(bm_path)` from the licensed SMPL model file.  Neither smplx nor the file is reachable
+here, so the model PARAMETERS are supplied by the caller as arrays with the shapes of the SMPL file (`from_arrays`, or
+`from_npz` for a converted model file); the algorithm is smplx's published lbs() restated -- parity unpinned.
+
+`forward` is differentiable with respect to `pose_body` (first order, through `pndf_lbs_backward`); the betas and the global
+orientation are constants, as in the reference's optimisation (motion_denoise.py:27,67; root_orient=None).  There is no CPU
+or eager fallback: without the library or a gfx950 device the constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+from torch.autograd.function import once_differentiable
+
+from .engine import PndfError, load_library
+
+_KEYS = ("v_template", "shapedirs", "posedirs", "J_regressor", "parents", "lbs_weights")
+
+
+def _f32(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+
+
+class _Lbs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pose_body, owner):
+        th = pose_body.detach().reshape(-1, 69)
+        if th.dtype != torch.float32 or not th.is_contiguous():
+            th = th.float().contiguous()
+        N = th.shape[0]
+        verts = torch.empty(N, owner.num_vertices, 3, device=th.device, dtype=torch.float32)
+        joints = torch.empty(N, owner.num_joints, 3, device=th.device, dtype=torch.float32)
+        owner._call("pndf_lbs_forward", th.data_ptr(), N, verts.data_ptr(), joints.data_ptr(), owner._workspace(1, N, th.device),
+                    owner._stream(th.device))
+        ctx.owner = owner
+        ctx.save_for_backward(th)
+        ctx.in_shape, ctx.in_dtype = pose_body.shape, pose_body.dtype
+        return verts, joints
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_verts, g_joints):
+        (th,) = ctx.saved_tensors
+        owner, N = ctx.owner, th.shape[0]
+        gv = None if g_verts is None else g_verts.float().contiguous()
+        gj = None if g_joints is None else g_joints.float().contiguous()
+        g = torch.empty_like(th)
+        owner._call("pndf_lbs_backward", th.data_ptr(), None if gv is None else gv.data_ptr(),
+                    None if gj is None else gj.data_ptr(), N, g.data_ptr(), owner._workspace(1, N, th.device),
+                    owner._stream(th.device))
+        return g.reshape(ctx.in_shape).to(ctx.in_dtype), None
+
+
+class BodyModel(torch.nn.Module):
+    def __init__(self, params, num_betas=10, batch_size=1, model_type="smpl", device="cuda:0", betas=None,
+                 extra_joint_vertex=None, faces=None):
+        super().__init__()
+        if model_type != "smpl":
+            raise PndfError("only model_type='smpl' (24 joints, 23 x 9 pose feature) is implemented")
+        self.model_type = model_type
+        self.num_joints_smpl = 23                                    # SMPL.NUM_JOINTS (body_model.py:30)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise PndfError("BodyModel runs on the HIP kernels only; no CPU path exists")
+        missing = [k for k in _KEYS if k not in params]
+        if missing:
+            raise PndfError(f"body-model parameters lack {missing}")
+        vt = _f32(params["v_template"])
+        V = vt.shape[0]
+        sd = _f32(params["shapedirs"])[:, :, :num_betas]
+        nb = sd.shape[2]
+        b = np.zeros(nb, np.float32) if betas is None else _f32(betas).reshape(-1)[:nb]
+        pd = _f32(params["posedirs"])
+        if pd.shape != (207, V * 3):
+            raise PndfError(f"posedirs must be [207, {V * 3}] (smplx layout), got {pd.shape}")
+        jr, w = _f32(params["J_regressor"]), _f32(params["lbs_weights"])
+        par = np.ascontiguousarray(np.asarray(params["parents"], dtype=np.int32))
+        par[0] = -1
+        if extra_joint_vertex is None:
+            extra_joint_vertex = params.get("extra_joint_vertex", ())
+        ex = np.ascontiguousarray(np.asarray(extra_joint_vertex, dtype=np.int32))
+        if jr.shape != (24, V) or w.shape != (V, 24) or par.shape != (24,):
+            raise PndfError("J_regressor [24,V], lbs_weights [V,24], parents [24] expected")
+        self.lib = load_library()
+        self.handle = ctypes.c_void_p()
+        sd_c = np.ascontiguousarray(sd)
+        rc = self.lib.pndf_lbs_create(ctypes.byref(self.handle), V, nb, vt.ctypes.data, sd_c.ctypes.data, b.ctypes.data,
+                                      pd.ctypes.data, jr.ctypes.data, par.ctypes.data, w.ctypes.data, ex.ctypes.data, len(ex),
+                                      self.device.index or 0)
+        if rc != 0:
+            msg = self.lib.pndf_lbs_last_error(None).decode()
+            self.handle = None
+            raise PndfError(f"pndf_lbs_create failed ({rc}): {msg}")
+        self.num_vertices = V
+        self.num_joints = 24 + len(ex)
+        self.faces_tensor = None if faces is None else torch.as_tensor(np.asarray(faces, dtype=np.int64), device=self.device)
+        self.register_buffer("betas", torch.from_numpy(b.copy()).to(self.device))
+        self._ws = {}
+
+    @classmethod
+    def from_npz(cls, path, **kw):
+        """A converted SMPL model file: an .npz holding v_template, shapedirs, posedirs [207, 3V], J_regressor (dense),
+        parents (kintree_table[0]), lbs_weights (`weights` of the SMPL pickle) and optionally f (faces)."""
+        z = dict(np.load(path))
+        if "weights" in z and "lbs_weights" not in z:
+            z["lbs_weights"] = z["weights"]
+        return cls(z, faces=z.get("f"), **kw)
+
+    # ---- plumbing -------------------------------------------------------------------------------
+    def _stream(self, device):
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def _workspace(self, S, T, device):
+        """scratch of the C ABI calls (caller-owned there): one cached buffer per shape class, grown on demand"""
+        need = max(int(self.lib.pndf_lbs_workspace_floats(self.handle, S, T)),
+                   int(self.lib.pndf_lbs_workspace_floats(self.handle, 1, S * T)))
+        buf = self._ws.get(device)
+        if buf is None or buf.numel() < need:
+            buf = self._ws[device] = torch.empty(need, device=device, dtype=torch.float32)
+        return buf.data_ptr()
+
+    def _call(self, name, *args):
+        rc = getattr(self.lib, name)(self.handle, *args)
+        if rc != 0:
+            raise PndfError(f"{name} failed ({rc}): {self.lib.pndf_lbs_last_error(self.handle).decode()}")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.pndf_lbs_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference API (body_model.py:33-52) -----------------------------------------------------
+    def forward(self, root_orient=None, pose_body=None, betas=None, return_dict=False, **kwargs):
+        if root_orient is not None:
+            raise PndfError("root_orient is SMPL's zero global_orient parameter here (the reference passes None)")
+        if betas is not None and torch.count_nonzero(betas.to(self.betas.device).reshape(-1, self.betas.numel()) - self.betas):
+            raise PndfError("betas are fixed at construction (motion_denoise.py:27,67: zeros, requires_grad False)")
+        pose_body = pose_body.to(self.device)
+        verts, joints = _Lbs.apply(pose_body, self)
+        out = {"vertices": verts, "faces": self.faces_tensor, "betas": self.betas, "Jtr": joints,
+               "body_pose": pose_body.reshape(-1, 69), "full_pose": None}
+        return out if return_dict else SimpleNamespace(**out)
+
+    # ---- fused objective terms (motion_denoise.py:86-94 with their reverse pass, one launch sequence) -------------------
+    @torch.no_grad()
+    def joints_of(self, theta):
+        """Jtr of the given poses [.., 69] -> [N, num_joints, 3] (no vertices written)."""
+        th = theta.to(self.device, torch.float32).reshape(-1, 69).contiguous()
+        joints = torch.empty(th.shape[0], self.num_joints, 3, device=self.device, dtype=torch.float32)
+        self._call("pndf_lbs_forward", th.data_ptr(), th.shape[0], None, joints.data_ptr(), self._workspace(1, th.shape[0], th.device),
+                   self._stream(th.device))
+        return joints
+
+    @torch.no_grad()
+    def terms_grad(self, theta, joints0, it, out=None):
+        """theta [S,T,69], joints0 [S*T, num_joints, 3] -> d (10 (1+it) temp + [it>0] 100/(1+it) data) / d theta [S,T,69]."""
+        S, T = theta.shape[:2]
+        g = torch.empty_like(theta) if out is None else out
+        self._call("pndf_lbs_terms_grad", theta.data_ptr(), None if joints0 is None else joints0.data_ptr(), S, T, int(it),
+                   g.data_ptr(), self._workspace(S, T, theta.device), self._stream(theta.device))
+        return g

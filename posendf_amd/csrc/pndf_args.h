@@ -57,3 +57,45 @@ struct PndfQuatDistArgs {
 };
 static_assert(sizeof(PndfQuatDistArgs) == 128 && offsetof(PndfQuatDistArgs, K) == 32 &&
               offsetof(PndfQuatDistArgs, w) == 44, "PndfQuatDistArgs layout");
+
+// ---- linear-blend skinning (pndf_lbs.hip): SMPL-shaped body model, smplx lbs() restated
+constexpr int PNDF_LBS_J = 24;             // joints of the kinematic tree (SMPL)
+constexpr int PNDF_LBS_PF = 208;           // pose feature: 23 x 9 = 207 rotation-matrix entries, padded to 52 k-steps of 4
+constexpr int PNDF_LBS_GV = 16;            // vertices per group = rows of one MFMA tile
+constexpr int PNDF_LBS_MAX_EXTRA = 32;     // joints picked from vertices (SMPL: 21)
+// one vertex group in the packed model ("blob", floats; lane-linear tiles, see pndf_lbs.hip):
+//   P  [3 comps][208 k][16 v]   pose blend shapes      W [32 joints][16 v]  skinning weights (rows 24..31 zero)
+//   VS [3 comps][16 v]          shaped template        FL [16 v] int32      -2 padding, -1 ordinary, >= 0 extra-joint index
+constexpr int PNDF_LBS_BLOB_P = 0;
+constexpr int PNDF_LBS_BLOB_W = 3 * PNDF_LBS_PF * PNDF_LBS_GV;                 // 9984
+constexpr int PNDF_LBS_BLOB_VS = PNDF_LBS_BLOB_W + 32 * PNDF_LBS_GV;           // 10496
+constexpr int PNDF_LBS_BLOB_FL = PNDF_LBS_BLOB_VS + 3 * PNDF_LBS_GV;           // 10544
+constexpr int PNDF_LBS_BLOB_FLOATS = 10752;                                    // 42 KiB = 42 LDS-DMA pieces of 1 KiB
+static_assert(PNDF_LBS_BLOB_FL + PNDF_LBS_GV <= PNDF_LBS_BLOB_FLOATS && PNDF_LBS_BLOB_FLOATS % 256 == 0, "blob layout");
+
+struct PndfLbsModel {                      // per-model constants, by value in the arguments of the per-frame kernels
+    float J[PNDF_LBS_J][3];                // rest joints: J_regressor (v_template + shapedirs betas)
+    float rel[PNDF_LBS_J][3];              // joint relative to its parent (root: the joint itself)
+    int parent[PNDF_LBS_J];
+};
+
+struct PndfLbsArgs {
+    const float* theta;        // [S*T, 69] axis-angle body pose (global orientation = SMPL's zero parameter)
+    const float* joints0;      // [S*T, 24 + NE, 3] joints of the initial poses (data term), or null
+    const float* blob;         // [NG][PNDF_LBS_BLOB_FLOATS]
+    const float* g_verts;      // general reverse pass: d L / d vertices [S*T, V, 3], or null
+    const float* g_joints;     // general reverse pass: d L / d joints [S*T, 24 + NE, 3], or null
+    float* pfp;                // [S*T, 208] pose feature, k-permuted for the B operand (lane group g holds k = 4 s + g)
+    float* Ap;                 // [S*T, 4, 12, 6] relative joint transforms, B-operand order
+    float* Gt;                 // [S*T, 24, 3] posed joints
+    float* gpf;                // [vsplit, S*T, 208]  d L / d pose feature, partial per vertex range
+    float* gA;                 // [vsplit, S*T, 12, 32] d L / d joint transform entries
+    float* halo_pf;            // [vsplit, S*cps, 208] the same for the frame a chunk shares with the next chunk
+    float* halo_A;             // [vsplit, S*cps, 12, 32]
+    float* verts;              // forward output [S*T, V, 3] or null
+    float* joints;             // forward output [S*T, 24 + NE, 3] or null
+    float* g_theta;            // [S*T, 69]
+    int S, T, V, NG, NE, cps, vsplit, it_gt0;
+    float w_temp, w_data;      // per element: 10 (1 + it) / ((T - 1) V),  100 / (1 + it) / (T (24 + NE))
+    PndfLbsModel model;
+};

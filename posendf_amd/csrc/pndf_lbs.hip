@@ -1,0 +1,686 @@
+// Linear-blend skinning of an SMPL-shaped body model and the two body-model terms of the reference's motion-denoise
+// objective, forward and reverse, for gfx950.
+//
+// What it replaces: experiments/body_model.py:27-40 (`smplx.SMPL(...)` called with betas, body_pose, global_orient = None)
+// and experiments/motion_denoise.py:86-94 (vertex temporal term, joint data term) + the autograd pass through them.
+// smplx is third-party code that is not under /root/reference: its PUBLISHED algorithm is restated here --
+//   v_shaped = v_template + shapedirs betas;  J = J_regressor v_shaped                       (host, at create: betas are fixed)
+//   R_j = Rodrigues(theta_j) (angle = |r + 1e-8|);  pose_feature = (R_1..R_23 - I)            [207]
+//   v_posed = v_shaped + pose_feature posedirs                                                [V,3]   <- dense: 207 x 3V
+//   G_j = G_parent(j) [R_j | J_j - J_parent(j)];  A_j = [G_R | G_t - G_R J_j]                 (rigid transform chain)
+//   verts_v = sum_j W[v,j] (A_R[j] v_posed_v + A_t[j]);  joints = (G_t[0..23], verts[extra_joint_vertex])
+// -- parity unpinned (oracle/lbs_np.py says the same).
+//
+// Work: per frame 2 x 4.28 M MACs for the pose blend shapes (forward + reverse) and 2 x 2 M for the skinning transforms
+// against 276 B of pose in and 276 B of gradient out: this is dense fp32 contraction work, so it runs on the fp32 MFMA
+// pipe (v_mfma_f32_16x16x4_f32), "transposed" like the distance engine: D rows = 16 vertices (or 16 pose-feature entries /
+// joints in the reverse pass), D columns = 16 FRAMES of one wave.  Vertices, skinning matrices and vertex gradients of a
+// (16 vertex x 16 frame) tile live in registers only; nothing per-vertex ever goes to HBM in the fused-terms mode.
+//
+// Three kernels:
+//   pndf_lbs_pose_kernel            one thread per frame: Rodrigues, transform chain -> pose feature, A, posed joints
+//   pndf_lbs_vertex_kernel<MODE>    one wave per chunk of 16 frames, four chunks per workgroup sharing the model stream:
+//       the packed model ("blob": 42 KiB per 16 vertices, lane-linear MFMA tiles) is streamed global -> LDS by DMA,
+//       double buffered, and read TWICE from LDS: as A operand of the forward pose-blend contraction (rows = vertices) and,
+//       with a transposed conflict-free ds_read_b128, as A operand of the reverse contraction (rows = pose-feature entries).
+//       MODE 0: vertices / vertex-picked joints out.  MODE 1: the two weighted terms of motion_denoise.py:86-94 formed in
+//       registers (neighbouring frames are neighbouring lanes) and pushed straight back: d L / d pose_feature and
+//       d L / d A accumulate in registers over all vertices.  MODE 2: general reverse pass for given d L / d verts.
+//   pndf_lbs_pose_backward_kernel   one thread per frame: reverse of the transform chain and of Rodrigues -> d L / d theta
+// In MODE 1 a chunk is 16 frames = 15 pairs; consecutive chunks share a frame, whose two partial results ("halo") are summed
+// by the last kernel.  Small problems split the vertex range over blockIdx.y (`vsplit`) and sum the partials there too, in
+// a fixed order: results are deterministic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/posendf_amd.h"
+#include "pndf_args.h"
+#include "pndf_host.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int NJ = PNDF_LBS_J, PF = PNDF_LBS_PF, GV = PNDF_LBS_GV, BLOB = PNDF_LBS_BLOB_FLOATS;
+constexpr int KS = PF / 4;                 // 52 k-steps of the pose-blend contraction
+constexpr int KT = PF / 16;                // 13 row tiles of d L / d pose_feature
+constexpr int C_STRIDE = PF * GV;          // floats per component of P in a blob (3328)
+constexpr int A_FLOATS = 12 * 32;          // d L / d A per frame: [12 entries][32 joints (24 used)]
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// smplx batch_rodrigues: angle = |r + 1e-8|, axis = r / angle, R = I + sin K + (1 - cos) K K   (row-major 3x3)
+__device__ __forceinline__ void rodrigues(float rx, float ry, float rz, float* R) {
+    const float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
+    const float th = sqrtf(ax * ax + ay * ay + az * az);
+    const float nx = rx / th, ny = ry / th, nz = rz / th;
+    const float s = sinf(th), c1 = 1.0f - cosf(th);
+    R[0] = 1.0f - c1 * (nz * nz + ny * ny); R[1] = -s * nz + c1 * nx * ny;          R[2] = s * ny + c1 * nx * nz;
+    R[3] = s * nz + c1 * nx * ny;          R[4] = 1.0f - c1 * (nz * nz + nx * nx); R[5] = -s * nx + c1 * ny * nz;
+    R[6] = -s * ny + c1 * nx * nz;         R[7] = s * nx + c1 * ny * nz;           R[8] = 1.0f - c1 * (nx * nx + ny * ny);
+}
+
+// reverse of rodrigues: d <gR, R(r)> / d r
+__device__ __forceinline__ void rodrigues_vjp(float rx, float ry, float rz, const float* gR, float* gr) {
+    const float a[3] = {rx + 1e-8f, ry + 1e-8f, rz + 1e-8f};
+    const float th = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    const float nx = rx / th, ny = ry / th, nz = rz / th;
+    const float s = sinf(th), c = cosf(th), c1 = 1.0f - c;
+    const float K[9] = {0.f, -nz, ny, nz, 0.f, -nx, -ny, nx, 0.f};
+    const float KK[9] = {-(nz * nz + ny * ny), nx * ny, nx * nz, nx * ny, -(nz * nz + nx * nx), ny * nz,
+                         nx * nz, ny * nz, -(nx * nx + ny * ny)};
+    float g_th = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g_th += gR[i] * (c * K[i] + s * KK[i]);
+    // gK = s gR + (1 - c) (gR K^T + K^T gR)
+    float gK[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc += gR[3 * i + k] * K[3 * j + k] + K[3 * k + i] * gR[3 * k + j];
+            gK[3 * i + j] = s * gR[3 * i + j] + c1 * acc;
+        }
+    const float gn[3] = {gK[7] - gK[5], gK[2] - gK[6], gK[3] - gK[1]};
+    g_th -= (gn[0] * rx + gn[1] * ry + gn[2] * rz) / (th * th);          // n = r / th
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gr[i] = gn[i] / th + g_th * a[i] / th;
+}
+
+// rotations, global rotations and global translations of the 24 joints of one frame (smplx batch_rigid_transform)
+__device__ __forceinline__ void frame_transforms(const float* th, const PndfLbsModel& m, float (&R)[NJ][9], float (&GR)[NJ][9],
+                                                 float (&Gt)[NJ][3]) {
+    rodrigues(0.f, 0.f, 0.f, R[0]);          // SMPL's global_orient parameter: zeros (body_model.py:35-40 passes None)
+    for (int j = 1; j < NJ; ++j) rodrigues(th[3 * j - 3], th[3 * j - 2], th[3 * j - 1], R[j]);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) GR[0][i] = R[0][i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Gt[0][i] = m.rel[0][i];
+    for (int j = 1; j < NJ; ++j) {
+        const int p = m.parent[j];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                GR[j][3 * a + b] = GR[p][3 * a] * R[j][b] + GR[p][3 * a + 1] * R[j][3 + b] + GR[p][3 * a + 2] * R[j][6 + b];
+            Gt[j][a] = GR[p][3 * a] * m.rel[j][0] + GR[p][3 * a + 1] * m.rel[j][1] + GR[p][3 * a + 2] * m.rel[j][2] + Gt[p][a];
+        }
+    }
+}
+
+// chunks of frames per sequence: fused-terms mode walks 15 pairs per chunk (consecutive chunks share a frame)
+__host__ __device__ inline int chunks_fwd(int T) { return (T + 15) / 16; }
+__host__ __device__ inline int chunks_pairs(int T) { return T > 1 ? (T - 1 + 14) / 15 : 1; }
+
+}  // namespace
+
+// ------------------------------------------------------------------ per-frame forward
+extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_kernel(PndfLbsArgs a) {
+    const long long n = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (n >= (long long)a.S * a.T) return;
+    float R[NJ][9], GR[NJ][9], Gt[NJ][3];
+    frame_transforms(a.theta + n * 69, a.model, R, GR, Gt);
+    // pose feature, k-permuted so that lane group g of the vertex kernel reads its 52 values contiguously:
+    // pfp[g * 52 + s] = pose_feature[4 s + g]
+    float* pf = a.pfp + n * PF;
+    for (int k = 0; k < PF; ++k) {
+        float v = 0.f;
+        if (k < 9 * (NJ - 1)) v = R[1 + k / 9][k % 9] - (((k % 9) % 4 == 0) ? 1.0f : 0.0f);
+        pf[(k & 3) * KS + (k >> 2)] = v;
+    }
+    // A_j = [G_R | G_t - G_R J_j] in B-operand order: Ap[g][entry][s] = A[joint 4 s + g][entry]
+    float* Ap = a.Ap + n * 288;
+    for (int j = 0; j < NJ; ++j) {
+        const int g = j & 3, s = j >> 2;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Ap[g * 72 + e * 6 + s] = GR[j][e];
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            Ap[g * 72 + (9 + e) * 6 + s] = Gt[j][e] - (GR[j][3 * e] * a.model.J[j][0] + GR[j][3 * e + 1] * a.model.J[j][1] +
+                                                        GR[j][3 * e + 2] * a.model.J[j][2]);
+    }
+    const int njt = NJ + a.NE;
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            if (a.Gt) a.Gt[n * (NJ * 3) + 3 * j + e] = Gt[j][e];
+            if (a.joints) a.joints[(n * njt + j) * 3 + e] = Gt[j][e];
+        }
+}
+
+// ------------------------------------------------------------------ per (16 vertices x 16 frames) tile
+template <int MODE>
+__device__ __forceinline__ void lbs_vertex_body(const PndfLbsArgs& a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // 2 x BLOB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, p = lane & 15;
+    constexpr int STRIDE = (MODE == 1) ? 15 : 16;
+    const int T = a.T, cps = a.cps, nch = a.S * cps, njt = NJ + a.NE;
+    int cid = blockIdx.x * 4 + wave;
+    const bool wave_on = cid < nch;
+    if (!wave_on) cid = nch - 1;                    // idle waves shadow the last chunk (they take part in the DMA / barriers)
+    const int s = cid / cps, c = cid - s * cps, f0 = c * STRIDE;
+    const int t = f0 + p;
+    const bool t_ok = wave_on && t < T;
+    const long long n = (long long)s * T + (t < T ? t : T - 1);
+    const bool owned = t_ok && (MODE != 1 || p < 15 || t == T - 1);     // MODE 1: lane 15 belongs to the next chunk
+    const bool pair_ok = MODE == 1 && t_ok && p < 15 && t + 1 < T;
+    const long long N = (long long)a.S * T;
+
+    // ---- B operands of this wave's 16 frames (constant over the vertex groups)
+    float pfB[KS], AB[72];
+    {
+        const f32x4* src = (const f32x4*)(a.pfp + n * PF + g * KS);
+#pragma unroll
+        for (int i = 0; i < KS / 4; ++i) {
+            const f32x4 v = src[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pfB[4 * i + r] = v[r];
+        }
+        const f32x4* srcA = (const f32x4*)(a.Ap + n * 288 + g * 72);
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const f32x4 v = srcA[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) AB[4 * i + r] = v[r];
+        }
+    }
+    f32x4 gpf[KT], gA[12][2];
+    if constexpr (MODE != 0) {
+#pragma unroll
+        for (int i = 0; i < KT; ++i) gpf[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 12; ++i) gA[i][0] = gA[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int vs = blockIdx.y;
+    const int grp0 = (int)((long long)a.NG * vs / a.vsplit), grp1 = (int)((long long)a.NG * (vs + 1) / a.vsplit);
+    // model stream: one blob = 42 pieces of 1 KiB, piece i moved by wave i % 4 (LDS destination = wave-uniform base + lane * 16)
+    auto dma = [&](int grp, int buf) {
+        const float* src = a.blob + (size_t)grp * BLOB + lane * 4;
+        float* dst = smem + buf * BLOB;
+        for (int i = wave; i < BLOB / 256; i += 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
+    };
+    if (grp0 < grp1) dma(grp0, 0);
+    for (int grp = grp0; grp < grp1; ++grp) {
+        const int buf = (grp - grp0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of blob `grp` have landed ...
+        __syncthreads();                                      // ... everyone's have, and everyone has left the other buffer
+        if (grp + 1 < grp1) dma(grp + 1, buf ^ 1);
+        const float* Bf = smem + buf * BLOB;
+
+        // ---- pose blend shapes: off[comp] rows = vertices 4 g + r, columns = frames
+        f32x4 off[3];
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = mfma4(Bf[c3 * C_STRIDE + ks * 64 + lane], pfB[ks], acc);
+            off[c3] = acc;
+        }
+        // ---- skinning transforms T = sum_j W[v, j] A_j: 12 entries
+        f32x4 Tm[12];
+        {
+            float wv[6];
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) wv[ks] = Bf[PNDF_LBS_BLOB_W + ks * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) acc = mfma4(wv[ks], AB[e * 6 + ks], acc);
+                Tm[e] = acc;
+            }
+        }
+        const i32x4 fl = *(const i32x4*)(Bf + PNDF_LBS_BLOB_FL + 4 * g);
+        f32x4 vp[3], V[3];
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) vp[c3] = *(const f32x4*)(Bf + PNDF_LBS_BLOB_VS + c3 * GV + 4 * g) + off[c3];
+#pragma unroll
+        for (int a3 = 0; a3 < 3; ++a3) V[a3] = Tm[3 * a3] * vp[0] + Tm[3 * a3 + 1] * vp[1] + Tm[3 * a3 + 2] * vp[2] + Tm[9 + a3];
+
+        if constexpr (MODE == 0) {
+            if (t_ok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int v = grp * GV + 4 * g + r;
+                    if (v < a.V) {
+                        if (a.verts) {
+                            float* dst = a.verts + ((size_t)n * a.V + v) * 3;
+                            dst[0] = V[0][r]; dst[1] = V[1][r]; dst[2] = V[2][r];
+                        }
+                        if (fl[r] >= 0 && a.joints) {
+                            float* dst = a.joints + ((size_t)n * njt + NJ + fl[r]) * 3;
+                            dst[0] = V[0][r]; dst[1] = V[1][r]; dst[2] = V[2][r];
+                        }
+                    }
+                }
+            }
+            continue;
+        }
+
+        // ---- d L / d vertices of the tile
+        f32x4 gV[3];
+        if constexpr (MODE == 1) {
+            // temporal term: frame p + 1 is the next lane of the 16-lane row.  No epsilon under the root, as in the
+            // reference (motion_denoise.py:89): two identical consecutive vertices give NaN there and here.
+            f32x4 d[3], u[3];
+#pragma unroll
+            for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[a3][r] = V[a3][r] - __shfl_down(V[a3][r], 1, 16);
+            const f32x4 n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float inv = a.w_temp / sqrtf(n2[r]);
+                const bool ok = pair_ok && fl[r] != -2;
+#pragma unroll
+                for (int a3 = 0; a3 < 3; ++a3) u[a3][r] = ok ? d[a3][r] * inv : 0.f;
+            }
+#pragma unroll
+            for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float up = __shfl_up(u[a3][r], 1, 16);
+                    gV[a3][r] = u[a3][r] - (p > 0 ? up : 0.f);
+                }
+            // data term on the joints that are picked from vertices (the 24 chain joints: pndf_lbs_pose_backward_kernel)
+            if (a.it_gt0 && owned) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (fl[r] >= 0) {
+                        const float* j0 = a.joints0 + ((size_t)n * njt + NJ + fl[r]) * 3;
+                        const float dx = V[0][r] - j0[0], dy = V[1][r] - j0[1], dz = V[2][r] - j0[2];
+                        const float inv = a.w_data / sqrtf(dx * dx + dy * dy + dz * dz);
+                        gV[0][r] += dx * inv; gV[1][r] += dy * inv; gV[2][r] += dz * inv;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int v = grp * GV + 4 * g + r;
+                const bool ok = t_ok && v < a.V;
+#pragma unroll
+                for (int a3 = 0; a3 < 3; ++a3) {
+                    float gv = (ok && a.g_verts) ? a.g_verts[((size_t)n * a.V + v) * 3 + a3] : 0.f;
+                    if (ok && fl[r] >= 0 && a.g_joints) gv += a.g_joints[((size_t)n * njt + NJ + fl[r]) * 3 + a3];
+                    gV[a3][r] = gv;
+                }
+            }
+        }
+
+        // ---- reverse of the skinning: d L / d v_posed = T_R^T gV
+        f32x4 gvp[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) gvp[b] = Tm[b] * gV[0] + Tm[3 + b] * gV[1] + Tm[6 + b] * gV[2];
+        // ---- d L / d pose_feature[k] += sum_{v, comp} P[comp][k][v] gvp[comp][v]: rows = k, contraction = the tile's vertices
+        {
+            const float* Pt = Bf + p * GV + 4 * g;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                f32x4 acc = gpf[kt];
+#pragma unroll
+                for (int c3 = 0; c3 < 3; ++c3) {
+                    const f32x4 w = *(const f32x4*)(Pt + c3 * C_STRIDE + kt * 256);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = mfma4(w[r], gvp[c3][r], acc);
+                }
+                gpf[kt] = acc;
+            }
+        }
+        // ---- d L / d A[j][entry] += sum_v W[v, j] gV (x) [v_posed, 1]: rows = joints
+        {
+            const float* Wt = Bf + PNDF_LBS_BLOB_W + p * GV + 4 * g;
+            const f32x4 w0 = *(const f32x4*)Wt, w1 = *(const f32x4*)(Wt + 256);
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const f32x4 X = (e < 9) ? gV[e / 3] * vp[e % 3] : gV[e - 9];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gA[e][0] = mfma4(w0[r], X[r], gA[e][0]);
+                    gA[e][1] = mfma4(w1[r], X[r], gA[e][1]);
+                }
+            }
+        }
+    }
+    if constexpr (MODE != 0) {
+        if (t_ok) {
+            float* o_pf = owned ? a.gpf + ((size_t)vs * N + n) * PF : a.halo_pf + ((size_t)vs * nch + cid) * PF;
+            float* o_A = owned ? a.gA + ((size_t)vs * N + n) * A_FLOATS : a.halo_A + ((size_t)vs * nch + cid) * A_FLOATS;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) *(f32x4*)(o_pf + 16 * kt + 4 * g) = gpf[kt];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                *(f32x4*)(o_A + e * 32 + 4 * g) = gA[e][0];
+                *(f32x4*)(o_A + e * 32 + 16 + 4 * g) = gA[e][1];
+            }
+        }
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(256, 1) pndf_lbs_vertex_forward_kernel(PndfLbsArgs a) { lbs_vertex_body<0>(a); }
+extern "C" __global__ void __launch_bounds__(256, 1) pndf_lbs_vertex_terms_kernel(PndfLbsArgs a) { lbs_vertex_body<1>(a); }
+extern "C" __global__ void __launch_bounds__(256, 1) pndf_lbs_vertex_reverse_kernel(PndfLbsArgs a) { lbs_vertex_body<2>(a); }
+
+// ------------------------------------------------------------------ per-frame reverse
+extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_backward_kernel(PndfLbsArgs a) {
+    const long long N = (long long)a.S * a.T;
+    const long long n = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    const int T = a.T, s = (int)(n / T), t = (int)(n - (long long)s * T), njt = NJ + a.NE;
+    const int nch = a.S * a.cps;
+    float R[NJ][9], GR[NJ][9], Gt[NJ][3];
+    frame_transforms(a.theta + n * 69, a.model, R, GR, Gt);
+    // the frame a chunk of pairs shares with the next chunk got a second partial result there
+    const bool halo = a.halo_pf && t > 0 && t % 15 == 0 && t / 15 < a.cps;
+    const long long hidx = (long long)s * a.cps + t / 15 - 1;
+    auto sum_pf = [&](int k) {
+        float acc = 0.f;
+        for (int v = 0; v < a.vsplit; ++v) acc += a.gpf[((size_t)v * N + n) * PF + k];
+        if (halo)
+            for (int v = 0; v < a.vsplit; ++v) acc += a.halo_pf[((size_t)v * nch + hidx) * PF + k];
+        return acc;
+    };
+    auto sum_A = [&](int e, int j) {
+        float acc = 0.f;
+        for (int v = 0; v < a.vsplit; ++v) acc += a.gA[((size_t)v * N + n) * A_FLOATS + e * 32 + j];
+        if (halo)
+            for (int v = 0; v < a.vsplit; ++v) acc += a.halo_A[((size_t)v * nch + hidx) * A_FLOATS + e * 32 + j];
+        return acc;
+    };
+    float gGR[NJ][9], gGt[NJ][3], gR[NJ][9];
+    for (int j = 0; j < NJ; ++j) {
+        float gAt[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) gAt[e] = sum_A(9 + e, j);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) gGR[j][e] = sum_A(e, j) - gAt[e / 3] * a.model.J[j][e % 3];      // A_t = G_t - G_R J
+        // joints[:, :24] = G_t: data term (motion_denoise.py:93-94) or the caller's d L / d joints
+        float gj[3] = {0.f, 0.f, 0.f};
+        if (a.g_joints) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) gj[e] = a.g_joints[((size_t)n * njt + j) * 3 + e];
+        } else if (a.it_gt0 && a.joints0) {
+            const float* j0 = a.joints0 + ((size_t)n * njt + j) * 3;
+            const float dx = Gt[j][0] - j0[0], dy = Gt[j][1] - j0[1], dz = Gt[j][2] - j0[2];
+            const float inv = a.w_data / sqrtf(dx * dx + dy * dy + dz * dz);
+            gj[0] = dx * inv; gj[1] = dy * inv; gj[2] = dz * inv;
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) gGt[j][e] = gAt[e] + gj[e];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) gR[j][e] = (j > 0) ? sum_pf(9 * (j - 1) + e) : 0.f;                // pose_feature = R_1.. - I
+    }
+    for (int i = NJ - 1; i >= 1; --i) {          // reverse of G_i = G_parent [R_i | rel_i]
+        const int pj = a.model.parent[i];
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 3; ++y) {
+                float acc = 0.f, acc2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    acc += GR[pj][3 * k + x] * gGR[i][3 * k + y];          // G_R[p]^T gG_R[i]
+                    acc2 += gGR[i][3 * x + k] * R[i][3 * y + k];           // gG_R[i] R_i^T
+                }
+                gR[i][3 * x + y] += acc;
+                gGR[pj][3 * x + y] += acc2 + gGt[i][x] * a.model.rel[i][y];
+            }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) gGt[pj][e] += gGt[i][e];
+    }
+    for (int j = 1; j < NJ; ++j) {
+        float gr[3];
+        const float* th = a.theta + n * 69 + 3 * (j - 1);
+        rodrigues_vjp(th[0], th[1], th[2], gR[j], gr);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) a.g_theta[n * 69 + 3 * (j - 1) + e] = gr[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host: handle, packing, launches
+struct pndf_lbs_model {
+    int device = 0;
+    int V = 0, NG = 0, NE = 0;
+    float* d_blob = nullptr;
+    PndfLbsModel consts;
+    int sm_count = 256;
+    std::string err;
+};
+
+static thread_local std::string g_lbs_create_err;
+static int lbs_fail(pndf_lbs_model* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_lbs_create_err = msg;
+    return code;
+}
+
+extern "C" const char* pndf_lbs_last_error(pndf_lbs_handle h) { return h ? h->err.c_str() : g_lbs_create_err.c_str(); }
+
+extern "C" int64_t pndf_lbs_packed_floats(int32_t V) { return V < 1 ? 0 : (int64_t)((V + GV - 1) / GV) * BLOB; }
+
+// Host-only packer (needs no device): the model in MFMA tile order + the rest joints.  `J_out` (72 floats) and `rel_out`
+// (72 floats) may be null.  Returns 0 or a negative pndf_status.
+extern "C" int pndf_lbs_pack_host(int32_t V, int32_t NB, const float* v_template, const float* shapedirs, const float* betas,
+                                  const float* posedirs, const float* J_regressor, const int32_t* parents,
+                                  const float* lbs_weights, const int32_t* extra_joint_vertex, int32_t n_extra, float* blob,
+                                  float* J_out, float* rel_out) {
+    if (V < 1 || NB < 0 || !v_template || !posedirs || !J_regressor || !parents || !lbs_weights || !blob) return PNDF_ERR_BAD_ARG;
+    if (NB > 0 && (!shapedirs || !betas)) return PNDF_ERR_BAD_ARG;
+    if (n_extra < 0 || n_extra > PNDF_LBS_MAX_EXTRA || (n_extra > 0 && !extra_joint_vertex)) return PNDF_ERR_BAD_ARG;
+    if (parents[0] >= 0) return PNDF_ERR_UNSUPPORTED;
+    for (int j = 1; j < NJ; ++j)
+        if (parents[j] < 0 || parents[j] >= j) return PNDF_ERR_UNSUPPORTED;      // parents precede their children (SMPL)
+    for (int e = 0; e < n_extra; ++e)
+        if (extra_joint_vertex[e] < 0 || extra_joint_vertex[e] >= V) return PNDF_ERR_BAD_ARG;
+    // v_shaped = v_template + blend_shapes(betas, shapedirs); J = J_regressor v_shaped   (smplx lbs(), first two steps)
+    std::vector<float> vsh((size_t)V * 3);
+    for (int i = 0; i < V * 3; ++i) {
+        double acc = v_template[i];
+        for (int l = 0; l < NB; ++l) acc += (double)shapedirs[(size_t)i * NB + l] * betas[l];
+        vsh[i] = (float)acc;
+    }
+    float J[NJ][3];
+    for (int j = 0; j < NJ; ++j)
+        for (int e = 0; e < 3; ++e) {
+            double acc = 0.0;
+            for (int v = 0; v < V; ++v) acc += (double)J_regressor[(size_t)j * V + v] * vsh[(size_t)v * 3 + e];
+            J[j][e] = (float)acc;
+        }
+    for (int j = 0; j < NJ; ++j)
+        for (int e = 0; e < 3; ++e) {
+            if (J_out) J_out[3 * j + e] = J[j][e];
+            if (rel_out) rel_out[3 * j + e] = (j == 0) ? J[j][e] : J[j][e] - J[parents[j]][e];
+        }
+    const int NG = (V + GV - 1) / GV;
+    std::vector<int> flag((size_t)NG * GV, -2);
+    for (int v = 0; v < V; ++v) flag[v] = -1;
+    for (int e = 0; e < n_extra; ++e) flag[extra_joint_vertex[e]] = e;      // (a vertex picked twice keeps the last index)
+    memset(blob, 0, (size_t)NG * BLOB * sizeof(float));
+    const int npf = 9 * (NJ - 1);
+    for (int grp = 0; grp < NG; ++grp) {
+        float* b = blob + (size_t)grp * BLOB;
+        for (int vi = 0; vi < GV; ++vi) {
+            const int v = grp * GV + vi;
+            ((int*)(b + PNDF_LBS_BLOB_FL))[vi] = flag[(size_t)grp * GV + vi];
+            if (v >= V) continue;
+            for (int c = 0; c < 3; ++c) {
+                for (int k = 0; k < npf; ++k)
+                    b[PNDF_LBS_BLOB_P + c * C_STRIDE + k * GV + vi] = posedirs[(size_t)k * V * 3 + (size_t)v * 3 + c];
+                b[PNDF_LBS_BLOB_VS + c * GV + vi] = vsh[(size_t)v * 3 + c];
+            }
+            for (int j = 0; j < NJ; ++j) b[PNDF_LBS_BLOB_W + j * GV + vi] = lbs_weights[(size_t)v * NJ + j];
+        }
+    }
+    return PNDF_OK;
+}
+
+extern "C" int pndf_lbs_create(pndf_lbs_handle* out, int32_t V, int32_t NB, const float* v_template, const float* shapedirs,
+                               const float* betas, const float* posedirs, const float* J_regressor, const int32_t* parents,
+                               const float* lbs_weights, const int32_t* extra_joint_vertex, int32_t n_extra, int device) {
+    if (!out) return lbs_fail(nullptr, PNDF_ERR_BAD_ARG, "out is null");
+    *out = nullptr;
+    if (V < 1) return lbs_fail(nullptr, PNDF_ERR_BAD_ARG, "V < 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return lbs_fail(nullptr, PNDF_ERR_NO_DEVICE, "no HIP device " + std::to_string(device) + " (the body model has no CPU fallback)");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return lbs_fail(nullptr, PNDF_ERR_NO_DEVICE, "kernels are built for gfx950 only");
+    const int NG = (V + GV - 1) / GV;
+    std::vector<float> blob((size_t)NG * BLOB);
+    float J[NJ * 3], rel[NJ * 3];
+    const int rc = pndf_lbs_pack_host(V, NB, v_template, shapedirs, betas, posedirs, J_regressor, parents, lbs_weights,
+                                      extra_joint_vertex, n_extra, blob.data(), J, rel);
+    if (rc == PNDF_ERR_UNSUPPORTED)
+        return lbs_fail(nullptr, rc, "kinematic tree: 24 joints, parents[0] = -1 and every parent before its children (SMPL)");
+    if (rc != PNDF_OK) return lbs_fail(nullptr, rc, "null pointer, or an extra-joint vertex outside [0, V), or more than 32 of them");
+    DeviceGuard guard(device);
+    if (!guard.ok) return lbs_fail(nullptr, PNDF_ERR_HIP, "hipSetDevice failed");
+    pndf_lbs_model* h = new pndf_lbs_model();
+    h->device = device; h->V = V; h->NG = NG; h->NE = n_extra;
+    h->sm_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    memcpy(h->consts.J, J, sizeof(J));
+    memcpy(h->consts.rel, rel, sizeof(rel));
+    for (int j = 0; j < NJ; ++j) h->consts.parent[j] = parents[j];
+    hipError_t e = hipMalloc((void**)&h->d_blob, blob.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
+    const int lds = 2 * BLOB * (int)sizeof(float);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pndf_lbs_vertex_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pndf_lbs_vertex_terms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pndf_lbs_vertex_reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+        const std::string m = std::string("pndf_lbs_create: ") + hipGetErrorString(e);
+        if (h->d_blob) (void)hipFree(h->d_blob);
+        delete h;
+        return lbs_fail(nullptr, PNDF_ERR_HIP, m);
+    }
+    *out = h;
+    return PNDF_OK;
+}
+
+extern "C" int pndf_lbs_destroy(pndf_lbs_handle h) {
+    if (!h) return PNDF_OK;
+    DeviceGuard guard(h->device);
+    if (h->d_blob) (void)hipFree(h->d_blob);
+    delete h;
+    return PNDF_OK;
+}
+
+extern "C" int32_t pndf_lbs_num_joints(pndf_lbs_handle h) { return h ? NJ + h->NE : 0; }
+extern "C" int32_t pndf_lbs_num_vertices(pndf_lbs_handle h) { return h ? h->V : 0; }
+
+// vertex ranges per chunk quad: enough workgroups to fill the chip for small problems (deterministic in S, T only)
+static int lbs_vsplit(const pndf_lbs_model* h, int nch) {
+    const int quads = (nch + 3) / 4;
+    int vsplit = (2 * h->sm_count + quads - 1) / quads;
+    if (vsplit > 8) vsplit = 8;
+    if (vsplit > h->NG) vsplit = h->NG;
+    return vsplit < 1 ? 1 : vsplit;
+}
+
+// workspace layout (floats): pfp | Ap | Gt | gpf | gA | halo_pf | halo_A   (sized for the fused-terms mode, the largest)
+static int64_t lbs_workspace(const pndf_lbs_model* h, int64_t S, int64_t T, PndfLbsArgs* a, float* base, int mode) {
+    const int64_t N = S * T;
+    const int cps = (mode == 1) ? chunks_pairs((int)T) : chunks_fwd((int)T);
+    const int64_t nch = S * cps;
+    const int vsplit = lbs_vsplit(h, (int)nch);
+    int64_t off = 0;
+    auto take = [&](int64_t n) { const int64_t o = off; off += (n + 3) & ~(int64_t)3; return base ? base + o : nullptr; };
+    float* pfp = take(N * PF);
+    float* Ap = take(N * 288);
+    float* Gt = take(N * NJ * 3);
+    float* gpf = take((int64_t)vsplit * N * PF);
+    float* gA = take((int64_t)vsplit * N * A_FLOATS);
+    float* hpf = take((int64_t)vsplit * nch * PF);
+    float* hA = take((int64_t)vsplit * nch * A_FLOATS);
+    if (a) {
+        a->pfp = pfp; a->Ap = Ap; a->Gt = Gt; a->gpf = gpf; a->gA = gA;
+        a->halo_pf = (mode == 1) ? hpf : nullptr; a->halo_A = (mode == 1) ? hA : nullptr;
+        a->cps = cps; a->vsplit = vsplit;
+    }
+    return off;
+}
+
+extern "C" int64_t pndf_lbs_workspace_floats(pndf_lbs_handle h, int32_t S, int32_t T) {
+    if (!h || S < 1 || T < 1) return 0;
+    const int64_t a = lbs_workspace(h, S, T, nullptr, nullptr, 1), b = lbs_workspace(h, S, T, nullptr, nullptr, 2);
+    return a > b ? a : b;
+}
+
+static int lbs_launch(pndf_lbs_model* h, int mode, PndfLbsArgs& a, void* workspace, void* stream) {
+    if (((uintptr_t)workspace) & 15) return lbs_fail(h, PNDF_ERR_BAD_ARG, "workspace must be 16-byte aligned");
+    a.blob = h->d_blob; a.V = h->V; a.NG = h->NG; a.NE = h->NE; a.model = h->consts;
+    (void)lbs_workspace(h, a.S, a.T, &a, (float*)workspace, mode);
+    DeviceGuard guard(h->device);
+    if (!guard.ok) return lbs_fail(h, PNDF_ERR_HIP, "hipSetDevice failed");
+    const long long N = (long long)a.S * a.T;
+    const dim3 fgrid((unsigned)((N + 63) / 64)), fblock(64);
+    const dim3 vgrid((unsigned)(((long long)a.S * a.cps + 3) / 4), (unsigned)(mode == 0 ? 1 : a.vsplit)), vblock(256);
+    const int lds = 2 * BLOB * (int)sizeof(float);
+    if (mode == 0) a.vsplit = 1;
+    hipLaunchKernelGGL(pndf_lbs_pose_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
+    if (mode == 0) {
+        if (a.verts || (a.joints && a.NE > 0))
+            hipLaunchKernelGGL(pndf_lbs_vertex_forward_kernel, vgrid, vblock, lds, (hipStream_t)stream, a);
+    } else {
+        if (mode == 1) hipLaunchKernelGGL(pndf_lbs_vertex_terms_kernel, vgrid, vblock, lds, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(pndf_lbs_vertex_reverse_kernel, vgrid, vblock, lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(pndf_lbs_pose_backward_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lbs_fail(h, PNDF_ERR_HIP, std::string("launch: ") + hipGetErrorString(e));
+    return PNDF_OK;
+}
+
+static void lbs_clear(PndfLbsArgs& a) { memset(&a, 0, sizeof(a)); }
+
+extern "C" int pndf_lbs_forward(pndf_lbs_handle h, const float* theta, int64_t N, float* verts, float* joints, void* workspace,
+                                void* stream) {
+    if (!h) return PNDF_ERR_BAD_ARG;
+    if (N < 0 || N > 0x7fffffff) return lbs_fail(h, PNDF_ERR_BAD_ARG, "bad frame count");
+    if (N == 0) return PNDF_OK;
+    if (!theta || !workspace || (!verts && !joints)) return lbs_fail(h, PNDF_ERR_BAD_ARG, "null pointer");
+    PndfLbsArgs a;
+    lbs_clear(a);
+    a.theta = theta; a.verts = verts; a.joints = joints; a.S = 1; a.T = (int)N;
+    return lbs_launch(h, 0, a, workspace, stream);
+}
+
+extern "C" int pndf_lbs_terms_grad(pndf_lbs_handle h, const float* theta, const float* joints0, int32_t S, int32_t T, int32_t it,
+                                   float* g_theta, void* workspace, void* stream) {
+    if (!h) return PNDF_ERR_BAD_ARG;
+    if (S < 0 || T < 0 || it < 0) return lbs_fail(h, PNDF_ERR_BAD_ARG, "negative size");
+    if (S == 0 || T == 0) return PNDF_OK;
+    if (!theta || !g_theta || !workspace || (it > 0 && !joints0)) return lbs_fail(h, PNDF_ERR_BAD_ARG, "null pointer");
+    PndfLbsArgs a;
+    lbs_clear(a);
+    a.theta = theta; a.joints0 = joints0; a.g_theta = g_theta; a.S = S; a.T = T; a.it_gt0 = it > 0 ? 1 : 0;
+    // motion_denoise.py:31-32 weights over :89,94 means
+    a.w_temp = T > 1 ? 10.0f * (float)(1 + it) / ((float)(T - 1) * (float)h->V) : 0.f;
+    a.w_data = it > 0 ? 100.0f / (float)(1 + it) / ((float)T * (float)(NJ + h->NE)) : 0.f;
+    return lbs_launch(h, 1, a, workspace, stream);
+}
+
+extern "C" int pndf_lbs_backward(pndf_lbs_handle h, const float* theta, const float* g_verts, const float* g_joints, int64_t N,
+                                 float* g_theta, void* workspace, void* stream) {
+    if (!h) return PNDF_ERR_BAD_ARG;
+    if (N < 0 || N > 0x7fffffff) return lbs_fail(h, PNDF_ERR_BAD_ARG, "bad frame count");
+    if (N == 0) return PNDF_OK;
+    if (!theta || !g_theta || !workspace) return lbs_fail(h, PNDF_ERR_BAD_ARG, "null pointer");
+    PndfLbsArgs a;
+    lbs_clear(a);
+    a.theta = theta; a.g_verts = g_verts; a.g_joints = g_joints; a.g_theta = g_theta; a.S = 1; a.T = (int)N;
+    return lbs_launch(h, 2, a, workspace, stream);
+}

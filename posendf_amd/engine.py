@@ -65,6 +65,28 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.pndf_denoise_update.restype = c_int
     lib.pndf_denoise_update_body.argtypes = [c_void_p] * 9 + [c_int32] * 4 + [c_float, c_void_p]
     lib.pndf_denoise_update_body.restype = c_int
+    LH = c_void_p
+    lib.pndf_lbs_create.argtypes = [POINTER(LH), c_int32, c_int32] + [c_void_p] * 8 + [c_int32, c_int]
+    lib.pndf_lbs_create.restype = c_int
+    lib.pndf_lbs_destroy.argtypes = [LH]
+    lib.pndf_lbs_num_joints.argtypes = [LH]
+    lib.pndf_lbs_num_joints.restype = c_int32
+    lib.pndf_lbs_num_vertices.argtypes = [LH]
+    lib.pndf_lbs_num_vertices.restype = c_int32
+    lib.pndf_lbs_workspace_floats.argtypes = [LH, c_int32, c_int32]
+    lib.pndf_lbs_workspace_floats.restype = c_int64
+    lib.pndf_lbs_forward.argtypes = [LH, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.pndf_lbs_forward.restype = c_int
+    lib.pndf_lbs_terms_grad.argtypes = [LH, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]
+    lib.pndf_lbs_terms_grad.restype = c_int
+    lib.pndf_lbs_backward.argtypes = [LH, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]
+    lib.pndf_lbs_backward.restype = c_int
+    lib.pndf_lbs_packed_floats.argtypes = [c_int32]
+    lib.pndf_lbs_packed_floats.restype = c_int64
+    lib.pndf_lbs_pack_host.argtypes = [c_int32, c_int32] + [c_void_p] * 8 + [c_int32, c_void_p, c_void_p, c_void_p]
+    lib.pndf_lbs_pack_host.restype = c_int
+    lib.pndf_lbs_last_error.argtypes = [LH]
+    lib.pndf_lbs_last_error.restype = c_char_p
     lib.pndf_quat_topk.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p,
                                    c_void_p, c_void_p]
     lib.pndf_quat_topk.restype = c_int
@@ -83,7 +105,9 @@ EXPORTS = ("pndf_default_config", "pndf_create", "pndf_destroy", "pndf_load_weig
            "pndf_forward_grad", "pndf_project", "pndf_debug_forward_grad", "pndf_debug_floats",
            "pndf_debug_project_timing", "pndf_debug_timing_regions",
            "pndf_packed_sizes", "pndf_pack_host", "pndf_pack_host_split", "pndf_aa2quat", "pndf_denoise_update", "pndf_denoise_update_body", "pndf_quat_topk",
-           "pndf_last_error", "pndf_version", "pndf_kernel_name")
+           "pndf_lbs_create", "pndf_lbs_destroy", "pndf_lbs_num_joints", "pndf_lbs_num_vertices", "pndf_lbs_workspace_floats",
+           "pndf_lbs_forward", "pndf_lbs_terms_grad", "pndf_lbs_backward", "pndf_lbs_packed_floats", "pndf_lbs_pack_host",
+           "pndf_lbs_last_error", "pndf_last_error", "pndf_version", "pndf_kernel_name")
 
 
 def state_dict_order(encoder: bool = True):

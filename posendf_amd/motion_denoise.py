@@ -15,7 +15,10 @@ pose-space surrogates (per-joint axis-angle differences), which keep the objecti
 `optimize(fused=True)` runs the same loop without PyTorch in it: per Adam step one engine launch (distances and
 d d / d q for all S x T frames) and one HIP kernel (`pndf_denoise_update`, posendf_amd/csrc/pndf_denoise.hip) that
 does the per-sequence mean, the weights, the axis-angle Jacobian, the pose-space terms, Adam and the next step's
-quaternions -- 3 launches per step instead of ~60.  It needs `body_model is None` (the surrogate terms).
+quaternions -- 3 launches per step instead of ~60.  With `body_model is None` it optimises the surrogate terms; with a
+`posendf_amd.BodyModel` (the HIP linear-blend-skinning kernels, csrc/pndf_lbs.hip) it optimises the REFERENCE's objective:
+per Adam step the engine launch, the fused body-model pass (`pndf_lbs_terms_grad`: vertices, the vertex temporal term and the
+joint data term of motion_denoise.py:86-94 and their gradient, nothing per-vertex in HBM) and `pndf_denoise_update_body`.
 
 Sequences are independent problems (one `main()` per sequence in the reference, :171-188): a batch [S, T, 69] is
 optimised with per-sequence means, one engine launch per Adam step for all S x T frames.
@@ -63,7 +66,12 @@ class MotionDenoise:
         if self.body_model is None:
             pts = body_pose.reshape(S, T, 23, 3)[:, :, :21]          # pose-space surrogate "vertices" = "joints"
             return pts, pts
-        v, j = self.body_model(body_pose.reshape(S * T, 69))
+        from .body_model import BodyModel
+        if isinstance(self.body_model, BodyModel):          # the reference's call (motion_denoise.py:86): vertices and Jtr
+            out = self.body_model(pose_body=body_pose.reshape(S * T, 69))
+            v, j = out.vertices, out.Jtr
+        else:
+            v, j = self.body_model(body_pose.reshape(S * T, 69))
         return v.reshape(S, T, *v.shape[1:]), j.reshape(S, T, *j.shape[1:])
 
     def _mean_norm(self, x):
@@ -92,8 +100,11 @@ class MotionDenoise:
     def _optimize_fused(self, pose, iterations, steps_per_iter, lr):
         """The loop of `optimize` on the engine + pndf_denoise_update, no autograd (module docstring)."""
         import ctypes
-        if self.body_model is not None:
-            raise ValueError("fused=True implements the pose-space surrogate terms only (body_model must be None)")
+        from .body_model import BodyModel
+        bm = self.body_model
+        if bm is not None and not isinstance(bm, BodyModel):
+            raise ValueError("fused=True needs body_model None (pose-space surrogates) or a posendf_amd.BodyModel (HIP LBS); "
+                             "an arbitrary callable runs through the autograd driver (fused=False)")
         S, T = pose.shape[:2]
         N = S * T
         dev = pose.device
@@ -108,14 +119,23 @@ class MotionDenoise:
         dq = torch.empty(N, 21, 4, device=dev, dtype=torch.float32)
         if lib.pndf_aa2quat(bufs[0].data_ptr(), q.data_ptr(), N, stream) != 0:
             raise RuntimeError("pndf_aa2quat failed")
+        if bm is not None:
+            joints0 = bm.joints_of(theta0)                  # smpl_init.Jtr of the noisy poses (motion_denoise.py:60,63)
+            g_body = torch.empty_like(theta0)
         k = 0
         for it in range(iterations):
             for _ in range(steps_per_iter):
                 k += 1
                 eng.forward_grad(q.data_ptr(), None, d.data_ptr(), dq.data_ptr(), N, stream.value or 0)
-                rc = lib.pndf_denoise_update(bufs[0].data_ptr(), bufs[1].data_ptr(), theta0.data_ptr(), d.data_ptr(),
-                                             dq.data_ptr(), m.data_ptr(), v.data_ptr(), q.data_ptr(), S, T, it, k,
-                                             float(lr), stream)
+                if bm is not None:
+                    bm.terms_grad(bufs[0], joints0, it, out=g_body)
+                    rc = lib.pndf_denoise_update_body(bufs[0].data_ptr(), bufs[1].data_ptr(), theta0.data_ptr(), d.data_ptr(),
+                                                      dq.data_ptr(), g_body.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                                      q.data_ptr(), S, T, it, k, float(lr), stream)
+                else:
+                    rc = lib.pndf_denoise_update(bufs[0].data_ptr(), bufs[1].data_ptr(), theta0.data_ptr(), d.data_ptr(),
+                                                 dq.data_ptr(), m.data_ptr(), v.data_ptr(), q.data_ptr(), S, T, it, k,
+                                                 float(lr), stream)
                 if rc != 0:
                     raise RuntimeError(f"pndf_denoise_update failed ({rc})")
                 bufs.reverse()

@@ -112,7 +112,7 @@ def pose_gate(err, sigma, what="", factor=8.0, floor=8e-6, exempt=None, tol=1e-4
     assert np.median(err) <= max(tol / 10, factor * float(np.median(sigma))), (what, float(np.median(err)))
 
 
-def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0, margin=None, kink_tol=1e-5, cap=10.0):
+def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0, margin=None, kink_tol=1e-5, cap=10.0, sigma=None):
     """Gate for quantities that are DISCONTINUOUS in the input (d d/d q and everything derived from it):
     a pre-activation within rounding of a ReLU/LeakyReLU kink flips its derivative (1 vs slope), so any two
     fp32 evaluations -- including the reference's own fp32 run against its fp64 run -- disagree by O(1) on a
@@ -124,7 +124,9 @@ def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0, margin=None,
 
     Outlier MAGNITUDE (round 3; the fraction alone let single poses be arbitrarily wrong).  Every pose above `tol` must be
     EXPLAINED: either the reference arithmetic's own fp32 run is off at that pose too (ref_rows > tol / 4: an
-    ill-conditioned pose or a trajectory that the reference itself cannot hold), or -- relu family, when the caller
+    ill-conditioned pose or a trajectory that the reference itself cannot hold), or the error is within 8 x the fp32
+    sensitivity of the reference arithmetic at that pose (`sigma`: fp32_noise / traj_envelope -- one fp32 run may be lucky
+    where eight perturbed ones are not: the s4g25 softplus poses), or -- relu family, when the caller
     supplies `margin` (oracle kink_margin / trajectory_kink_margin of the fp64 run) -- a pre-activation came within
     `kink_tol` of a kink, where the derivative may legitimately flip.  Unexplained outliers fail.  Outliers explained by
     the reference's own error are capped at `cap` x the reference run's largest error; kink poses, whose error after a
@@ -144,11 +146,12 @@ def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0, margin=None,
     out = mine_rows > tol
     by_ref = ref_rows > tol / 4
     by_kink = np.zeros(n, bool) if margin is None else (np.asarray(margin) < kink_tol)
-    unexplained = out & ~by_ref & ~by_kink
+    by_sigma = np.zeros(n, bool) if sigma is None else (mine_rows <= 8.0 * np.asarray(sigma, dtype=np.float64) + 8e-6)
+    unexplained = out & ~by_ref & ~by_kink & ~by_sigma
     assert not unexplained.any(), (what, "outliers that neither the reference's fp32 error nor a kink explains",
                                    np.flatnonzero(unexplained)[:8].tolist(), mine_rows[unexplained][:8].tolist(),
                                    ref_rows[unexplained][:8].tolist())
-    capped = out & by_ref & ~by_kink
+    capped = out & by_ref & ~by_kink & ~by_sigma
     if capped.any():
         assert mine_rows[capped].max() <= cap * max(float(ref_rows.max()), tol), (
             what, "outlier magnitude", float(mine_rows[capped].max()), float(ref_rows.max()))
@@ -159,6 +162,26 @@ def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0, margin=None,
     print(f"[gate {what}] n {n} median {np.median(mine_rows):.2e} p95 {np.percentile(mine_rows, 95):.2e} max {mine_rows.max():.2e}"
           f" | ref p95 {np.percentile(ref_rows, 95):.2e} max {ref_rows.max():.2e} | outliers {int(out.sum())}"
           f" (ref-explained {int((out & by_ref).sum())}, kink {int(kinked.sum())})")
+
+
+def traj_envelope(q, sd, act, steps, truth_q, draws=4, seed=1, truth_d=None, d_metric=None):
+    """`margin` and `sigma` arguments of outlier_gate for a free-running `steps`-step projection from q: the kink margins
+    along the fp64 trajectory (traj_margin) and the per-pose fp32 sensitivity of the REFERENCE arithmetic -- the largest
+    error against `truth_q` (the fp64 trajectory's end point) over `draws` fp32 oracle trajectories whose inputs are
+    perturbed by one fp32 rounding.  With `truth_d` (+ `d_metric(d, truth_d)` -> per-pose errors, default d_rows) a second
+    envelope for the distance of the last iteration is returned as well: (env_q, env_d)."""
+    from oracle import posendf_np as onp
+    q = np.asarray(q, dtype=np.float32)
+    rng = np.random.default_rng(seed)
+    sig, sig_d = [], []
+    for _ in range(draws):
+        qk = (q * (1 + rng.uniform(-2.0 ** -23, 2.0 ** -23, q.shape))).astype(np.float32)
+        qo, do = onp.project(qk, sd, steps=steps, act=act)
+        sig.append(rel_err_rows(qo, truth_q))
+        if truth_d is not None:
+            sig_d.append((d_metric or d_rows)(do.reshape(-1), truth_d))
+    env = dict(margin=traj_margin(q, sd, act, steps), sigma=np.max(sig, axis=0))
+    return env if truth_d is None else (env, dict(margin=env["margin"], sigma=np.max(sig_d, axis=0)))
 
 
 def traj_margin(q, sd, act, steps=1):

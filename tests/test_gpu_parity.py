@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import (ALL_REGIMES, LITE_REGIMES, REGIMES, d_err, d_rows, fp32_noise, golden_weights, load_golden, outlier_gate,
-                      pose_gate, rel_err, rel_err_rows, traj_margin)
+                      pose_gate, rel_err, rel_err_rows, traj_envelope, traj_margin)
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -78,7 +78,7 @@ def test_golden_single_step(torch_cuda, act, regime, precision):
         assert e_d[i] <= 8 * sig_d[i] + 8e-6, (name, "d", e_d[i], sig_d[i])
         assert e_g[i] <= 8 * sig_g[i] + 8e-6 or (ex is not None and ex[i]), (name, "dq", e_g[i], sig_g[i])
         assert np.isfinite(d_np[i]).all() and np.isfinite(dq_np[i]).all(), name
-    outlier_gate(e_g, rel_err_rows(g["dq_f32"], g["dq_f64"]), TOL, "dq", margin=traj_margin(g["q"], sd, act))
+    outlier_gate(e_g, rel_err_rows(g["dq_f32"], g["dq_f64"]), TOL, "dq", margin=traj_margin(g["q"], sd, act), sigma=sig_g)
     # forward-only launch gives the same distances as the forward+grad launch
     with torch.no_grad():
         d2 = net(torch.from_numpy(g["q"]), train=False)["dist_pred"]      # CPU tensor is moved (posendf.py:64)
@@ -107,8 +107,8 @@ def test_golden_autograd_contract(torch_cuda, act, precision, regime):
     truth = g["dq_f64"] * g["grad_out"].reshape(-1, 1, 1)
     ref_rows = rel_err_rows(g["grad_pose_f32"], truth)
     margin = traj_margin(g["q"], sd, act)
-    outlier_gate(rel_err_rows(q.grad.cpu().numpy(), truth), ref_rows, TOL, "grad_out", margin=margin)
     _, sig_g, _, _ = fp32_noise(g["q"], sd, act, extra_g=[ref_rows])
+    outlier_gate(rel_err_rows(q.grad.cpu().numpy(), truth), ref_rows, TOL, "grad_out", margin=margin, sigma=sig_g)
     pose_gate(rel_err_rows(q.grad.cpu().numpy(), truth), sig_g, "grad_out", exempt=kink_exempt(g["q"], sd, act))
     for it in (() if regime in LITE_REGIMES else (0, 3)):
         q = torch.from_numpy(g["q"]).cuda().requires_grad_(True)
@@ -119,7 +119,7 @@ def test_golden_autograd_contract(torch_cuda, act, precision, regime):
         scale = 2e7 * g["d_f64"].mean() / ((1 + it) * len(g["q"]))
         truth = g["dq_f64"] * scale
         outlier_gate(rel_err_rows(q.grad.cpu().numpy(), truth), rel_err_rows(g[f"prior_grad_it{it}"], truth),
-                     2 * TOL, "prior", margin=margin)
+                     2 * TOL, "prior", margin=margin, sigma=sig_g)
 
 
 @pytest.mark.parametrize("act,precision", cases(ALL_ACTS))
@@ -138,22 +138,22 @@ def test_golden_projection(torch_cuda, act, regime, precision):
         truth = g[f"q{steps}_f64"]
         mine = rel_err_rows(qp, truth)
         ref = rel_err_rows(g[f"q{steps}_f32"], truth)
-        margin = traj_margin(g["q"], golden_weights(regime), act, steps)
-        outlier_gate(mine, ref, TOL, f"project{steps}", margin=margin)       # includes BASELINE.md section 5's p95 gate
+        dref64 = g["dtrace_f64"][steps - 1]
+        floor = max(0.05 * np.abs(dref64).max(), 1e-30)       # s2g3: every pose is clipped (d == 0) after a few steps
+        derr = lambda a, t=None: np.abs(np.asarray(a, np.float64).reshape(-1) - dref64) / np.maximum(np.abs(dref64), floor)
+        env, env_d = traj_envelope(g["q"], golden_weights(regime), act, steps, truth, truth_d=dref64, d_metric=derr)
+        outlier_gate(mine, ref, TOL, f"project{steps}", **env)       # includes BASELINE.md section 5's p95 gate
         if regime in REGIMES:      # the original headline statement: 90 % of the poses inside the bar, unconditionally
             assert np.percentile(mine, 90) < TOL, (steps, float(np.percentile(mine, 90)))
         # d_last is dist_pred of the last iteration (before its update); along a free-running trajectory it
         # is subject to the same kink divergence as q, so it gets the same outlier gate
-        dref64 = g["dtrace_f64"][steps - 1]
-        floor = max(0.05 * np.abs(dref64).max(), 1e-30)       # s2g3: every pose is clipped (d == 0) after a few steps
-        derr = lambda a: np.abs(np.asarray(a, np.float64) - dref64) / np.maximum(np.abs(dref64), floor)
         if steps == 1 and regime in REGIMES:
             assert d_err(dl.cpu().numpy()[:, 0], g["dtrace_f32"][0]) < TOL
         elif steps == 1:
             sig_d, _, _, _ = fp32_noise(g["q"], golden_weights(regime), act, extra_d=[d_rows(g["dtrace_f32"][0], dref64)])
             pose_gate(d_rows(dl.cpu().numpy()[:, 0], dref64), sig_d, "d_last1")
         else:
-            outlier_gate(derr(dl.cpu().numpy()[:, 0]), derr(g["dtrace_f32"][steps - 1]), 20 * TOL, f"d_last{steps}", margin=margin)
+            outlier_gate(derr(dl.cpu().numpy()[:, 0]), derr(g["dtrace_f32"][steps - 1]), 20 * TOL, f"d_last{steps}", **env_d)
 
 
 @pytest.mark.parametrize("act,precision", cases(["lrelu", "softplus"]))
@@ -171,11 +171,12 @@ def test_ragged_batches_match_oracle(torch_cuda, B, act, precision):
     do, go = onp.forward_grad(qn, sd, act)
     _, g64 = onp.forward_grad(qn, sd, act, dtype=np.float64)
     assert d_err(d.detach().cpu().numpy(), do) < TOL
-    outlier_gate(rel_err_rows(dq.cpu().numpy(), g64), rel_err_rows(go, g64), TOL, "dq", margin=traj_margin(qn, sd, act))
+    outlier_gate(rel_err_rows(dq.cpu().numpy(), g64), rel_err_rows(go, g64), TOL, "dq", margin=traj_margin(qn, sd, act),
+                 sigma=fp32_noise(qn, sd, act)[1])
     qp, _ = net.project(q.detach(), steps=4)
     q64, _ = onp.project(qn, sd, steps=4, act=act, dtype=np.float64)
     q32, _ = onp.project(qn, sd, steps=4, act=act)
-    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project4", margin=traj_margin(qn, sd, act, 4))
+    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project4", **traj_envelope(qn, sd, act, 4, q64))
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -232,7 +233,7 @@ def test_full_size_properties(torch_cuda, act, precision):
     idx = np.random.default_rng(0).choice(B, 256, replace=False)
     q64, _ = onp.project(qn[idx], sd, steps=10, act=act, dtype=np.float64)
     q32, _ = onp.project(qn[idx], sd, steps=10, act=act)
-    outlier_gate(rel_err_rows(q10[idx].cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project10", margin=traj_margin(qn[idx], sd, act, 10))
+    outlier_gate(rel_err_rows(q10[idx].cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project10", **traj_envelope(qn[idx], sd, act, 10, q64))
     # (5) the projection decreases the predicted distance on average (it is a descent on d^2 / 2)
     d0 = net(q, train=False)["dist_pred"]
     q100, dl100 = net.project(q, steps=100)
@@ -243,10 +244,9 @@ def test_full_size_properties(torch_cuda, act, precision):
     idx100 = np.random.default_rng(1).choice(B, 256, replace=False)
     q64, d64 = onp.project(qn[idx100], sd, steps=100, act=act, dtype=np.float64)
     q32, d32 = onp.project(qn[idx100], sd, steps=100, act=act)
-    margin100 = traj_margin(qn[idx100], sd, act, 100)
-    outlier_gate(rel_err_rows(q100[idx100].cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project100 at B = 65,536",
-                 margin=margin100)
-    outlier_gate(d_rows(dl100[idx100].cpu().numpy(), d64), d_rows(d32, d64), 20 * TOL, "d_last100 at B = 65,536", margin=margin100)
+    env100, envd100 = traj_envelope(qn[idx100], sd, act, 100, q64, truth_d=d64.reshape(-1))
+    outlier_gate(rel_err_rows(q100[idx100].cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project100 at B = 65,536", **env100)
+    outlier_gate(d_rows(dl100[idx100].cpu().numpy(), d64), d_rows(d32, d64), 20 * TOL, "d_last100 at B = 65,536", **envd100)
     # (6) steps = 0 is the identity
     q0, _ = net.project(q, steps=0)
     assert torch.equal(q0, q)
@@ -463,7 +463,7 @@ def test_narrower_architecture_runs_zero_padded(torch_cuda, act, precision):
     qp, _ = net.project(q.detach(), steps=5)
     q64, _ = onp.project(qn, sd, steps=5, act=act, dtype=np.float64)
     q32, _ = onp.project(qn, sd, steps=5, act=act)
-    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project5", margin=traj_margin(qn, sd, act, 5))
+    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project5", **traj_envelope(qn, sd, act, 5, q64))
 
 
 @pytest.mark.parametrize("hidden", [[1, 1, 1, 1, 1, 1], [17, 33, 65, 31, 15, 1], [256, 512, 1024, 512, 256, 63],
@@ -497,7 +497,7 @@ def test_narrower_architecture_width_extremes(torch_cuda, act, precision, hidden
     qp, dl = net.project(q.detach(), steps=3)
     q64, _ = onp.project(qn, sd, steps=3, act=act, dtype=np.float64)
     q32, _ = onp.project(qn, sd, steps=3, act=act)
-    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project3", margin=traj_margin(qn, sd, act, 3))
+    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project3", **traj_envelope(qn, sd, act, 3, q64))
 
 
 def _rescaled(sd, c):

@@ -55,5 +55,5 @@ def test_sweep(weights, act, signed, precision):
     q32, _ = onp.project(qn[idx], sd, steps=5, act=act)
     qp, _ = net.project(q.detach()[idx].contiguous(), steps=5)
     from conftest import outlier_gate
-    from conftest import traj_margin
-    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), 1e-4, "project5", margin=traj_margin(qn[idx], sd, act, 5))
+    from conftest import traj_envelope
+    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), 1e-4, "project5", **traj_envelope(qn[idx], sd, act, 5, q64))

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import d_err, outlier_gate, rel_err_rows, traj_margin
+from conftest import d_err, fp32_noise, outlier_gate, rel_err_rows, traj_envelope, traj_margin
 from posendf_amd import synth
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -60,12 +60,12 @@ def test_engine_matches_reference_vectors(act, precision):
     (dq,) = torch.autograd.grad(d, q, grad_outputs=torch.ones_like(d))
     assert d_err(d.detach().cpu().numpy(), g["d_f32"]) < TOL
     outlier_gate(rel_err_rows(dq.cpu().numpy(), g["dq_f64"]), rel_err_rows(g["dq_f32"], g["dq_f64"]), TOL, "dq",
-                 margin=traj_margin(g["q"], weights(), act))
+                 margin=traj_margin(g["q"], weights(), act), sigma=fp32_noise(g["q"], weights(), act)[1])
     for steps in (1, 10, 100):
         qp, _ = net.project(q.detach(), steps=steps)
         truth = g[f"q{steps}_f64"]
         outlier_gate(rel_err_rows(qp.cpu().numpy(), truth), rel_err_rows(g[f"q{steps}_f32"], truth), TOL, f"project{steps}",
-                     margin=traj_margin(g["q"], weights(), act, steps))
+                     **traj_envelope(g["q"], weights(), act, steps, truth))
 
 
 @pytest.mark.gpu
@@ -112,4 +112,4 @@ def test_noenc_narrower_combination(act, precision):
     qp, _ = net.project(q.detach(), steps=5)
     q64, _ = onp.project(qn, sd, steps=5, act=act, dtype=np.float64)
     q32, _ = onp.project(qn, sd, steps=5, act=act)
-    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project5", margin=traj_margin(qn, sd, act, 5))
+    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "project5", **traj_envelope(qn, sd, act, 5, q64))

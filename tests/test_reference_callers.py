@@ -9,7 +9,7 @@ the real reference produced for the same inputs (tests/golden)."""
 import numpy as np
 import pytest
 
-from conftest import golden_weights, load_golden, outlier_gate, rel_err_rows, traj_margin
+from conftest import fp32_noise, golden_weights, load_golden, outlier_gate, rel_err_rows, traj_envelope, traj_margin
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -49,7 +49,7 @@ def test_sample_pose_project_block(act, precision):
     out = noisy_poses.detach().cpu().numpy()
     truth = g["q10_f64"]
     outlier_gate(rel_err_rows(out, truth), rel_err_rows(g["q10_f32"], truth), TOL, "sample_poses block",
-                 margin=traj_margin(g["q"], golden_weights("live"), act, 10))
+                 **traj_envelope(g["q"], golden_weights("live"), act, 10, truth))
     assert abs(means[0].item() - g["dtrace_f32"][0].mean()) <= TOL * abs(g["dtrace_f32"][0].mean())
     # the fused persistent launch computes the same ten iterations, bit for bit (product rounded, then subtracted)
     fused, _ = pose_prior.project(start, steps=10)
@@ -98,7 +98,8 @@ def test_motion_denoise_pose_prior_block(act, precision):
         scale = 2e7 * g["d_f64"].mean() / ((1 + it) * len(g["q"]))
         truth = g["dq_f64"] * scale
         outlier_gate(rel_err_rows(pose_quat.grad.cpu().numpy(), truth), rel_err_rows(g[f"prior_grad_it{it}"], truth),
-                     2 * TOL, "pose_pr block", margin=traj_margin(g["q"], golden_weights("mixed"), act))
+                     2 * TOL, "pose_pr block", margin=traj_margin(g["q"], golden_weights("mixed"), act),
+                     sigma=fp32_noise(g["q"], golden_weights("mixed"), act)[1])
         before = pose_quat.detach().clone()
         optimizer.step()                                                 # :99
         moved = (pose_quat.detach() - before).abs()
@@ -126,7 +127,7 @@ def test_forward_grad_full_size_with_grad_out():
         (g1,) = torch.autograd.grad(d, q, grad_outputs=torch.ones_like(d))
         truth = g64 * go[idx].reshape(-1, 1, 1)
         outlier_gate(rel_err_rows(gq[idx].cpu().numpy(), truth), rel_err_rows(g32 * go[idx].reshape(-1, 1, 1), truth), TOL,
-                     "grad_out at B = 65,536", margin=traj_margin(qn[idx], sd, "lrelu"))
+                     "grad_out at B = 65,536", margin=traj_margin(qn[idx], sd, "lrelu"), sigma=fp32_noise(qn[idx], sd, "lrelu")[1])
         assert np.abs(d[idx, 0].detach().cpu().numpy() - d64[:, 0]).max() <= TOL * np.abs(d64).max()
         # linear in grad_outputs (the facade multiplies the saved unit gradient)
         assert torch.equal(gq, torch.from_numpy(go).cuda().reshape(-1, 1, 1) * g1)

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, d_rows, fp32_noise, outlier_gate, pose_gate, rel_err_rows, traj_margin
+from conftest import GOLDEN, d_rows, fp32_noise, outlier_gate, pose_gate, rel_err_rows, traj_envelope, traj_margin
 
 ACTS = ("lrelu", "softplus")
 TOL = 1e-4
@@ -120,12 +120,14 @@ def test_trained_projection(torch_cuda, act, precision):
     q0 = torch.from_numpy(g["q"]).cuda()
     for steps in (1, 10):
         qp, d_last = net.project(q0, steps=steps)
-        outlier_gate(rel_err_rows(qp.cpu().numpy(), g[f"q{steps}_f64"]),
-                     rel_err_rows(g[f"q{steps}_f32"], g[f"q{steps}_f64"]), TOL, f"q{steps}", margin=traj_margin(g["q"], sd, act, steps))
         ref = g["dtrace_f64"][steps - 1]
+        dm = lambda a, t=None: np.abs(np.asarray(a, np.float64).reshape(-1) - ref) / np.maximum(np.abs(ref), 0.05 * np.abs(ref).max())
+        env, env_d = traj_envelope(g["q"], sd, act, steps, g[f"q{steps}_f64"], truth_d=ref, d_metric=dm)
+        outlier_gate(rel_err_rows(qp.cpu().numpy(), g[f"q{steps}_f64"]),
+                     rel_err_rows(g[f"q{steps}_f32"], g[f"q{steps}_f64"]), TOL, f"q{steps}", **env)
         err = np.abs(d_last.cpu().numpy().reshape(-1) - ref) / np.maximum(np.abs(ref), 0.05 * np.abs(ref).max())
         ref32 = np.abs(g["dtrace_f32"][steps - 1] - ref) / np.maximum(np.abs(ref), 0.05 * np.abs(ref).max())
-        outlier_gate(err, ref32, TOL, f"d_last{steps}", margin=traj_margin(g["q"], sd, act, steps))
+        outlier_gate(err, ref32, TOL, f"d_last{steps}", **env_d)
 
 
 @pytest.mark.gpu

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_weights, outlier_gate, rel_err_rows
+from conftest import golden_weights, outlier_gate, rel_err_rows, traj_envelope
 
 SHARDS = 8
 
@@ -87,8 +87,8 @@ def test_config3_batch_524288_as_eight_virtual_shards(rccl_single_rank, act, pre
     q0 = q_all[idx].cpu().numpy()
     q64, _ = onp.project(q0, sd, steps=steps, act=act, dtype=np.float64)
     q32, _ = onp.project(q0, sd, steps=steps, act=act)
-    margin = onp.trajectory_kink_margin(q0, sd, steps, act)
-    outlier_gate(rel_err_rows(q_sh[idx].cpu().numpy(), q64), rel_err_rows(q32, q64), 1e-4, "config3 project100", margin=margin)
+    outlier_gate(rel_err_rows(q_sh[idx].cpu().numpy(), q64), rel_err_rows(q32, q64), 1e-4, "config3 project100",
+                 **traj_envelope(q0, sd, act, steps, q64))
     # the projection is a descent on d^2 / 2 for every shard
     d0 = net(q_all[: B // SHARDS], train=False)["dist_pred"]
     assert d_sh[: B // SHARDS].mean() < d0.mean()
