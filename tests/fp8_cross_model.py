@@ -1,0 +1,98 @@
+"""CPU emulation behind DESIGN.md "what the >= 10x target costs": the split-precision trunk with its two CROSS terms on
+scaled fp8 (gfx950's double-rate v_mfma_f32_16x16x128_f8f6f4) and the hi x hi term kept on fp16,
+    W x  ~=  Wh xh (fp16 MFMA)  +  q8(Wh) q8(xl)  +  q8(Wl) q8(xh)   (fp8 e4m3 MFMAs, fp32 accumulate)
+against the three-fp16-term arithmetic of the product kernels (precision f16x3) and fp64 truth, on the trunk of the
+reference network (oracle/posendf_np.py supplies the encoder, the activations and the reverse pass structure).
+Test infrastructure / analysis only: no kernel implements `f16f8`; tests/test_fp8_cross_terms.py records the verdict.
+
+Scaling gives fp8 its best case: weights per layer and operands per pose by exact powers of two as in the product, and --
+`block=32` -- additionally one power of two per 32 contraction elements (the MX block scale of the f8f6f4 instruction)."""
+import numpy as np
+
+from oracle import posendf_np as onp
+
+
+def q_e4m3(x):
+    """round to nearest fp8 e4m3 (OCP: 3 mantissa bits, exponents 2^-6 .. 2^8, max 448, subnormal step 2^-9)"""
+    x = np.asarray(x, np.float64)
+    m, e = np.frexp(np.abs(x))                      # |x| = m 2^e, m in [0.5, 1)
+    e = np.clip(e - 1, -6, 8)                       # exponent of the leading bit, clamped to the normal range
+    step = np.ldexp(1.0, e - 3)
+    q = np.minimum(np.round(np.abs(x) / step) * step, 448.0)
+    return np.sign(x) * q
+
+
+def _pow2_scale(a, top, axis=None):
+    """power of two s with max|a| s in [top / 2, top)"""
+    m = np.abs(a).max(axis=axis, keepdims=axis is not None)
+    m = np.where(m > 0, m, 1.0)
+    return np.ldexp(1.0, (np.log2(top) - np.floor(np.log2(m)) - 1).astype(int))
+
+
+def _split16(a):
+    hi = a.astype(np.float16).astype(np.float64)
+    lo = (a - hi).astype(np.float16).astype(np.float64)
+    return hi, lo
+
+
+def _q8_blocks(a, block, axis):
+    """fp8 with one power-of-two scale per `block` elements along `axis` (block = 0: one per row / pose)"""
+    if block == 0:
+        s = _pow2_scale(a, 256.0, axis=axis)
+        return q_e4m3(a * s) / s
+    a2 = np.moveaxis(a, axis, -1)
+    k = a2.shape[-1]
+    pad = (-k) % block
+    ap = np.pad(a2, [(0, 0)] * (a2.ndim - 1) + [(0, pad)]).reshape(a2.shape[:-1] + (-1, block))
+    s = _pow2_scale(ap, 256.0, axis=-1)
+    out = (q_e4m3(ap * s) / s).reshape(a2.shape[:-1] + (-1,))[..., :k]
+    return np.moveaxis(out, -1, axis)
+
+
+def split_matmul(x, W, mode, block=32):
+    """x [B,K] @ W[N,K]^T under the emulated arithmetic.  mode: 'f16x3' (product), 'f16f8' (cross terms on fp8)."""
+    sw = _pow2_scale(W, 2.0 ** 13)                                # per layer
+    sx = _pow2_scale(x, 2.0 ** 14, axis=1)                        # per pose
+    Wh, Wl = _split16(W * sw)
+    xh, xl = _split16(x * sx)
+    acc = (xh @ Wh.T).astype(np.float32).astype(np.float64)
+    if mode == "f16x3":
+        acc = acc + xl @ Wh.T + xh @ Wl.T
+    else:
+        acc = acc + _q8_blocks(xl, block, 1) @ _q8_blocks(Wh, block, 1).T + _q8_blocks(xh, block, 1) @ _q8_blocks(Wl, block, 1).T
+    return (acc.astype(np.float32).astype(np.float64) / sx) / sw
+
+
+def forward_grad(q, sd, act, mode, block=32, beta=100.0):
+    """d and d d / d q with the six wide trunk layers (lin0..lin5, forward and reverse) under `mode`; encoder, lin6, the
+    activations and everything else in fp64 (they are fp32 / exact in the kernels: this isolates the trunk arithmetic)."""
+    dt = np.float64
+    q = np.asarray(q, dt).reshape(-1, 21, 4)
+    n, denom = onp.normalize_joint_axis(q)
+    f, ecache = onp.encoder_forward(n, sd, act, beta, keep=True)
+    x, zs = f, []
+    for l in range(7):
+        W, b = np.asarray(sd[f"dfnet.lin{l}.weight"], dt), np.asarray(sd[f"dfnet.lin{l}.bias"], dt)
+        z = (split_matmul(x, W, mode, block) if l < 6 else x @ W.T) + b
+        zs.append(z)
+        x = onp._act(z, act, beta) if l < 6 else onp._act(z, onp._out_kind(act), beta)
+    d = x
+    g = onp._dact(zs[-1], onp._out_kind(act), beta)
+    for l in range(6, -1, -1):
+        W = np.asarray(sd[f"dfnet.lin{l}.weight"], dt)
+        g = split_matmul(g, W.T, mode, block) if l < 6 else g @ W
+        if l > 0:
+            g = g * onp._dact(zs[l - 1], act, beta)
+    gf = [g[:, 6 * i:6 * i + 6].copy() for i in range(21)]
+    gn = np.zeros_like(n)
+    for i in range(20, -1, -1):
+        p = onp.PARENT[i]
+        z1, z2 = ecache[i]
+        w1 = np.asarray(sd[f"enc.net.{i}.net.0.weight"], dt)
+        w2 = np.asarray(sd[f"enc.net.{i}.net.2.weight"], dt)
+        gin = ((gf[i] * onp._dact(z2, act, beta)) @ w2 * onp._dact(z1, act, beta)) @ w1
+        gn[:, i, :] = gin[:, :4]
+        if p != -1:
+            gf[p] = gf[p] + gin[:, 4:]
+    dot = (gn * q).sum(axis=1, keepdims=True)
+    return d, gn / denom - q * dot / (denom * denom * denom)

@@ -404,6 +404,187 @@ __global__ void __launch_bounds__(256, 1) k32b(const char* stream, float* out, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+
+// ------------------------------------------------------------------ VROLE: producer / consumer wave pairs (round 3)
+// A wave pair shares 32 poses as two 16-pose operand sets, but instead of splitting the contraction (V32 / V32b: partial
+// sums and activated halves cross the pair twice per chunk) the two waves take the two PARTS of the fused layer pair:
+//   A-wave  holds the phase input of BOTH pose sets (256 registers, read-only B operands), computes the chunk rows
+//           (part A) for both: each weight pair read ONCE -> 6 MFMAs; hands the activated chunk over through LDS (4 KiB)
+//   B-wave  holds the output accumulators of BOTH pose sets (256 registers), runs part B: again 6 MFMAs per pair read
+// (lin2, lin3) has as many part-A as part-B pairs per chunk (32 + 32), so the two roles are balanced; the accumulator
+// layer of one phase is the input layer of the next, so the roles simply swap from phase to phase with no exchange.
+// Every slot carries 4 part-A pairs (tiles 0..7) and 4 part-B pairs (tiles 8..15): a wave reads 8 of the 16 tiles and
+// issues 24 MFMAs per slot, as in V16.  ORDER: 0 = set-major (hh0 hl0 lh0 hh1 hl1 lh1: chains of three, Wh kept for
+// two), 1 = term-major (hh0 hh1 hl0 hl1 lh0 lh1: Wh kept for four, two alternating accumulators).
+// hl term with the lo operand held in an AccVGPR: hipcc never feeds an MFMA's A / B operand from the AGPR file by itself
+// (it copies the 4 registers to VGPRs first: v_accvgpr_read x4 + s_nop in front of the MFMA), the ISA allows it.  The
+// chain order hh (builtin), hl (this), lh (builtin) keeps a compiler-visible MFMA last on every accumulator, so the
+// hazard recognizer still covers every later VALU read of the accumulator.
+__device__ __forceinline__ f32x4 mf16_hl_agpr(f16x8 w, f16x8 x_lo, f32x4 c) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(w), "a"(x_lo));
+    return c;
+}
+template <int TN, bool ROLE_B, int ORDER>
+__device__ __forceinline__ void vrole_group(Ring& ring, DmaSrc& src, uint32_t& dst, f16x8 (&cur)[4], const f16x8 (&oh)[2][2],
+                                            const f16x8 (&ol)[2][2], f32x4 (&acc0)[2], f32x4 (&acc1)[2]) {
+    // this wave's two pairs of the half slot: tiles TN' .. TN'+3 of its own half (ring.lane carries the half offset)
+    f16x8 nxt[4];
+    constexpr int TNEXT = (TN + 8) % SLOT_TILES;      // event bookkeeping only: the wave visits both halves' events
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SB();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        f32x4 (&a)[2] = i ? acc1 : acc0;
+        const f16x8 wh = cur[2 * i], wl = cur[2 * i + 1];
+        if constexpr (ORDER == 0) {
+            a[0] = mf16(wh, oh[i][0], a[0]);
+            SB();
+            if (i == 0) group_events<TNEXT>(ring, src, dst);
+            nxt[2 * i] = __builtin_bit_cast(f16x8, ring_tile(ring, (TNEXT / 2) + 2 * i));
+            SB();
+            a[0] = ROLE_B ? mf16(wh, ol[i][0], a[0]) : mf16_hl_agpr(wh, ol[i][0], a[0]);
+            SB();
+            nxt[2 * i + 1] = __builtin_bit_cast(f16x8, ring_tile(ring, (TNEXT / 2) + 2 * i + 1));
+            SB();
+            a[0] = mf16(wl, oh[i][0], a[0]);
+            SB();
+            if (i == 0) dma_two<TNEXT, 0>(src, dst);
+            else dma_two<TNEXT, 1>(src, dst);
+            SB();
+            a[1] = mf16(wh, oh[i][1], a[1]);
+            a[1] = ROLE_B ? mf16(wh, ol[i][1], a[1]) : mf16_hl_agpr(wh, ol[i][1], a[1]);
+            a[1] = mf16(wl, oh[i][1], a[1]);
+            SB();
+        } else {
+            a[0] = mf16(wh, oh[i][0], a[0]);
+            SB();
+            if (i == 0) group_events<TNEXT>(ring, src, dst);
+            nxt[2 * i] = __builtin_bit_cast(f16x8, ring_tile(ring, (TNEXT / 2) + 2 * i));
+            SB();
+            a[1] = mf16(wh, oh[i][1], a[1]);
+            SB();
+            nxt[2 * i + 1] = __builtin_bit_cast(f16x8, ring_tile(ring, (TNEXT / 2) + 2 * i + 1));
+            SB();
+            a[0] = mf16(wh, ol[i][0], a[0]);
+            a[1] = mf16(wh, ol[i][1], a[1]);
+            SB();
+            if (i == 0) dma_two<TNEXT, 0>(src, dst);
+            else dma_two<TNEXT, 1>(src, dst);
+            SB();
+            a[0] = mf16(wl, oh[i][0], a[0]);
+            a[1] = mf16(wl, oh[i][1], a[1]);
+            SB();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+}
+
+// A-role: 8 slots per chunk, 4 pairs per slot = k-blocks 2 SL, 2 SL + 1 x chunk tiles 0, 1
+template <int SL, int ORDER>
+__device__ __forceinline__ void vrole_a_slots(Ring& ring, DmaSrc& src, uint32_t& dst, f16x8 (&cur)[4], const f16x8 (&xh)[16][2],
+                                              const f16x8 (&xl)[16][2], f32x4 (&ch)[2][2], int& slot) {
+    if constexpr (SL < 8) {
+        // group 0: (kb = 2 SL, ci = 0), (kb = 2 SL, ci = 1); group 1: the same for kb = 2 SL + 1
+        const f16x8 oh0[2][2] = {{xh[2 * SL][0], xh[2 * SL][1]}, {xh[2 * SL][0], xh[2 * SL][1]}};
+        const f16x8 ol0[2][2] = {{xl[2 * SL][0], xl[2 * SL][1]}, {xl[2 * SL][0], xl[2 * SL][1]}};
+        vrole_group<0, false, ORDER>(ring, src, dst, cur, oh0, ol0, ch[0], ch[1]);
+        const f16x8 oh1[2][2] = {{xh[2 * SL + 1][0], xh[2 * SL + 1][1]}, {xh[2 * SL + 1][0], xh[2 * SL + 1][1]}};
+        const f16x8 ol1[2][2] = {{xl[2 * SL + 1][0], xl[2 * SL + 1][1]}, {xl[2 * SL + 1][0], xl[2 * SL + 1][1]}};
+        vrole_group<8, false, ORDER>(ring, src, dst, cur, oh1, ol1, ch[0], ch[1]);
+        if (++slot == STEP_SLOTS) { slot = 0; ring_next_step(ring); }
+        vrole_a_slots<SL + 1, ORDER>(ring, src, dst, cur, xh, xl, ch, slot);
+    }
+}
+// B-role: 4 pairs per slot = output tiles 4 SL .. 4 SL + 3, one chunk k-block
+template <int SL, int ORDER>
+__device__ __forceinline__ void vrole_b_slots(Ring& ring, DmaSrc& src, uint32_t& dst, f16x8 (&cur)[4], const f16x8 (&yh)[2],
+                                              const f16x8 (&yl)[2], f32x4 (&acc)[32][2], int& slot) {
+    if constexpr (SL < 8) {
+        const f16x8 oh[2][2] = {{yh[0], yh[1]}, {yh[0], yh[1]}};
+        const f16x8 ol[2][2] = {{yl[0], yl[1]}, {yl[0], yl[1]}};
+        vrole_group<0, true, ORDER>(ring, src, dst, cur, oh, ol, acc[4 * SL], acc[4 * SL + 1]);
+        vrole_group<8, true, ORDER>(ring, src, dst, cur, oh, ol, acc[4 * SL + 2], acc[4 * SL + 3]);
+        if (++slot == STEP_SLOTS) { slot = 0; ring_next_step(ring); }
+        vrole_b_slots<SL + 1, ORDER>(ring, src, dst, cur, yh, yl, acc, slot);
+    }
+}
+
+template <int ORDER>
+__global__ void __launch_bounds__(256, 1) krole(const char* stream, float* out, int nchunks, unsigned long long* cyc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role_b = wave & 1;
+    unsigned s = threadIdx.x * 2654435761u + blockIdx.x * 97u + 1u;
+    Ring ring; ring.gstream = stream; ring.smem = smem; ring.lane = lane;
+    ring_start(ring, wave);
+    ring_wait_dma();
+    __syncthreads();
+    ring.lane = lane + 512 * role_b;     // tile reads: A-waves read tiles 0..7 of a slot, B-waves tiles 8..15 (8 KiB = 512 x 16 B)
+    char* xch = smem + LDS_F;            // hand-over window per pair: [buffer][pose set][hi | lo][lane] x 16 B = 8 KiB
+    char* win = xch + (wave >> 1) * 8192;
+    DmaSrc src{nullptr, 0u};
+    uint32_t dst = 0;
+    int slot = 0;
+    f16x8 cur[4];
+    ring_boundary(ring);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur[i] = __builtin_bit_cast(f16x8, ring_tile(ring, i));
+    float r = 0;
+    unsigned long long t0;
+    if (!role_b) {
+        f16x8 xh[16][2], xl[16][2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) { xh[i][p] = rand_operand(s, 1.0f); xl[i][p] = rand_operand(s, 4e-4f); }
+        f32x4 ch[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) for (int p = 0; p < 2; ++p) ch[i][p] = f32x4{0, 0, 0, 0};
+        t0 = __builtin_amdgcn_s_memtime();
+        for (int c = 0; c < nchunks; ++c) {
+            vrole_a_slots<0, ORDER>(ring, src, dst, cur, xh, xl, ch, slot);
+            // epilogue stand-in + hand-over of the activated chunk (both pose sets, hi and lo): 4 x 16 B per lane
+            char* w = win + (c & 1) * 4096 + lane * 16;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                f16x8 h;
+                for (int j = 0; j < 4; ++j) { h[j] = (_Float16)(ch[0][p][j] * 1e-3f); h[4 + j] = (_Float16)(ch[1][p][j] * 1e-3f); }
+                *(f16x8*)(w + p * 2048) = h;
+                *(f16x8*)(w + p * 2048 + 1024) = h;
+                ch[0][p] = f32x4{0, 0, 0, 0};
+                ch[1][p] = f32x4{0, 0, 0, 0};
+            }
+        }
+        r = ch[0][0][0];
+    } else {
+        f32x4 acc[32][2];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) for (int p = 0; p < 2; ++p) acc[i][p] = f32x4{0, 0, 0, 0};
+        f16x8 yh[2] = {rand_operand(s, 1.0f), rand_operand(s, 1.0f)}, yl[2] = {rand_operand(s, 4e-4f), rand_operand(s, 4e-4f)};
+        t0 = __builtin_amdgcn_s_memtime();
+        for (int c = 0; c < nchunks; ++c) {
+            vrole_b_slots<0, ORDER>(ring, src, dst, cur, yh, yl, acc, slot);
+            // the chunk the A-wave handed over one period ago (the slot barriers in between order the window)
+            const char* w = win + ((c + 1) & 1) * 4096 + lane * 16;
+            if (c > 0) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const f16x8 h = *(const f16x8*)(w + p * 2048);
+                    const f16x8 l = *(const f16x8*)(w + p * 2048 + 1024);
+                    yh[p] = h;
+                    for (int j = 0; j < 8; ++j) yl[p][j] = l[j] * (_Float16)4e-4f;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) r += acc[i][0][0] + acc[i][1][3];
+    }
+    if (threadIdx.x == 0) cyc[blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <class K>
 static float run(K kern, const char* name, const char* stream, float* out, int nchunks) {
     static unsigned long long* cyc = nullptr;
@@ -449,6 +630,9 @@ int main() {
         const float e = run(k32b<true>, "V32b 16x16x32, chains of three", stream, out, nchunks);
         run(k32b<true, 1>, "  diag: same B for both halves", stream, out, nchunks);
         run(k32b<true, 2>, "  diag: one accumulator per pair", stream, out, nchunks);
+        const float f = run(krole<0>, "VROLE A-wave / B-wave, set-major", stream, out, nchunks);
+        const float g = run(krole<1>, "VROLE A-wave / B-wave, term-major", stream, out, nchunks);
+        printf("   time vs V16: VROLE set-major %.3f  term-major %.3f\n", f / a, g / a);
         printf("   time vs V16: V32 chains %.3f  V32 interleaved %.3f  V32b %.3f  V32b chains %.3f\n", b / a, c / a, d / a, e / a);
     }
     return 0;
