@@ -221,26 +221,25 @@ __device__ __forceinline__ void lbs_vertex_body(const PndfLbsArgs& a) {
         const float* Bf = smem + buf * BLOB;
 
         // ---- pose blend shapes: off[comp] rows = vertices 4 g + r, columns = frames
+        // (every contraction below walks its independent accumulator chains round-robin: a 16x16x4 fp32 MFMA that
+        // accumulates onto the result of the one issued just before it waits ~8 cycles beyond its 32 of issue)
         f32x4 off[3];
 #pragma unroll
-        for (int c3 = 0; c3 < 3; ++c3) {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c3 = 0; c3 < 3; ++c3) off[c3] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acc = mfma4(Bf[c3 * C_STRIDE + ks * 64 + lane], pfB[ks], acc);
-            off[c3] = acc;
-        }
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) off[c3] = mfma4(Bf[c3 * C_STRIDE + ks * 64 + lane], pfB[ks], off[c3]);
         // ---- skinning transforms T = sum_j W[v, j] A_j: 12 entries
         f32x4 Tm[12];
         {
-            float wv[6];
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) wv[ks] = Bf[PNDF_LBS_BLOB_W + ks * 64 + lane];
+            for (int e = 0; e < 12; ++e) Tm[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 12; ++e) {
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < 6; ++ks) {
+                const float wv = Bf[PNDF_LBS_BLOB_W + ks * 64 + lane];
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks) acc = mfma4(wv[ks], AB[e * 6 + ks], acc);
-                Tm[e] = acc;
+                for (int e = 0; e < 12; ++e) Tm[e] = mfma4(wv, AB[e * 6 + ks], Tm[e]);
             }
         }
         const i32x4 fl = *(const i32x4*)(Bf + PNDF_LBS_BLOB_FL + 4 * g);
@@ -329,30 +328,30 @@ __device__ __forceinline__ void lbs_vertex_body(const PndfLbsArgs& a) {
         {
             const float* Pt = Bf + p * GV + 4 * g;
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                f32x4 acc = gpf[kt];
+            for (int c3 = 0; c3 < 3; ++c3) {
+                f32x4 w[KT];
 #pragma unroll
-                for (int c3 = 0; c3 < 3; ++c3) {
-                    const f32x4 w = *(const f32x4*)(Pt + c3 * C_STRIDE + kt * 256);
+                for (int kt = 0; kt < KT; ++kt) w[kt] = *(const f32x4*)(Pt + c3 * C_STRIDE + kt * 256);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = mfma4(w[r], gvp[c3][r], acc);
-                }
-                gpf[kt] = acc;
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) gpf[kt] = mfma4(w[kt][r], gvp[c3][r], gpf[kt]);
             }
         }
         // ---- d L / d A[j][entry] += sum_v W[v, j] gV (x) [v_posed, 1]: rows = joints
         {
             const float* Wt = Bf + PNDF_LBS_BLOB_W + p * GV + 4 * g;
             const f32x4 w0 = *(const f32x4*)Wt, w1 = *(const f32x4*)(Wt + 256);
+            f32x4 X[12];
 #pragma unroll
-            for (int e = 0; e < 12; ++e) {
-                const f32x4 X = (e < 9) ? gV[e / 3] * vp[e % 3] : gV[e - 9];
+            for (int e = 0; e < 12; ++e) X[e] = (e < 9) ? gV[e / 3] * vp[e % 3] : gV[e - 9];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    gA[e][0] = mfma4(w0[r], X[r], gA[e][0]);
-                    gA[e][1] = mfma4(w1[r], X[r], gA[e][1]);
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int e = 0; e < 12; ++e) {
+                    gA[e][0] = mfma4(w0[r], X[e][r], gA[e][0]);
+                    gA[e][1] = mfma4(w1[r], X[e][r], gA[e][1]);
                 }
-            }
         }
     }
     if constexpr (MODE != 0) {
