@@ -275,10 +275,8 @@ __device__ __forceinline__ void stage_derivative_tile(const SpRef& sp, int slot,
 }
 template <int YOUNGER>
 __device__ __forceinline__ void wait_staged_derivatives() {
-    if constexpr (YOUNGER >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (YOUNGER >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (YOUNGER >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_assert(YOUNGER >= 0 && YOUNGER < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(YOUNGER) : "memory");
 }
 constexpr int SP_SLOT_CHUNK[3] = {0, 16, 80};      // chunk layers x1 (8x2), x3 (32x2), x5 (4x4)
 constexpr int SP_SLOT_X2 = 96, SP_SLOT_X4 = 128, SP_SLOT_X6 = 160, SP_SLOT_ENC = 164;   // encoder: 2 tiles per joint

@@ -55,6 +55,16 @@ constexpr int A_FLOATS = 12 * 32;          // d L / d A per frame: [12 entries][
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// Neighbouring FRAMES are neighbouring lanes of a 16-lane row (lane = 16 g + p, p = frame of the chunk): one DPP move each,
+// no LDS round trip.  row_shl:1 -- lane p reads lane p + 1 (frame t + 1), row_shr:1 -- lane p reads lane p - 1; lanes that
+// would read across the row's edge get 0 (bound_ctrl).
+__device__ __forceinline__ float next_frame(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x101, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float prev_frame(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true));
+}
+
 // smplx batch_rodrigues: angle = |r + 1e-8|, axis = r / angle, R = I + sin K + (1 - cos) K K   (row-major 3x3)
 __device__ __forceinline__ void rodrigues(float rx, float ry, float rz, float* R) {
     const float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
@@ -278,11 +288,11 @@ __device__ __forceinline__ void lbs_vertex_body(const PndfLbsArgs& a) {
 #pragma unroll
             for (int a3 = 0; a3 < 3; ++a3)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) d[a3][r] = V[a3][r] - __shfl_down(V[a3][r], 1, 16);
+                for (int r = 0; r < 4; ++r) d[a3][r] = V[a3][r] - next_frame(V[a3][r]);
             const f32x4 n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float inv = a.w_temp / sqrtf(n2[r]);
+                const float inv = a.w_temp * __builtin_amdgcn_rsqf(n2[r]);      // 0 -> inf -> 0 * inf = NaN, as d / sqrt(0)
                 const bool ok = pair_ok && fl[r] != -2;
 #pragma unroll
                 for (int a3 = 0; a3 < 3; ++a3) u[a3][r] = ok ? d[a3][r] * inv : 0.f;
@@ -290,10 +300,7 @@ __device__ __forceinline__ void lbs_vertex_body(const PndfLbsArgs& a) {
 #pragma unroll
             for (int a3 = 0; a3 < 3; ++a3)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float up = __shfl_up(u[a3][r], 1, 16);
-                    gV[a3][r] = u[a3][r] - (p > 0 ? up : 0.f);
-                }
+                for (int r = 0; r < 4; ++r) gV[a3][r] = u[a3][r] - prev_frame(u[a3][r]);      // lane 0: no pair inside this chunk
             // data term on the joints that are picked from vertices (the 24 chain joints: pndf_lbs_pose_backward_kernel)
             if (a.it_gt0 && owned) {
 #pragma unroll
