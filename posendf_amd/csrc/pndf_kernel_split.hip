@@ -398,7 +398,7 @@ struct SplitPhase {
                         if constexpr (r == 3) *act.sp.slot(act.spslot + c * CT + ci) = bt[ci];
                     }
                 } else if constexpr (SP && BWD) {
-                    if constexpr (r == 0) bt[ci] = *(const f32x4*)(act.stage + (stage_window(c) + ci) * 1024 + act.lane * 16);
+                    if constexpr (r == 0) bt[ci] = *(const f32x4*)(act.stage + ci * 1024 + act.lane * 16);
                     y[ci][r] = (a * cf) * bt[ci][r];
                 } else if constexpr (!BWD) {
                     y[ci][r] = lrelu_bit(fmaf(a, cf, bt[ci][r]), act.slope, bits);
@@ -449,34 +449,14 @@ struct SplitPhase {
     // epilogue multiplies by them, by DMA into the wave's staging window (single-buffered: the epilogue that reads it
     // runs before the next init_chunk).  At least STAGE_YOUNGER ring pieces are issued between the fetch and its use,
     // so `vmcnt(STAGE_YOUNGER)` there proves the tiles have landed without draining the ring.
-    // Round 3: the fetch runs TWO chunks ahead into a double-buffered window (chunk c -> window c & 1; 2 CT <= 8 tiles of
-    // the wave's 8.25 KiB).  One part A ahead was enough in the two big phases (~2,000 cycles) but not in (lin5^T, lin4^T),
-    // whose part A is 24 MFMAs = 400 cycles -- less than the latency of a scratch line that left the L2 -- so every chunk of
-    // that phase stalled on its derivatives.  Younger VM operations at the point of use, at least: the CT fetches of the
-    // next chunk + the 2 AG ring pieces of one part A (prologue case; in steady state a whole chunk period more).
-#ifndef PNDF_SP_STAGE_AHEAD
-#define PNDF_SP_STAGE_AHEAD 2
-#endif
-    static constexpr int STAGE_YOUNGER = (PNDF_SP_STAGE_AHEAD == 2) ? CT + 2 * AG : ((2 * AG < 12) ? 2 * AG : 12);
-    static_assert(PNDF_SP_STAGE_AHEAD == 1 || 2 * CT <= 8, "two staging windows fit the wave's feature rows");
-    static __device__ __forceinline__ int stage_window(int c) { return (PNDF_SP_STAGE_AHEAD == 2) ? (c & 1) * CT : 0; }
-    static __device__ __forceinline__ void stage_chunk(const SAct& act, int c) {
-        if constexpr (SP && BWD) {
-#pragma unroll
-            for (int ci = 0; ci < CT; ++ci)
-                stage_derivative_tile(act.sp, act.spslot + c * CT + ci, act.stage + (stage_window(c) + ci) * 1024);
-        }
-    }
-    // `c` = the chunk whose part A follows.  Its derivative tiles were staged one call earlier (two-ahead mode: this call
-    // stages chunk c + 1, if there is one; the phase's first call stages both chunk 0 and chunk 1).
+    // (Round 3 measured a fetch TWO chunks ahead into a double-buffered window -- the part A of (lin5^T, lin4^T) is only
+    // 24 MFMAs long -- and found no gain: 105.5 ms one ahead, 104.9 .. 113 ms two ahead, same bits; profiles/r03/ab_sp_stage.txt.
+    // The phase's overhead is issue-bound VALU work, not the latency of these tiles.)
+    static constexpr int STAGE_YOUNGER = (2 * AG < 12) ? 2 * AG : 12;
     static __device__ __forceinline__ void init_chunk(f32x4 (&ch)[3][CT], const float* biasA, int c, int g, const SAct& act) {
         if constexpr (SP && BWD) {
-            if constexpr (PNDF_SP_STAGE_AHEAD == 2) {
-                if (c == 0) stage_chunk(act, 0);
-                if (c + 1 < NC) stage_chunk(act, c + 1);
-            } else {
-                stage_chunk(act, c);
-            }
+#pragma unroll
+            for (int ci = 0; ci < CT; ++ci) stage_derivative_tile(act.sp, act.spslot + c * CT + ci, act.stage + ci * 1024);
         }
 #pragma unroll
         for (int ci = 0; ci < CT; ++ci) {
