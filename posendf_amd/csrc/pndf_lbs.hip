@@ -20,8 +20,8 @@
 // Three kernels:
 //   pndf_lbs_pose_kernel            one thread per frame: Rodrigues, transform chain -> pose feature, A, posed joints
 //   pndf_lbs_vertex_kernel<MODE>    one wave per chunk of 16 frames, four chunks per workgroup sharing the model stream:
-//       the packed model ("blob": 42 KiB per 16 vertices, lane-linear MFMA tiles) is streamed global -> LDS by DMA,
-//       double buffered, and read TWICE from LDS: as A operand of the forward pose-blend contraction (rows = vertices) and,
+//       the packed model ("blob": 42 KiB per 16 vertices, lane-linear MFMA tiles) is streamed global -> LDS by DMA into
+//       three buffers (the loop is software-pipelined one group deep), and read TWICE from LDS: as A operand of the forward pose-blend contraction (rows = vertices) and,
 //       with a transposed conflict-free ds_read_b128, as A operand of the reverse contraction (rows = pose-feature entries).
 //       MODE 0: vertices / vertex-picked joints out.  MODE 1: the two weighted terms of motion_denoise.py:86-94 formed in
 //       registers (neighbouring frames are neighbouring lanes) and pushed straight back: d L / d pose_feature and
@@ -166,10 +166,17 @@ extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_kernel(PndfLbsArg
         }
 }
 
+__device__ __forceinline__ void lbs_rotate(f32x4 (&off)[3], f32x4 (&Tm)[12], const f32x4 (&off_n)[3], const f32x4 (&Tm_n)[12]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) off[i] = off_n[i];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Tm[i] = Tm_n[i];
+}
+
 // ------------------------------------------------------------------ per (16 vertices x 16 frames) tile
 template <int MODE>
 __device__ __forceinline__ void lbs_vertex_body(const PndfLbsArgs& a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // 2 x BLOB
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // 3 x BLOB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, p = lane & 15;
@@ -222,35 +229,46 @@ __device__ __forceinline__ void lbs_vertex_body(const PndfLbsArgs& a) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256),
                                              (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
     };
-    if (grp0 < grp1) dma(grp0, 0);
-    for (int grp = grp0; grp < grp1; ++grp) {
-        const int buf = (grp - grp0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of blob `grp` have landed ...
-        __syncthreads();                                      // ... everyone's have, and everyone has left the other buffer
-        if (grp + 1 < grp1) dma(grp + 1, buf ^ 1);
-        const float* Bf = smem + buf * BLOB;
-
-        // ---- pose blend shapes: off[comp] rows = vertices 4 g + r, columns = frames
-        // (every contraction below walks its independent accumulator chains round-robin: a 16x16x4 fp32 MFMA that
-        // accumulates onto the result of the one issued just before it waits ~8 cycles beyond its 32 of issue)
-        f32x4 off[3];
+    // The forward contractions of a group (pose blend shapes, skinning transforms: MFMA only) and the VALU section that
+    // turns them into vertices and vertex gradients are independent ACROSS groups, so the loop is software-pipelined:
+    // iteration `grp` issues the forward MFMAs of group grp + 1 next to the VALU section of group grp, then the reverse
+    // MFMAs of group grp -- the matrix pipe no longer idles through ~300 VALU instructions per group.  Three blob buffers:
+    // `grp` (reverse operands), `grp + 1` (forward operands), `grp + 2` in flight.
+    auto forward_mfma = [&](const float* Bf, f32x4 (&off)[3], f32x4 (&Tm)[12]) {
+        // (every contraction walks its independent accumulator chains round-robin: a 16x16x4 fp32 MFMA that accumulates
+        // onto the result of the one issued just before it waits ~8 cycles beyond its 32 of issue)
 #pragma unroll
         for (int c3 = 0; c3 < 3; ++c3) off[c3] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int c3 = 0; c3 < 3; ++c3) off[c3] = mfma4(Bf[c3 * C_STRIDE + ks * 64 + lane], pfB[ks], off[c3]);
-        // ---- skinning transforms T = sum_j W[v, j] A_j: 12 entries
-        f32x4 Tm[12];
-        {
 #pragma unroll
-            for (int e = 0; e < 12; ++e) Tm[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 12; ++e) Tm[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) {
-                const float wv = Bf[PNDF_LBS_BLOB_W + ks * 64 + lane];
+        for (int ks = 0; ks < 6; ++ks) {
+            const float wv = Bf[PNDF_LBS_BLOB_W + ks * 64 + lane];
 #pragma unroll
-                for (int e = 0; e < 12; ++e) Tm[e] = mfma4(wv, AB[e * 6 + ks], Tm[e]);
-            }
+            for (int e = 0; e < 12; ++e) Tm[e] = mfma4(wv, AB[e * 6 + ks], Tm[e]);
+        }
+    };
+    f32x4 off[3], Tm[12];          // pose-blend offsets (rows = vertices 4 g + r, columns = frames) and T = sum_j W[v, j] A_j
+    if (grp0 < grp1) {
+        dma(grp0, 0);
+        if (grp0 + 1 < grp1) dma(grp0 + 1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        forward_mfma(smem, off, Tm);
+    }
+    for (int grp = grp0; grp < grp1; ++grp) {
+        const int k = grp - grp0;
+        const float* Bf = smem + (k % 3) * BLOB;
+        f32x4 off_n[3], Tm_n[12];
+        if (grp + 1 < grp1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of blob grp + 1 have landed ...
+            __syncthreads();                                      // ... everyone's have, and everyone has left buffer (k + 2) % 3
+            if (grp + 2 < grp1) dma(grp + 2, (k + 2) % 3);
+            forward_mfma(smem + ((k + 1) % 3) * BLOB, off_n, Tm_n);
         }
         const i32x4 fl = *(const i32x4*)(Bf + PNDF_LBS_BLOB_FL + 4 * g);
         f32x4 vp[3], V[3];
@@ -276,6 +294,7 @@ __device__ __forceinline__ void lbs_vertex_body(const PndfLbsArgs& a) {
                     }
                 }
             }
+            lbs_rotate(off, Tm, off_n, Tm_n);
             continue;
         }
 
@@ -360,6 +379,7 @@ __device__ __forceinline__ void lbs_vertex_body(const PndfLbsArgs& a) {
                     gA[e][1] = mfma4(w1[r], X[e][r], gA[e][1]);
                 }
         }
+        lbs_rotate(off, Tm, off_n, Tm_n);
     }
     if constexpr (MODE != 0) {
         if (t_ok) {
@@ -562,7 +582,7 @@ extern "C" int pndf_lbs_create(pndf_lbs_handle* out, int32_t V, int32_t NB, cons
     for (int j = 0; j < NJ; ++j) h->consts.parent[j] = parents[j];
     hipError_t e = hipMalloc((void**)&h->d_blob, blob.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
-    const int lds = 2 * BLOB * (int)sizeof(float);
+    const int lds = 3 * BLOB * (int)sizeof(float);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pndf_lbs_vertex_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pndf_lbs_vertex_terms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pndf_lbs_vertex_reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -634,7 +654,7 @@ static int lbs_launch(pndf_lbs_model* h, int mode, PndfLbsArgs& a, void* workspa
     const long long N = (long long)a.S * a.T;
     const dim3 fgrid((unsigned)((N + 63) / 64)), fblock(64);
     const dim3 vgrid((unsigned)(((long long)a.S * a.cps + 3) / 4), (unsigned)(mode == 0 ? 1 : a.vsplit)), vblock(256);
-    const int lds = 2 * BLOB * (int)sizeof(float);
+    const int lds = 3 * BLOB * (int)sizeof(float);
     if (mode == 0) a.vsplit = 1;
     hipLaunchKernelGGL(pndf_lbs_pose_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
     if (mode == 0) {
