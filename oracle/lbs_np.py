@@ -21,37 +21,12 @@ from __future__ import annotations
 
 import numpy as np
 
-# SMPL kinematic tree (smplx: model.parents = kintree_table[0], root = -1) -- data of the model file, reproduced here
-# only as the default of the synthetic model generator
-SMPL_PARENTS = (-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21)
-SMPL_V = 6890
-# smplx VertexJointSelector for SMPL (vertex_ids['smplh']): nose, eyes, ears, feet (big toe, small toe, heel; L then R),
-# finger tips (thumb .. pinky; L then R) -- 21 extra joints, 45 in all.  Restated from memory of the published table:
-# part of what "parity unpinned" covers; the product takes the list as a parameter.
-SMPL_EXTRA_JOINT_VERTICES = (332, 6260, 2800, 4071, 583, 3216, 3226, 3387, 6617, 6624, 6787,
-                             2746, 2319, 2445, 2556, 2673, 6191, 5782, 5905, 6016, 6133)
+from posendf_amd.synth import SMPL_EXTRA_JOINT_VERTICES, SMPL_PARENTS, SMPL_V, make_body_model  # noqa: E402,F401
 
 
-def synthetic_model(V=SMPL_V, n_betas=10, seed=0, parents=SMPL_PARENTS, extra=SMPL_EXTRA_JOINT_VERTICES, max_influences=4):
-    """A random body model with SMPL's shapes and structure: a template cloud of ~1.7 m, a joint regressor with convex
-    rows, skinning weights with <= 4 non-zeros per vertex that sum to one, shape dirs of ~1 cm and pose dirs of ~1 mm per
-    unit of the pose feature (SMPL's pose-corrective magnitudes)."""
-    rng = np.random.default_rng(seed)
-    J = len(parents)
-    v_template = (rng.normal(size=(V, 3)) * np.array([0.25, 0.55, 0.12])).astype(np.float32)
-    shapedirs = (rng.normal(size=(V, 3, n_betas)) * 0.01).astype(np.float32)
-    posedirs = (rng.normal(size=((J - 1) * 9, V * 3)) * 0.002).astype(np.float32)
-    jr = rng.random((J, V)) ** 8
-    J_regressor = (jr / jr.sum(1, keepdims=True)).astype(np.float32)
-    w = np.zeros((V, J), np.float64)
-    for v in range(V):
-        idx = rng.choice(J, max_influences, replace=False)
-        w[v, idx] = rng.random(max_influences) + 0.05
-    lbs_weights = (w / w.sum(1, keepdims=True)).astype(np.float32)
-    extra = tuple(int(e) % V for e in extra)
-    return dict(v_template=v_template, shapedirs=shapedirs, posedirs=posedirs, J_regressor=J_regressor,
-                parents=np.asarray(parents, np.int32), lbs_weights=lbs_weights,
-                extra_joint_vertex=np.asarray(extra, np.int32), betas=np.zeros(n_betas, np.float32))
+def synthetic_model(*args, **kwargs):
+    """random SMPL-shaped model parameters (posendf_amd.synth.make_body_model: shared with the benchmarks, like make_weights)"""
+    return make_body_model(*args, **kwargs)
 
 
 # ---------------------------------------------------------------- smplx/lbs.py, restated

@@ -85,8 +85,9 @@ class BodyModel(torch.nn.Module):
         jr, w = _f32(params["J_regressor"]), _f32(params["lbs_weights"])
         par = np.ascontiguousarray(np.asarray(params["parents"], dtype=np.int32))
         par[0] = -1
-        if extra_joint_vertex is None:
-            extra_joint_vertex = params.get("extra_joint_vertex", ())
+        if extra_joint_vertex is None:      # smplx's SMPL always appends its 21 vertex-picked joints (45 in all)
+            from .synth import SMPL_EXTRA_JOINT_VERTICES, SMPL_V
+            extra_joint_vertex = params.get("extra_joint_vertex", SMPL_EXTRA_JOINT_VERTICES if V == SMPL_V else ())
         ex = np.ascontiguousarray(np.asarray(extra_joint_vertex, dtype=np.int32))
         if jr.shape != (24, V) or w.shape != (V, 24) or par.shape != (24,):
             raise PndfError("J_regressor [24,V], lbs_weights [V,24], parents [24] expected")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[4] with the REFERENCE's objective (pose prior + SMPL vertex temporal term + joint data term,
 experiments/motion_denoise.py:74-99) on one GPU: S sequences x T frames of a synthetic SMPL-shaped body model (6,890
-vertices, 24 joints, 21 vertex-picked joints; oracle/lbs_np.synthetic_model, this script is measurement infrastructure).
+vertices, 24 joints, 21 vertex-picked joints; posendf_amd.synth.make_body_model).
 Times the fused body-model pass (pndf_lbs_terms_grad: three kernels), the forward, and the whole fused Adam step.
 Algorithmic work per frame of the fused pass (real dimensions, forward + reverse):
   pose blend shapes 2 x 207 x 20,670 MACs + skinning transforms 2 x 6,890 x 24 x 12 MACs = 12.53 M MACs = 25.06 MFLOP
@@ -16,7 +16,6 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-from oracle import lbs_np  # noqa: E402  (synthetic model parameters only)
 from posendf_amd import BodyModel, PoseNDF, amass_config, synth  # noqa: E402
 from posendf_amd.motion_denoise import MotionDenoise  # noqa: E402
 
@@ -44,7 +43,7 @@ def main():
     ap.add_argument("--precision", default="f16x3")
     args = ap.parse_args()
     S, T = args.seqs, args.frames
-    m = lbs_np.synthetic_model(seed=11)
+    m = synth.make_body_model(seed=11)
     bm = BodyModel(m, device="cuda:0", extra_joint_vertex=m["extra_joint_vertex"])
     g = torch.Generator().manual_seed(0)
     theta = (torch.cumsum(0.02 * torch.randn(S, T, 69, generator=g), dim=1) + 0.3 * torch.randn(S, 1, 69, generator=g)
