@@ -135,3 +135,30 @@ def test_fused_denoise_with_body_model_matches_oracle_loop(smpl_like, precision)
     d2 = (auto - got).abs().flatten()
     assert d2.median().item() < 1e-5 and (d2 > 1e-3).float().mean().item() < 0.01
     assert {"pose_pr", "temp"} <= set(hist[0]) and "data" in hist[-1]
+
+
+def test_small_model_short_sequences_and_reference_nan_semantics():
+    """A 41-vertex model (three vertex groups, the last one padded), sequences of 2, 15, 16 and 17 frames (one pair; one
+    chunk exactly; a chunk boundary with and without a shared frame), and the reference's behaviour for two IDENTICAL
+    consecutive frames: no epsilon under the root (motion_denoise.py:89), so the temporal gradient of those frames is NaN."""
+    from posendf_amd import BodyModel
+    m = lbs_np.synthetic_model(V=41, seed=5, extra=(3, 17, 40))
+    bm = BodyModel(m, device="cuda:0")
+    assert bm.num_joints == 27 and bm.num_vertices == 41
+    for T in (2, 15, 16, 17):
+        th = _theta(2, T, seed=T)
+        th0 = th + 0.04
+        j0 = bm.joints_of(torch.from_numpy(th0))
+        g = bm.terms_grad(torch.from_numpy(th).cuda(), j0, 1).cpu().numpy()
+        for s in range(2):
+            _, J0 = lbs_np.lbs(th0[s], m)
+            g64, _ = lbs_np.body_terms(th[s], J0, m, 1)
+            assert np.abs(g[s] - g64).max() < TOL * np.abs(g64).max(), (T, s)
+    th = _theta(1, 6, seed=1)
+    th[0, 3] = th[0, 2]                                      # frames 2 and 3 identical: |V2 - V3| = 0
+    g = bm.terms_grad(torch.from_numpy(th).cuda(), None, 0).cpu().numpy()[0]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        g64, _ = lbs_np.body_terms(th[0], None, m, 0)
+    assert np.isnan(g64[2]).all() and np.isnan(g64[3]).all() and np.isfinite(g64[[0, 1, 4, 5]]).all()      # the reference's NaN
+    assert np.isnan(g[2]).all() and np.isnan(g[3]).all() and np.isfinite(g[[0, 1, 4, 5]]).all()
+    assert np.abs(g[[0, 1, 4, 5]] - g64[[0, 1, 4, 5]]).max() < TOL * np.abs(g64[[0, 1, 4, 5]]).max()
