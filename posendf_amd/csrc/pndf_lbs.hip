@@ -264,14 +264,12 @@ __device__ __forceinline__ void lbs_vertex_body(const PndfLbsArgs& a) {
         const int k = grp - grp0;
         const float* Bf = smem + (k % 3) * BLOB;
         f32x4 off_n[3], Tm_n[12];
-        const bool more = grp + 1 < grp1;
-        if (more) {
+        if (grp + 1 < grp1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of blob grp + 1 have landed ...
             __syncthreads();                                      // ... everyone's have, and everyone has left buffer (k + 2) % 3
             if (grp + 2 < grp1) dma(grp + 2, (k + 2) % 3);
+            forward_mfma(smem + ((k + 1) % 3) * BLOB, off_n, Tm_n);
         }
-        // (the last iteration repeats its own group: no branch between these MFMAs and the VALU section they overlap with)
-        forward_mfma(smem + ((more ? k + 1 : k) % 3) * BLOB, off_n, Tm_n);
         const i32x4 fl = *(const i32x4*)(Bf + PNDF_LBS_BLOB_FL + 4 * g);
         f32x4 vp[3], V[3];
 #pragma unroll
@@ -322,14 +320,6 @@ __device__ __forceinline__ void lbs_vertex_body(const PndfLbsArgs& a) {
             for (int a3 = 0; a3 < 3; ++a3)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gV[a3][r] = u[a3][r] - prev_frame(u[a3][r]);      // lane 0: no pair inside this chunk
-            // One wave per SIMD overlaps its own VALU work with its own MFMAs only if they alternate in program order: deal
-            // the VALU section of this group (vertices, differences, norms: ~300 instructions) out behind the 228 forward
-            // MFMAs of the next group, two per MFMA (a 16x16x4 fp32 MFMA leaves 28 of its 32 cycles to other issue).
-#pragma unroll
-            for (int i = 0; i < 3 * KS + 72; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two VALU
-            }
             // data term on the joints that are picked from vertices (the 24 chain joints: pndf_lbs_pose_backward_kernel)
             if (a.it_gt0 && owned) {
 #pragma unroll
