@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpu-torch-baseline", action="store_true")
+    ap.add_argument("--no-motion-denoise", action="store_true", help="skip the configs[4] side block")
     ap.add_argument("--no-parity-sample", action="store_true", help="skip the oracle check of a sample of the timed result")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -328,6 +329,46 @@ def main():
                     "ms": ms1, "pose_steps_per_s": B / (ms1 * 1e-3),
                     "achieved_tflops": B * FLOP_PER_POSE_STEP / (ms1 * 1e-3) / 1e12}
 
+    # BASELINE.json configs[4] on one GPU's share (64 of 512 sequences x 300 frames) with the REFERENCE's objective: pose prior
+    # on the engine + SMPL-shaped body model (synthetic parameters, 6,890 vertices) with the vertex temporal and joint data
+    # terms fused (csrc/pndf_lbs.hip).  A side block, outside the timed region; never `value`.
+    def motion_denoise_block(S=64, T=300):
+        from posendf_amd import BodyModel
+        from posendf_amd.motion_denoise import MotionDenoise
+        bm = BodyModel(synth.make_body_model(seed=11), device=f"cuda:{local}")
+        g = torch.Generator().manual_seed(0)
+        theta = (torch.cumsum(0.02 * torch.randn(S, T, 69, generator=g), dim=1) + 0.3 * torch.randn(S, 1, 69, generator=g)
+                 + 0.1 * torch.randn(S, T, 69, generator=g)).to(dev)
+        j0 = bm.joints_of(theta + 0.02)
+        out = torch.empty_like(theta)
+        bm.terms_grad(theta, j0, 2, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            bm.terms_grad(theta, j0, 2, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms_lbs = e0.elapsed_time(e1) / 5
+        md = MotionDenoise(net, body_model=bm, device=f"cuda:{local}")
+        md.optimize(theta, iterations=1, steps_per_iter=2, fused=True)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        res, _ = md.optimize(theta, iterations=2, steps_per_iter=5, fused=True)
+        torch.cuda.synchronize()
+        ms_step = (time.perf_counter() - t) / 10 * 1e3
+        flop = 2 * (2 * 207 * 20670 + 2 * 6890 * 24 * 12)                 # per frame, forward + reverse
+        tf = S * T * flop / (ms_lbs * 1e-3) / 1e12
+        return {"workload": f"BASELINE.json configs[4], one GPU's share: {S} sequences x {T} frames, reference objective (pose prior + "
+                            "SMPL vertex temporal term + joint data term), synthetic SMPL-shaped body model, fused Adam steps",
+                "fused_adam_step_ms": ms_step, "frames_per_s": S * T / (ms_step * 1e-3),
+                "body_model_pass": {"kernel": "pndf_lbs_vertex_terms_kernel (+ pose kernels)", "ms": ms_lbs, "bound": "mfma",
+                                    "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
+                                    "algorithmic_flop_per_frame": flop},
+                "finite": bool(torch.isfinite(res).all()), "parity": "unpinned (smplx is third-party and absent; oracle/lbs_np.py)"}
+
+    denoise = motion_denoise_block() if (side and not args.no_motion_denoise and args.act != "softplus") else None
+
     fp32_ref = f16_ref = sp_ref = h16_ref = None
     if precision == "f16x3" and side and args.act != "softplus":
         # the activation of the reference's published checkpoints (sample_poses.py:115, motion_denoise.py:162-163)
@@ -417,6 +458,8 @@ def main():
             out["f16_single"] = f16_ref
         if sp_ref is not None:
             out["softplus"] = sp_ref
+        if denoise is not None:
+            out["motion_denoise_config4"] = denoise
         if h16_ref is not None:
             out["fp16_checkpoint"] = h16_ref
         if world == 1 and not args.no_gpu_torch_baseline:

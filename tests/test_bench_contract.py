@@ -43,6 +43,11 @@ def test_bench_json_line_default_precision():
     hb = d["host_boundary"]                       # PCIe-inclusive rate of a host-tensor caller: reported, never `value`
     assert hb["ms"] > d["roofline"]["kernel_ms"] and 0 < hb["poses_per_s"] < d["value"] * 1.02
     assert d["roofline"]["kernel_ms_median"] > 0
+    md = d["motion_denoise_config4"]              # configs[4] on one GPU's share with the reference's objective: a side block
+    assert md["finite"] and md["fused_adam_step_ms"] > 0 and 0 < md["body_model_pass"]["frac"] < 1
+    ps = d["parity_sample"]                       # the line checks what it timed (5 steps here)
+    assert ps["median"] < 1e-5 and ps["within_tolerance_frac"] > 0.9
+    assert d["roofline"]["traffic"] is None and d["roofline"]["traffic_stale"] is None      # only quoted for the profiled workload
     gt = d["gpu_torch_baseline"]                  # the denominator of north_star's ">= 10x", measured in the same run
     assert gt["value"] > 0 and abs(gt["speedup_of_value"] - d["value"] / gt["value"]) < 1e-9
 

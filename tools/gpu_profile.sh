@@ -10,7 +10,7 @@ ACT=${3:-lrelu}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-ref --no-gpu-torch-baseline --no-parity-sample --precision $PREC --act $ACT"
+BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32-ref --no-gpu-torch-baseline --no-parity-sample --no-motion-denoise --precision $PREC --act $ACT"
 rocprofv3 -L > "$ROOT/$OUT/counters_available.txt" 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace" -o trace -- $BENCH > "$ROOT/$OUT/trace.log" 2>&1
 echo "trace rc=$?"

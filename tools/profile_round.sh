@@ -24,7 +24,7 @@ smi() { rocm-smi --showpower --showclocks 2>/dev/null | grep -E "sclk|Package Po
     echo "== idle"; smi
     for cfg in "f16x3 lrelu" "f16x3 softplus" "fp32 lrelu"; do
         set -- $cfg
-        python bench.py --steps 150 --warmup 1 --no-cpu-baseline --no-fp32-ref --no-gpu-torch-baseline --no-parity-sample --precision $1 --act $2 > /dev/null 2>&1 &
+        python bench.py --steps 150 --warmup 1 --no-cpu-baseline --no-fp32-ref --no-gpu-torch-baseline --no-parity-sample --no-motion-denoise --precision $1 --act $2 > /dev/null 2>&1 &
         pid=$!
         sleep 14
         echo "== $1 $2 project loop running"
