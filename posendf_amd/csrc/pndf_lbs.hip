@@ -607,13 +607,22 @@ extern "C" int pndf_lbs_destroy(pndf_lbs_handle h) {
 extern "C" int32_t pndf_lbs_num_joints(pndf_lbs_handle h) { return h ? NJ + h->NE : 0; }
 extern "C" int32_t pndf_lbs_num_vertices(pndf_lbs_handle h) { return h ? h->V : 0; }
 
-// vertex ranges per chunk quad: enough workgroups to fill the chip for small problems (deterministic in S, T only)
+// Vertex ranges per chunk quad (blockIdx.y): the grid is quads x vsplit workgroups of one CU each, executed in rounds of
+// `sm_count`.  Pick the split (<= 8, <= NG) whose last round is fullest -- 64 sequences x 300 frames are 320 quads: a split
+// of 4 makes exactly 5 rounds where 1 or 2 leave the last round a quarter / half empty -- preferring, at equal fill, the
+// smaller split (fewer partial sums).  Deterministic in (S, T) only.
 static int lbs_vsplit(const pndf_lbs_model* h, int nch) {
-    const int quads = (nch + 3) / 4;
-    int vsplit = (2 * h->sm_count + quads - 1) / quads;
-    if (vsplit > 8) vsplit = 8;
-    if (vsplit > h->NG) vsplit = h->NG;
-    return vsplit < 1 ? 1 : vsplit;
+    const long long quads = (nch + 3) / 4, sm = h->sm_count;
+    const int vmax = h->NG < 8 ? h->NG : 8;
+    if (quads * vmax <= sm) return vmax;          // less than one round whatever the split: take all the parallelism there is
+    int best = 1;
+    double best_fill = 0.0;
+    for (int v = 1; v <= vmax; ++v) {
+        const long long wgs = quads * v, rounds = (wgs + sm - 1) / sm;
+        const double fill = (double)wgs / (double)(rounds * sm);
+        if (fill > best_fill + 0.02) { best_fill = fill; best = v; }
+    }
+    return best;
 }
 
 // workspace layout (floats): pfp | Ap | Gt | gpf | gA | halo_pf | halo_A   (sized for the fused-terms mode, the largest)
