@@ -124,3 +124,30 @@ def test_config4_512_sequences_as_eight_virtual_shards(rccl_single_rank, precisi
     diff = np.abs(out_sh[s].cpu().numpy() - ref)
     moved = np.abs(ref - theta[s].cpu().numpy()).max()
     assert np.median(diff) < 1e-5 and (diff > 1e-3).mean() < 0.01 and diff.max() < 0.5 * moved, (np.median(diff), diff.max(), moved)
+
+
+def _gloo_single_rank(port, outdir):
+    import sys
+    import torch.distributed as dist
+    from conftest import REPO
+    sys.path.insert(0, REPO)
+    from posendf_amd.sharding import run_virtual_shards
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    x = torch.arange(41 * 5, dtype=torch.float32).reshape(41, 5)
+    recv = torch.empty(41, 5)
+    out = run_virtual_shards(lambda blk: blk * 3, x, SHARDS, out=recv)          # every block through all_gather_into_tensor
+    ok = torch.equal(out, x * 3) and out.data_ptr() == recv.data_ptr()
+    dist.destroy_process_group()
+    np.save(os.path.join(outdir, "ok.npy"), np.array([ok]))
+
+
+def test_run_virtual_shards_through_a_process_group_cpu(tmp_path):
+    """the collective branch of run_virtual_shards (one forced rank, here gloo on CPU; the -m gpu tests use RCCL)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_gloo_single_rank, args=(30500 + os.getpid() % 2000, str(tmp_path)))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0 and bool(np.load(tmp_path / "ok.npy")[0])
