@@ -47,7 +47,10 @@ __device__ __forceinline__ void dma_two(const DmaSrc& src, uint32_t dst) {
 }  // namespace
 
 // ------------------------------------------------------------------ V16
-template <int TN, int XB, int BASE, bool PART_A, bool HALFREADS = false, bool CHAIN6 = false>
+// DUPDATA (round 3): all 8 tile reads are issued, but pairs 2, 3 of the group read the LDS addresses of pairs 0, 1 -- the
+// operand DATA of the HALFREADS arm (every second pair repeats a weight tile) at V16's read volume: separates what halving
+// the reads saves from what feeding the MFMA's A operand the same bits twice in a row saves.
+template <int TN, int XB, int BASE, bool PART_A, bool HALFREADS = false, bool CHAIN6 = false, bool DUPDATA = false>
 __device__ __forceinline__ void v16_group(Ring& ring, DmaSrc& src, uint32_t& dst, f16x8 (&cur)[8], const f16x8 (&xh)[16], const f16x8 (&xl)[16],
                                           f32x4 (&acc)[32]) {
     f16x8 nxt[8];
@@ -63,12 +66,14 @@ __device__ __forceinline__ void v16_group(Ring& ring, DmaSrc& src, uint32_t& dst
         acc[a] = mf16(wh, xh[XB + i], acc[a]);
         SB();
         if (i == 0) group_events<TNEXT>(ring, src, dst);
-        if (!HALFREADS || i < 2) nxt[2 * i] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2 * i));
+        if (DUPDATA) nxt[2 * i] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2 * (i & 1)));
+        else if (!HALFREADS || i < 2) nxt[2 * i] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2 * i));
         else nxt[2 * i] = nxt[2 * i - 4];                 // (diagnostic arm: V16's MFMA structure with pair-32's read volume)
         SB();
         acc[a] = mf16(wh, xl[XB + i], acc[a]);
         SB();
-        if (!HALFREADS || i < 2) nxt[2 * i + 1] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2 * i + 1));
+        if (DUPDATA) nxt[2 * i + 1] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2 * (i & 1) + 1));
+        else if (!HALFREADS || i < 2) nxt[2 * i + 1] = __builtin_bit_cast(f16x8, ring_tile(ring, TNEXT + 2 * i + 1));
         else nxt[2 * i + 1] = nxt[2 * i - 3];
         SB();
         acc[a] = mf16(wl, xh[XB + i], acc[a]);
@@ -81,18 +86,18 @@ __device__ __forceinline__ void v16_group(Ring& ring, DmaSrc& src, uint32_t& dst
     for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
 }
 
-template <int SL, bool HR, bool C6 = false>
+template <int SL, bool HR, bool C6 = false, bool DUP = false>
 __device__ __forceinline__ void v16_slots(Ring& ring, DmaSrc& src, uint32_t& dst, f16x8 (&cur)[8], const f16x8 (&xh)[16], const f16x8 (&xl)[16],
                                           f32x4 (&acc)[32], int& slot) {
     if constexpr (SL < 8) {
-        v16_group<0, (SL & 3) * 4, SL * 8, (SL < 4), HR, C6>(ring, src, dst, cur, xh, xl, acc);
-        v16_group<8, (SL & 3) * 4, SL * 8 + 4, (SL < 4), HR, C6>(ring, src, dst, cur, xh, xl, acc);
+        v16_group<0, (SL & 3) * 4, SL * 8, (SL < 4), HR, C6, DUP>(ring, src, dst, cur, xh, xl, acc);
+        v16_group<8, (SL & 3) * 4, SL * 8 + 4, (SL < 4), HR, C6, DUP>(ring, src, dst, cur, xh, xl, acc);
         if (++slot == STEP_SLOTS) { slot = 0; ring_next_step(ring); }
-        v16_slots<SL + 1, HR, C6>(ring, src, dst, cur, xh, xl, acc, slot);
+        v16_slots<SL + 1, HR, C6, DUP>(ring, src, dst, cur, xh, xl, acc, slot);
     }
 }
 
-template <bool HR, bool C6 = false>
+template <bool HR, bool C6 = false, bool DUP = false>
 __global__ void __launch_bounds__(256, 1) k16(const char* stream, float* out, int nchunks, unsigned long long* cyc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -114,7 +119,7 @@ __global__ void __launch_bounds__(256, 1) k16(const char* stream, float* out, in
     uint32_t dst = 0;
     int slot = 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (int c = 0; c < nchunks; ++c) v16_slots<0, HR, C6>(ring, src, dst, cur, xh, xl, acc, slot);
+    for (int c = 0; c < nchunks; ++c) v16_slots<0, HR, C6, DUP>(ring, src, dst, cur, xh, xl, acc, slot);
     if (threadIdx.x == 0) cyc[blockIdx.x] = __builtin_amdgcn_s_memtime() - t0;
     float r = 0;
     for (int i = 0; i < 32; ++i) r += acc[i][0] + acc[i][3];
@@ -538,6 +543,21 @@ __global__ void __launch_bounds__(256, 1) krole(const char* stream, float* out, 
         for (int i = 0; i < 16; ++i)
 #pragma unroll
             for (int p = 0; p < 2; ++p) { xh[i][p] = rand_operand(s, 1.0f); xl[i][p] = rand_operand(s, 4e-4f); }
+        // the lo operands are BORN in the accumulation register file (v_accvgpr_write with an "=a" result) so that the
+        // "a"-constrained hl MFMAs below read them in place: values that are defined in VGPRs get copied in front of every use
+        if constexpr (ORDER == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+                    const u32x4v v = __builtin_bit_cast(u32x4v, xl[i][p]);
+                    u32x4v r;
+                    asm volatile("v_accvgpr_write_b32 %0, %4\n\tv_accvgpr_write_b32 %1, %5\n\tv_accvgpr_write_b32 %2, %6\n\tv_accvgpr_write_b32 %3, %7"
+                                 : "=a"(r[0]), "=a"(r[1]), "=a"(r[2]), "=a"(r[3]) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+                    xl[i][p] = __builtin_bit_cast(f16x8, r);
+                }
+        }
         f32x4 ch[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) for (int p = 0; p < 2; ++p) ch[i][p] = f32x4{0, 0, 0, 0};
@@ -623,6 +643,7 @@ int main() {
     for (int rep = 0; rep < 2; ++rep) {
         const float a = run(k16<false>, "V16 (16 poses per wave)", stream, out, nchunks);
         run(k16<true>, "V16 with half the tile reads (diag)", stream, out, nchunks);
+        run(k16<false, false, true>, "V16, all reads, duplicated data (diag)", stream, out, nchunks);
         run(k16<false, true>, "V16, part B chains of six (diag)", stream, out, nchunks);
         const float b = run(k32<false>, "V32 pair-major chains", stream, out, nchunks);
         const float c = run(k32<true>, "V32 two accumulators interleaved", stream, out, nchunks);
