@@ -17,6 +17,11 @@ LITE_REGIMES = {"s2g3": dict(seed=2, gain=3.0, out_bias=0.05), "s4g25": dict(see
 ALL_REGIMES = {**REGIMES, **LITE_REGIMES}
 # the weight sets of the robustness sweep (tools/gpu_sweep.py, tests/test_gpu_sweep.py): (seed, gain, lin6.bias)
 SWEEP_WEIGHTS = ((0, 2.0, 0.1), (0, 2.5, 0.05), (1, 1.0, 0.2), (2, 3.0, 0.05), (3, 0.5, 0.3), (4, 2.5, 0.05))
+# HELD-OUT weight sets that never took part in calibrating a gate: PNDF_SWEEP_HELDOUT=1 (round 2's six) or =2 (six more, first
+# run in round 3 after the outlier gate was tightened) swaps them into tests/test_gpu_sweep.py; results under profiles/.
+_HELDOUT = {"1": ((5, 0.7, 0.3), (6, 1.5, 0.1), (7, 2.0, 0.0), (8, 3.5, 0.02), (9, 4.0, 0.1), (10, 2.2, -0.05)),
+            "2": ((11, 0.6, 0.25), (12, 1.2, 0.15), (13, 1.8, 0.0), (14, 2.8, 0.03), (15, 3.2, 0.08), (16, 2.4, -0.03))}
+SWEEP_WEIGHTS = _HELDOUT.get(os.environ.get("PNDF_SWEEP_HELDOUT", ""), SWEEP_WEIGHTS)
 
 
 def pytest_configure(config):
