@@ -186,7 +186,10 @@ def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0, margin=None,
     n = len(mine_rows)
     slack = max(0.003, 2.0 / n)
     assert np.isfinite(mine_rows).all(), (what, "non-finite error", int((~np.isfinite(mine_rows)).sum()))
-    assert np.median(mine_rows) < tol / 10, (what, float(np.median(mine_rows)))
+    # batch median: a tenth of the bar -- or, for a network on which the reference arithmetic's own fp32 median is worse than
+    # that (held-out set 2, seed 14 gain 2.8 softplus: 1.3e-5 for the fp32 oracle itself), `ratio` x the reference's median
+    assert np.median(mine_rows) < max(tol / 10, ratio * float(np.median(ref_rows))), (what, float(np.median(mine_rows)),
+                                                                                    float(np.median(ref_rows)))
     frac, ref_frac = float((mine_rows > tol).mean()), float((ref_rows > tol).mean())
     assert frac <= ratio * ref_frac + slack, (what, frac, ref_frac, float(mine_rows.max()), float(ref_rows.max()))
     # p95 inside the bar wherever the reference arithmetic's own p95 is
