@@ -149,7 +149,8 @@ class BodyModel(torch.nn.Module):
     def forward(self, root_orient=None, pose_body=None, betas=None, return_dict=False, **kwargs):
         if root_orient is not None:
             raise PndfError("root_orient is SMPL's zero global_orient parameter here (the reference passes None)")
-        if betas is not None and torch.count_nonzero(betas.to(self.betas.device).reshape(-1, self.betas.numel()) - self.betas):
+        if (betas is not None and self.betas.numel() > 0
+                and torch.count_nonzero(betas.to(self.betas.device).reshape(-1, self.betas.numel()) - self.betas)):
             raise PndfError("betas are fixed at construction (motion_denoise.py:27,67: zeros, requires_grad False)")
         pose_body = pose_body.to(self.device)
         verts, joints = _Lbs.apply(pose_body, self)
