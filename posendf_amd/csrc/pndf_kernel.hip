@@ -221,10 +221,14 @@ __device__ __forceinline__ void act_tiles(f32x4 (&x)[NT], uint32_t (&m)[(NT * 4 
 
 template <int NT, bool SP>
 __device__ __forceinline__ void dact_tiles(f32x4 (&gx)[NT], const uint32_t (&m)[(NT * 4 + 31) / 32], const ActP& ap, int spslot) {
+    // softplus: an opaque copy of the lane offset keeps hipcc from carrying the forward pass's NT slot addresses (64 bits each)
+    // across the whole step to here and spilling them (see dact_split_tiles in pndf_kernel_split.hip)
+    SpRef sp = ap.sp;
+    if constexpr (SP) asm volatile("" : "+v"(sp.off));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if constexpr (SP) {
-            gx[t] = gx[t] * *ap.sp.slot(spslot + t);
+            gx[t] = gx[t] * *sp.slot(spslot + t);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)

@@ -738,10 +738,16 @@ __device__ __forceinline__ void dact_split_tiles(f32x4 (&gx)[NT], Blk (&out)[NT 
     bound = pose_max(tiles_absmax<NT>(gx)) * act.to_true * dmax;
     oscale = pose_scale(bound);
     const float cf = act.to_true * oscale, k1 = (1.0f - act.slope) * cf, k0 = act.slope * cf;
+    // softplus: the NT slot addresses are the ones the forward pass stored to.  Left to itself hipcc keeps those NT 64-bit
+    // addresses alive from the forward activation pass to here -- across the whole step -- and spills them (66 of the
+    // kernel's 89 spilled VGPRs, one scratch_store per tile in the forward pass, one scratch_load here); an opaque copy of
+    // the lane offset makes it recompute them (two VALU instructions each).
+    SpRef sp = act.sp;
+    if constexpr (SP) asm volatile("" : "+v"(sp.off));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if constexpr (SP) {
-            gx[t] = (gx[t] * cf) * *act.sp.slot(act.spslot + t);
+            gx[t] = (gx[t] * cf) * *sp.slot(act.spslot + t);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
