@@ -12,6 +12,9 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#ifndef PNDF_SP_DIAG
+#define PNDF_SP_DIAG 0      // timing diagnostics of the softplus backward staging (WRONG results): 1 = no wait for the staged tiles,
+#endif                      // 2 = no staging DMA either (profiles/r03/sp_stage_diag.txt)
 
 namespace {
 
@@ -351,7 +354,7 @@ struct SplitPhase {
             if constexpr (S == 0) {
                 cf = act.to_true * act.oscale;
                 if constexpr (SP && BWD) {
-                    wait_staged_derivatives<STAGE_YOUNGER>();
+                    if (!(PNDF_SP_DIAG & 1)) wait_staged_derivatives<STAGE_YOUNGER>();
                 } else if constexpr (!BWD) {
 #pragma unroll
                     for (int ci = 0; ci < CT; ++ci) {
@@ -456,7 +459,8 @@ struct SplitPhase {
     static __device__ __forceinline__ void init_chunk(f32x4 (&ch)[3][CT], const float* biasA, int c, int g, const SAct& act) {
         if constexpr (SP && BWD) {
 #pragma unroll
-            for (int ci = 0; ci < CT; ++ci) stage_derivative_tile(act.sp, act.spslot + c * CT + ci, act.stage + ci * 1024);
+            for (int ci = 0; ci < CT; ++ci)
+                if (!(PNDF_SP_DIAG & 2)) stage_derivative_tile(act.sp, act.spslot + c * CT + ci, act.stage + ci * 1024);
         }
 #pragma unroll
         for (int ci = 0; ci < CT; ++ci) {
