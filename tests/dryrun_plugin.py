@@ -1,5 +1,6 @@
-"""pytest plugin for a CPU DRY RUN of the `-m gpu` tests' Python (development aid, never part of a real test run):
-    python -m pytest -p tools.dryrun_plugin -m gpu tests/test_gpu_parity.py -k "golden or ragged"
+"""TEST INFRASTRUCTURE (like the oracle it wraps; never imported by the product or by a real test run).
+pytest plugin for a CPU DRY RUN of the `-m gpu` tests' Python (development aid, never part of a real test run):
+    PYTHONPATH=tests python -m pytest -p dryrun_plugin -m gpu tests/test_gpu_parity.py -k "golden or ragged"
 The engine is replaced by the numpy fp32 oracle behind the same raw-pointer interface, `.cuda()` becomes a no-op and
 "cuda:0" becomes "cpu" -- so the test bodies, their gates and their envelopes run end to end on a box without a GPU
 (GPU minutes are scarce; a NameError in a gate should not cost a box).  An independent fp32 arithmetic in the kernel's
