@@ -11,6 +11,10 @@ here, so the model PARAMETERS are supplied by the caller as arrays with the shap
 `forward` is differentiable with respect to `pose_body` (first order, through `pndf_lbs_backward`); the betas and the global
 orientation are constants, as in the reference's optimisation (motion_denoise.py:27,67; root_orient=None).  There is no CPU
 or eager fallback: without the library or a gfx950 device the constructor raises.
+
+The C ABI takes its scratch from the caller; this class keeps ONE workspace per device and re-uses it for every call, so
+calls of one instance must be ordered on the device (one stream, or events) -- use one `BodyModel` per concurrently used
+stream, as with the softplus engine.
 """
 from __future__ import annotations
 
