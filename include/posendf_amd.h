@@ -142,6 +142,21 @@ int pndf_denoise_update(const float* theta_in, float* theta_out, const float* th
                         float* m, float* v, float* q_next, int32_t S, int32_t T, int32_t it, int32_t adam_step, float lr,
                         void* stream);
 
+/* The same step with EXPLICIT loss weights of the current outer iteration -- for callers whose schedule differs from
+ * motion_denoise.py's, e.g. the copy of the loop in experiments/partial_observation.py:29-35 (temp 1e2 (1+it), data 1e1/(1+it),
+ * pose prior 1e2 c/(1+it): LINEAR in c).  Objective: prior_coef * c^prior_power + temp_coef * temp + data_coef * data with
+ * c = mean_t d; prior_power 1 or 2; data_coef 0 switches the data term off (the reference does for it == 0).  g_body NULL:
+ * pose-space surrogates; otherwise the body-model gradient of pndf_lbs_terms_grad_w, evaluated with the same temp / data weights. */
+typedef struct {
+    float prior_coef;
+    int32_t prior_power;
+    float temp_coef;
+    float data_coef;
+} pndf_denoise_weights;
+int pndf_denoise_update_w(const float* theta_in, float* theta_out, const float* theta0, const float* d, const float* dq,
+                          const float* g_body, float* m, float* v, float* q_next, int32_t S, int32_t T,
+                          const pndf_denoise_weights* w, int32_t adam_step, float lr, void* stream);
+
 /* The same Adam step with the gradient of the BODY-MODEL terms (SMPL vertex temporal term + joint data term,
  * motion_denoise.py:86-94) in place of the pose-space surrogates: g_body [S,T,69] = d(weighted temp + data terms)/d theta as
  * produced by pndf_lbs_terms_grad below.  All 23 joints of the body pose are updated (the surrogates leave the two hand
@@ -180,6 +195,9 @@ int pndf_lbs_forward(pndf_lbs_handle h, const float* theta, int64_t N, float* ve
  * (identical consecutive vertices give NaN). */
 int pndf_lbs_terms_grad(pndf_lbs_handle h, const float* theta, const float* joints0, int32_t S, int32_t T, int32_t it,
                         float* g_theta, void* workspace, void* stream);
+/* The same with explicit weights: d / d theta of temp_coef * temp + data_coef * data (data_coef == 0: no data term). */
+int pndf_lbs_terms_grad_w(pndf_lbs_handle h, const float* theta, const float* joints0, int32_t S, int32_t T, float temp_coef,
+                          float data_coef, float* g_theta, void* workspace, void* stream);
 /* General reverse pass: g_theta [N,69] = d (<g_verts, verts> + <g_joints, joints>) / d theta (either may be NULL). */
 int pndf_lbs_backward(pndf_lbs_handle h, const float* theta, const float* g_verts, const float* g_joints, int64_t N,
                       float* g_theta, void* workspace, void* stream);

@@ -21,6 +21,10 @@ import numpy as np
 from . import posendf_np as onp
 
 NJ = 21
+# (coefficient, power of the loss, exponent of (1 + it)) per term: experiments/motion_denoise.py:29-35 and the copy of the loop
+# in experiments/partial_observation.py:29-35 (pose prior LINEAR in the mean distance)
+SCHEDULES = {"motion_denoise": {"temp": (10.0, 1, 1), "data": (100.0, 1, -1), "pose_pr": (1e7, 2, -1)},
+             "partial_observation": {"temp": (100.0, 1, 1), "data": (10.0, 1, -1), "pose_pr": (100.0, 1, -1)}}
 SURROGATE_EPS = 1e-20      # inside the sqrt of the surrogate norms (a zero difference has a zero, not a NaN, gradient)
 
 
@@ -42,7 +46,7 @@ def aa2quat_vjp(a, gq):
     return common * a + k * gq[..., 1:]
 
 
-def step_gradient(theta, theta0, sd, it, act="lrelu", beta=100.0, dtype=np.float64, body=None):
+def step_gradient(theta, theta0, sd, it, act="lrelu", beta=100.0, dtype=np.float64, body=None, schedule="motion_denoise"):
     """d (total weighted loss) / d theta for ONE sequence theta [T,69]; returns (grad [T,69], weighted terms dict).
     body = (model dict of oracle/lbs_np.py, joints0 [T, n_joints, 3]): the reference's SMPL vertex temporal term and joint
     data term (motion_denoise.py:86-94; oracle/lbs_np.body_terms, parity unpinned) instead of the pose-space surrogates."""
@@ -52,34 +56,38 @@ def step_gradient(theta, theta0, sd, it, act="lrelu", beta=100.0, dtype=np.float
     q, _, _ = axis_angle_to_quaternion(a)
     d, dq = onp.forward_grad(q.astype(dtype), sd, act, beta, dtype)
     c = d.mean(dtype=dtype)
-    terms = {"pose_pr": dtype(1e7) * c * c / dtype(1 + it)}
+    sch = SCHEDULES[schedule]
+    ev = lambda k: dtype(sch[k][0]) * dtype(1 + it) ** sch[k][2]
+    pc, pp = ev("pose_pr"), sch["pose_pr"][1]
+    w_temp, w_data = ev("temp"), ev("data")
+    terms = {"pose_pr": pc * c ** pp}
     g = np.zeros((T, 23, 3), dtype)
-    g[:, :NJ] = aa2quat_vjp(a, dq * (dtype(2e7) * c / (dtype(1 + it) * dtype(T))))
+    g[:, :NJ] = aa2quat_vjp(a, dq * ((dtype(2) * pc * c if pp == 2 else pc) / dtype(T)))
     if body is not None:
         from . import lbs_np
-        gb, bt = lbs_np.body_terms(theta, body[1], body[0], it, dtype)
+        gb, bt = lbs_np.body_terms(theta, body[1], body[0], it, dtype, coefs=(w_temp, w_data))
         if "temp" in bt:
-            terms["temp"] = dtype(10.0 * (1 + it)) * bt["temp"]
+            terms["temp"] = w_temp * bt["temp"]
         if "data" in bt:
-            terms["data"] = dtype(100.0 / (1 + it)) * bt["data"]
+            terms["data"] = w_data * bt["data"]
         return g.reshape(T, 69) + gb, terms
     if T > 1:
         diff = a[:-1] - a[1:]
         nrm = np.sqrt((diff * diff).sum(-1, keepdims=True) + dtype(SURROGATE_EPS))
-        w = dtype(10.0 * (1 + it)) / dtype((T - 1) * NJ)
-        terms["temp"] = dtype(10.0 * (1 + it)) * nrm.mean(dtype=dtype)
+        w = w_temp / dtype((T - 1) * NJ)
+        terms["temp"] = w_temp * nrm.mean(dtype=dtype)
         g[:-1, :NJ] += w * diff / nrm
         g[1:, :NJ] -= w * diff / nrm
     if it > 0:
         diff = a - np.asarray(theta0, dtype).reshape(T, 23, 3)[:, :NJ]
         nrm = np.sqrt((diff * diff).sum(-1, keepdims=True) + dtype(SURROGATE_EPS))
-        terms["data"] = dtype(100.0 / (1 + it)) * nrm.mean(dtype=dtype)
-        g[:, :NJ] += dtype(100.0 / (1 + it)) / dtype(T * NJ) * diff / nrm
+        terms["data"] = w_data * nrm.mean(dtype=dtype)
+        g[:, :NJ] += w_data / dtype(T * NJ) * diff / nrm
     return g.reshape(T, 69), terms
 
 
 def optimize(theta0, sd, iterations=10, steps_per_iter=50, lr=0.02, act="lrelu", beta=100.0, dtype=np.float64,
-             trace=False, body_model=None):
+             trace=False, body_model=None, schedule="motion_denoise"):
     """The loop of MotionDenoise.optimize (:70-99) for one sequence [T,69] or a batch of independent ones [S,T,69]."""
     theta0 = np.asarray(theta0, dtype)
     single = theta0.ndim == 2
@@ -96,7 +104,7 @@ def optimize(theta0, sd, iterations=10, steps_per_iter=50, lr=0.02, act="lrelu",
     for it in range(iterations):
         for _ in range(steps_per_iter):
             k += 1
-            g = np.stack([step_gradient(th[s], th0[s], sd, it, act, beta, dtype, bodies[s])[0] for s in range(th.shape[0])])
+            g = np.stack([step_gradient(th[s], th0[s], sd, it, act, beta, dtype, bodies[s], schedule)[0] for s in range(th.shape[0])])
             m = b1 * m + (1 - b1) * g
             v = b2 * v + (1 - b2) * g * g
             bc1, bc2 = 1 - b1 ** k, 1 - b2 ** k

@@ -136,9 +136,10 @@ def lbs_vjp(model, cache, g_verts, g_joints, dtype=np.float64):
 
 
 # ---------------------------------------------------------------- experiments/motion_denoise.py:86-94, restated
-def body_terms(theta, joints0, model, it, dtype=np.float64):
+def body_terms(theta, joints0, model, it, dtype=np.float64, coefs=None):
     """ONE sequence theta [T,69]: the unweighted temporal and data terms and the gradient of their WEIGHTED sum
-    10 (1 + it) temp + [it > 0] 100 / (1 + it) data  with respect to theta (motion_denoise.py:29-45,86-94).  Like the
+    10 (1 + it) temp + [it > 0] 100 / (1 + it) data  with respect to theta (motion_denoise.py:29-45,86-94).
+    `coefs` = (temp weight, data weight) replaces that schedule (experiments/partial_observation.py:31-32).  Like the
     reference there is no epsilon under the square roots: two identical consecutive vertices (or a joint that has not
     moved, which is why the reference skips the data term at it = 0, :92) give a NaN gradient."""
     theta = np.asarray(theta, dtype).reshape(-1, 69)
@@ -152,7 +153,7 @@ def body_terms(theta, joints0, model, it, dtype=np.float64):
         nrm = np.sqrt((diff * diff).sum(-1, keepdims=True))
         terms["temp"] = nrm.mean(dtype=dtype)
         with np.errstate(divide="ignore", invalid="ignore"):
-            u = diff / nrm * (dtype(10.0 * (1 + it)) / dtype(nrm.size))
+            u = diff / nrm * (dtype(10.0 * (1 + it) if coefs is None else coefs[0]) / dtype(nrm.size))
         gV[:-1] += u
         gV[1:] -= u
     if it > 0:
@@ -160,5 +161,5 @@ def body_terms(theta, joints0, model, it, dtype=np.float64):
         nrm = np.sqrt((diff * diff).sum(-1, keepdims=True))
         terms["data"] = nrm.mean(dtype=dtype)
         with np.errstate(divide="ignore", invalid="ignore"):
-            gJ += diff / nrm * (dtype(100.0 / (1 + it)) / dtype(nrm.size))
+            gJ += diff / nrm * (dtype(100.0 / (1 + it) if coefs is None else coefs[1]) / dtype(nrm.size))
     return lbs_vjp(model, cache, gV, gJ, dtype), terms

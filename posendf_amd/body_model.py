@@ -173,10 +173,16 @@ class BodyModel(torch.nn.Module):
         return joints
 
     @torch.no_grad()
-    def terms_grad(self, theta, joints0, it, out=None):
-        """theta [S,T,69], joints0 [S*T, num_joints, 3] -> d (10 (1+it) temp + [it>0] 100/(1+it) data) / d theta [S,T,69]."""
+    def terms_grad(self, theta, joints0, it, out=None, coefs=None):
+        """theta [S,T,69], joints0 [S*T, num_joints, 3] -> d (10 (1+it) temp + [it>0] 100/(1+it) data) / d theta [S,T,69];
+        `coefs` = (temp_coef, data_coef) replaces the motion_denoise.py schedule (data_coef 0: no data term)."""
         S, T = theta.shape[:2]
         g = torch.empty_like(theta) if out is None else out
-        self._call("pndf_lbs_terms_grad", theta.data_ptr(), None if joints0 is None else joints0.data_ptr(), S, T, int(it),
-                   g.data_ptr(), self._workspace(S, T, theta.device), self._stream(theta.device))
+        j0 = None if joints0 is None else joints0.data_ptr()
+        if coefs is None:
+            self._call("pndf_lbs_terms_grad", theta.data_ptr(), j0, S, T, int(it), g.data_ptr(),
+                       self._workspace(S, T, theta.device), self._stream(theta.device))
+        else:
+            self._call("pndf_lbs_terms_grad_w", theta.data_ptr(), j0, S, T, float(coefs[0]), float(coefs[1]), g.data_ptr(),
+                       self._workspace(S, T, theta.device), self._stream(theta.device))
         return g

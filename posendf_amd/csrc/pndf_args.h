@@ -41,11 +41,16 @@ struct PndfDenoiseArgs {
     float* q_next;         // [S*T,84] quaternions of the UPDATED theta
     const float* g_extra;  // null, or [S,T,69]: gradient of the body-model terms (pndf_lbs_terms_grad), already weighted;
                            //   when given, the pose-space surrogate terms are NOT added
-    int S, T, it, adam_step;
+    int S, T, adam_step, prior_power;
     float lr, beta1, beta2, eps;
+    // loss weights of this outer iteration, already evaluated (include/posendf_amd.h pndf_denoise_weights):
+    //   pose prior  prior_coef c^prior_power  (c = mean_t d),   temporal  temp_coef mean ||..||,   data  data_coef mean ||..||
+    float prior_coef, temp_coef, data_coef;
+    int reserved0;
 };
-static_assert(sizeof(PndfDenoiseArgs) == 104 && offsetof(PndfDenoiseArgs, g_extra) == 64 &&
-              offsetof(PndfDenoiseArgs, S) == 72 && offsetof(PndfDenoiseArgs, lr) == 88, "PndfDenoiseArgs layout");
+static_assert(sizeof(PndfDenoiseArgs) == 120 && offsetof(PndfDenoiseArgs, g_extra) == 64 &&
+              offsetof(PndfDenoiseArgs, S) == 72 && offsetof(PndfDenoiseArgs, lr) == 88 &&
+              offsetof(PndfDenoiseArgs, prior_coef) == 104, "PndfDenoiseArgs layout");
 
 struct PndfQuatDistArgs {
     const float* noise;    // [B,21,4]

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/posendf_amd.h"
 #include "pndf_args.h"
 #include "pndf_host.h"
 
@@ -81,7 +82,9 @@ extern "C" __global__ void __launch_bounds__(WG) pndf_denoise_update_kernel(Pndf
         const float kp = (angle < 1e-6f) ? (-1.0f / 24.0f) : ((0.5f * qq[0] - k) / (angle * angle));
         const float gv_dot_a = g4.y * x + g4.z * y + g4.w * z;
         const float common = -0.5f * k * g4.x + kp * gv_dot_a;
-        const float wp = 2.0e7f * c / ((float)(1 + a.it) * (float)T);
+        // d / d c of prior_coef c^p, spread over the T frames of the mean: p = 2 (motion_denoise.py:33: 1e7 c^2 / (1 + it)) or
+        // p = 1 (partial_observation.py:33: 1e2 c / (1 + it))
+        const float wp = (a.prior_power == 2 ? 2.0f * a.prior_coef * c : a.prior_coef) / (float)T;
         gx = wp * (common * x + k * g4.y);
         gy = wp * (common * y + k * g4.z);
         gz = wp * (common * z + k * g4.w);
@@ -92,9 +95,9 @@ extern "C" __global__ void __launch_bounds__(WG) pndf_denoise_update_kernel(Pndf
         const float* ge = a.g_extra + n * TH + 3 * j;
         gx += ge[0]; gy += ge[1]; gz += ge[2];
     } else if (j < NJ) {
-        // ---- temporal surrogate: 10 (1+it) * mean_{t<T-1, j} sqrt(|th_t - th_t+1|^2 + 1e-20)
+        // ---- temporal surrogate: temp_coef * mean_{t<T-1, j} sqrt(|th_t - th_t+1|^2 + 1e-20)
         if (T > 1) {
-            const float wt = 10.0f * (float)(1 + a.it) / ((float)(T - 1) * (float)NJ);
+            const float wt = a.temp_coef / ((float)(T - 1) * (float)NJ);
             if (t + 1 < T) {
                 const float* nx = th + TH;
                 const float dx = x - nx[0], dy = y - nx[1], dz = z - nx[2];
@@ -108,11 +111,11 @@ extern "C" __global__ void __launch_bounds__(WG) pndf_denoise_update_kernel(Pndf
                 gx -= r * dx; gy -= r * dy; gz -= r * dz;
             }
         }
-        // ---- data surrogate (it > 0): 100 / (1+it) * mean_{t, j} sqrt(|th - th0|^2 + 1e-20)
-        if (a.it > 0) {
+        // ---- data surrogate (it > 0: data_coef != 0): data_coef * mean_{t, j} sqrt(|th - th0|^2 + 1e-20)
+        if (a.data_coef != 0.f) {
             const float* t0 = a.theta0 + n * TH + 3 * j;
             const float dx = x - t0[0], dy = y - t0[1], dz = z - t0[2];
-            const float r = 100.0f / (float)(1 + a.it) / ((float)T * (float)NJ) / sqrtf(dx * dx + dy * dy + dz * dz + 1e-20f);
+            const float r = a.data_coef / ((float)T * (float)NJ) / sqrtf(dx * dx + dy * dy + dz * dz + 1e-20f);
             gx += r * dx; gy += r * dy; gz += r * dz;
         }
     }
@@ -157,9 +160,9 @@ extern "C" int pndf_aa2quat(const float* theta, float* q, int64_t N, void* strea
 }
 
 static int denoise_update(const float* theta_in, float* theta_out, const float* theta0, const float* d, const float* dq,
-                          float* m, float* v, float* q_next, const float* g_extra, int32_t S, int32_t T, int32_t it,
-                          int32_t adam_step, float lr, void* stream) {
-    if (S < 0 || T < 0 || it < 0 || adam_step < 1) return -1;
+                          float* m, float* v, float* q_next, const float* g_extra, int32_t S, int32_t T,
+                          const pndf_denoise_weights& w, int32_t adam_step, float lr, void* stream) {
+    if (S < 0 || T < 0 || adam_step < 1 || (w.prior_power != 1 && w.prior_power != 2)) return -1;
     if (S == 0 || T == 0) return 0;
     if (!theta_in || !theta_out || !theta0 || !d || !dq || !m || !v || !q_next || theta_in == theta_out) return -1;
     if ((((uintptr_t)dq) | ((uintptr_t)q_next)) & 15) return -1;
@@ -167,22 +170,43 @@ static int denoise_update(const float* theta_in, float* theta_out, const float* 
     if (!guard.ok) return -3;
     PndfDenoiseArgs a;
     a.theta_in = theta_in; a.theta_out = theta_out; a.theta0 = theta0; a.d = d; a.dq = dq; a.m = m; a.v = v;
-    a.q_next = q_next; a.g_extra = g_extra; a.S = S; a.T = T; a.it = it; a.adam_step = adam_step;
+    a.q_next = q_next; a.g_extra = g_extra; a.S = S; a.T = T; a.adam_step = adam_step; a.prior_power = w.prior_power;
+    a.prior_coef = w.prior_coef; a.temp_coef = w.temp_coef; a.data_coef = w.data_coef; a.reserved0 = 0;
     a.lr = lr; a.beta1 = 0.9f; a.beta2 = 0.999f; a.eps = 1e-8f;       // motion_denoise.py:70, torch.optim.Adam defaults
     const dim3 grid((unsigned)((T + FRAMES_PER_WG - 1) / FRAMES_PER_WG), (unsigned)S);
     hipLaunchKernelGGL(pndf_denoise_update_kernel, grid, dim3(WG), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// experiments/motion_denoise.py:29-35 at outer iteration `it`; the data term only for it > 0 (:92)
+static pndf_denoise_weights motion_denoise_weights(int32_t it) {
+    pndf_denoise_weights w;
+    w.prior_coef = 1.0e7f / (float)(1 + it);
+    w.prior_power = 2;
+    w.temp_coef = 10.0f * (float)(1 + it);
+    w.data_coef = it > 0 ? 100.0f / (float)(1 + it) : 0.0f;
+    return w;
+}
+
 extern "C" int pndf_denoise_update(const float* theta_in, float* theta_out, const float* theta0, const float* d,
                                    const float* dq, float* m, float* v, float* q_next, int32_t S, int32_t T, int32_t it,
                                    int32_t adam_step, float lr, void* stream) {
-    return denoise_update(theta_in, theta_out, theta0, d, dq, m, v, q_next, nullptr, S, T, it, adam_step, lr, stream);
+    if (it < 0) return -1;
+    return denoise_update(theta_in, theta_out, theta0, d, dq, m, v, q_next, nullptr, S, T, motion_denoise_weights(it), adam_step,
+                          lr, stream);
+}
+
+extern "C" int pndf_denoise_update_w(const float* theta_in, float* theta_out, const float* theta0, const float* d, const float* dq,
+                                     const float* g_body, float* m, float* v, float* q_next, int32_t S, int32_t T,
+                                     const pndf_denoise_weights* w, int32_t adam_step, float lr, void* stream) {
+    if (!w) return -1;
+    return denoise_update(theta_in, theta_out, theta0, d, dq, m, v, q_next, g_body, S, T, *w, adam_step, lr, stream);
 }
 
 extern "C" int pndf_denoise_update_body(const float* theta_in, float* theta_out, const float* theta0, const float* d,
                                         const float* dq, const float* g_body, float* m, float* v, float* q_next, int32_t S,
                                         int32_t T, int32_t it, int32_t adam_step, float lr, void* stream) {
-    if (!g_body) return -1;
-    return denoise_update(theta_in, theta_out, theta0, d, dq, m, v, q_next, g_body, S, T, it, adam_step, lr, stream);
+    if (!g_body || it < 0) return -1;
+    return denoise_update(theta_in, theta_out, theta0, d, dq, m, v, q_next, g_body, S, T, motion_denoise_weights(it), adam_step,
+                          lr, stream);
 }

@@ -693,19 +693,29 @@ extern "C" int pndf_lbs_forward(pndf_lbs_handle h, const float* theta, int64_t N
     return lbs_launch(h, 0, a, workspace, stream);
 }
 
+extern "C" int pndf_lbs_terms_grad_w(pndf_lbs_handle h, const float* theta, const float* joints0, int32_t S, int32_t T,
+                                     float temp_coef, float data_coef, float* g_theta, void* workspace, void* stream) {
+    if (!h) return PNDF_ERR_BAD_ARG;
+    if (S < 0 || T < 0) return lbs_fail(h, PNDF_ERR_BAD_ARG, "negative size");
+    if (S == 0 || T == 0) return PNDF_OK;
+    const bool data = data_coef != 0.f;
+    if (!theta || !g_theta || !workspace || (data && !joints0)) return lbs_fail(h, PNDF_ERR_BAD_ARG, "null pointer");
+    PndfLbsArgs a;
+    lbs_clear(a);
+    a.theta = theta; a.joints0 = joints0; a.g_theta = g_theta; a.S = S; a.T = T; a.it_gt0 = data ? 1 : 0;
+    // the weights over the means of motion_denoise.py:89,94
+    a.w_temp = T > 1 ? temp_coef / ((float)(T - 1) * (float)h->V) : 0.f;
+    a.w_data = data ? data_coef / ((float)T * (float)(NJ + h->NE)) : 0.f;
+    return lbs_launch(h, 1, a, workspace, stream);
+}
+
 extern "C" int pndf_lbs_terms_grad(pndf_lbs_handle h, const float* theta, const float* joints0, int32_t S, int32_t T, int32_t it,
                                    float* g_theta, void* workspace, void* stream) {
     if (!h) return PNDF_ERR_BAD_ARG;
-    if (S < 0 || T < 0 || it < 0) return lbs_fail(h, PNDF_ERR_BAD_ARG, "negative size");
-    if (S == 0 || T == 0) return PNDF_OK;
-    if (!theta || !g_theta || !workspace || (it > 0 && !joints0)) return lbs_fail(h, PNDF_ERR_BAD_ARG, "null pointer");
-    PndfLbsArgs a;
-    lbs_clear(a);
-    a.theta = theta; a.joints0 = joints0; a.g_theta = g_theta; a.S = S; a.T = T; a.it_gt0 = it > 0 ? 1 : 0;
-    // motion_denoise.py:31-32 weights over :89,94 means
-    a.w_temp = T > 1 ? 10.0f * (float)(1 + it) / ((float)(T - 1) * (float)h->V) : 0.f;
-    a.w_data = it > 0 ? 100.0f / (float)(1 + it) / ((float)T * (float)(NJ + h->NE)) : 0.f;
-    return lbs_launch(h, 1, a, workspace, stream);
+    if (it < 0) return lbs_fail(h, PNDF_ERR_BAD_ARG, "negative iteration");
+    // motion_denoise.py:31-32: temp 10 (1 + it), data 100 / (1 + it) for it > 0 (:92)
+    return pndf_lbs_terms_grad_w(h, theta, joints0, S, T, 10.0f * (float)(1 + it), it > 0 ? 100.0f / (float)(1 + it) : 0.0f, g_theta,
+                                 workspace, stream);
 }
 
 extern "C" int pndf_lbs_backward(pndf_lbs_handle h, const float* theta, const float* g_verts, const float* g_joints, int64_t N,

@@ -23,6 +23,11 @@ class PndfConfig(ctypes.Structure):
                 ("dims", c_int32 * 16), ("parent", c_int32 * 32), ("precision", c_int32)]
 
 
+class DenoiseWeights(ctypes.Structure):
+    """pndf_denoise_weights: the loss weights of one outer iteration, evaluated"""
+    _fields_ = [("prior_coef", c_float), ("prior_power", c_int32), ("temp_coef", c_float), ("data_coef", c_float)]
+
+
 class PndfError(RuntimeError):
     pass
 
@@ -63,6 +68,10 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.pndf_aa2quat.restype = c_int
     lib.pndf_denoise_update.argtypes = [c_void_p] * 8 + [c_int32] * 4 + [c_float, c_void_p]
     lib.pndf_denoise_update.restype = c_int
+    lib.pndf_denoise_update_w.argtypes = [c_void_p] * 9 + [c_int32, c_int32, POINTER(DenoiseWeights), c_int32, c_float, c_void_p]
+    lib.pndf_denoise_update_w.restype = c_int
+    lib.pndf_lbs_terms_grad_w.argtypes = [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p]
+    lib.pndf_lbs_terms_grad_w.restype = c_int
     lib.pndf_denoise_update_body.argtypes = [c_void_p] * 9 + [c_int32] * 4 + [c_float, c_void_p]
     lib.pndf_denoise_update_body.restype = c_int
     LH = c_void_p
@@ -104,7 +113,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
 EXPORTS = ("pndf_default_config", "pndf_create", "pndf_destroy", "pndf_load_weights", "pndf_forward",
            "pndf_forward_grad", "pndf_project", "pndf_debug_forward_grad", "pndf_debug_floats",
            "pndf_debug_project_timing", "pndf_debug_timing_regions",
-           "pndf_packed_sizes", "pndf_pack_host", "pndf_pack_host_split", "pndf_aa2quat", "pndf_denoise_update", "pndf_denoise_update_body", "pndf_quat_topk",
+           "pndf_packed_sizes", "pndf_pack_host", "pndf_pack_host_split", "pndf_aa2quat", "pndf_denoise_update", "pndf_denoise_update_body", "pndf_denoise_update_w", "pndf_lbs_terms_grad_w", "pndf_quat_topk",
            "pndf_lbs_create", "pndf_lbs_destroy", "pndf_lbs_num_joints", "pndf_lbs_num_vertices", "pndf_lbs_workspace_floats",
            "pndf_lbs_forward", "pndf_lbs_terms_grad", "pndf_lbs_backward", "pndf_lbs_packed_floats", "pndf_lbs_pack_host",
            "pndf_lbs_last_error", "pndf_last_error", "pndf_version", "pndf_kernel_name")

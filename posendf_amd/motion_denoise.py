@@ -40,18 +40,38 @@ def axis_angle_to_quaternion(axis_angle: torch.Tensor) -> torch.Tensor:
     return torch.cat([torch.cos(half), axis_angle * k], dim=-1)
 
 
-def loss_weights():
-    """experiments/motion_denoise.py:29-35."""
-    return {"temp": lambda cst, it: 10.0 ** 1 * cst * (1 + it),
-            "data": lambda cst, it: 10.0 ** 2 * cst / (1 + it),
-            "pose_pr": lambda cst, it: 10.0 ** 7 * cst * cst / (1 + it)}
+# The reference ships the loop twice with different weights: experiments/motion_denoise.py:29-35 and its copy
+# experiments/partial_observation.py:29-35 (whose pose prior is LINEAR in the mean distance).  (coefficient, power of the
+# loss, exponent of (1 + it)) per term:
+SCHEDULES = {
+    "motion_denoise": {"temp": (10.0 ** 1, 1, +1), "data": (10.0 ** 2, 1, -1), "pose_pr": (10.0 ** 7, 2, -1)},
+    "partial_observation": {"temp": (10.0 ** 2, 1, +1), "data": (10.0 ** 1, 1, -1), "pose_pr": (10.0 ** 2, 1, -1)},
+}
+
+
+def loss_weights(schedule="motion_denoise"):
+    """experiments/motion_denoise.py:29-35 (default) or experiments/partial_observation.py:29-35: {term: f(loss, it)}."""
+    def make(coef, power, e):
+        return lambda cst, it: coef * cst ** power * (1 + it) ** e
+    return {k: make(*v) for k, v in SCHEDULES[schedule].items()}
+
+
+def iteration_coefs(schedule, it):
+    """(prior_coef, prior_power, temp_coef, data_coef) of outer iteration `it` (the data term only for it > 0, :92): what the
+    C ABI takes (pndf_denoise_weights, pndf_lbs_terms_grad_w)."""
+    s = SCHEDULES[schedule]
+    ev = lambda k: s[k][0] * (1 + it) ** s[k][2]
+    return ev("pose_pr"), s["pose_pr"][1], ev("temp"), (ev("data") if it > 0 else 0.0)
 
 
 class MotionDenoise:
-    def __init__(self, posendf, body_model=None, device="cuda:0"):
+    def __init__(self, posendf, body_model=None, device="cuda:0", schedule="motion_denoise"):
+        if schedule not in SCHEDULES:
+            raise ValueError(f"unknown weight schedule {schedule!r} ({', '.join(SCHEDULES)})")
         self.pose_prior = posendf
         self.body_model = body_model
         self.device = device
+        self.schedule = schedule          # "partial_observation": the weights of experiments/partial_observation.py:29-35
 
     # ---- loss terms -----------------------------------------------------------------------------
     def pose_prior_term(self, body_pose):
@@ -91,9 +111,8 @@ class MotionDenoise:
             loss["data"] = self._mean_norm(joints - init_joints)                      # :93-94
         return loss
 
-    @staticmethod
-    def total(loss, it):
-        w = loss_weights()
+    def total(self, loss, it):
+        w = loss_weights(self.schedule)
         return torch.stack([w[k](v, it) for k, v in loss.items()]).sum(dim=0)         # backward_step, :37-45
 
     # ---- optimiser ------------------------------------------------------------------------------
@@ -123,19 +142,18 @@ class MotionDenoise:
             joints0 = bm.joints_of(theta0)                  # smpl_init.Jtr of the noisy poses (motion_denoise.py:60,63)
             g_body = torch.empty_like(theta0)
         k = 0
+        from .engine import DenoiseWeights
         for it in range(iterations):
+            pc, pp, tc, dc = iteration_coefs(self.schedule, it)
+            w = DenoiseWeights(pc, pp, tc, dc)
             for _ in range(steps_per_iter):
                 k += 1
                 eng.forward_grad(q.data_ptr(), None, d.data_ptr(), dq.data_ptr(), N, stream.value or 0)
                 if bm is not None:
-                    bm.terms_grad(bufs[0], joints0, it, out=g_body)
-                    rc = lib.pndf_denoise_update_body(bufs[0].data_ptr(), bufs[1].data_ptr(), theta0.data_ptr(), d.data_ptr(),
-                                                      dq.data_ptr(), g_body.data_ptr(), m.data_ptr(), v.data_ptr(),
-                                                      q.data_ptr(), S, T, it, k, float(lr), stream)
-                else:
-                    rc = lib.pndf_denoise_update(bufs[0].data_ptr(), bufs[1].data_ptr(), theta0.data_ptr(), d.data_ptr(),
-                                                 dq.data_ptr(), m.data_ptr(), v.data_ptr(), q.data_ptr(), S, T, it, k,
-                                                 float(lr), stream)
+                    bm.terms_grad(bufs[0], joints0, it, out=g_body, coefs=(w.temp_coef, w.data_coef))
+                rc = lib.pndf_denoise_update_w(bufs[0].data_ptr(), bufs[1].data_ptr(), theta0.data_ptr(), d.data_ptr(),
+                                               dq.data_ptr(), None if bm is None else g_body.data_ptr(), m.data_ptr(),
+                                               v.data_ptr(), q.data_ptr(), S, T, ctypes.byref(w), k, float(lr), stream)
                 if rc != 0:
                     raise RuntimeError(f"pndf_denoise_update failed ({rc})")
                 bufs.reverse()

@@ -107,8 +107,9 @@ def test_large_batch_matches_small_batch(smpl_like):
     assert torch.equal(g, g2)                                   # deterministic
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
-def test_fused_denoise_with_body_model_matches_oracle_loop(smpl_like, precision):
+@pytest.mark.parametrize("precision,schedule", [("f16x3", "motion_denoise"), ("fp32", "motion_denoise"),
+                                                ("f16x3", "partial_observation")])
+def test_fused_denoise_with_body_model_matches_oracle_loop(smpl_like, precision, schedule):
     """optimize(fused=True) with the reference's objective (pose prior + SMPL vertex temporal term + joint data term,
     motion_denoise.py:74-99): engine launch + fused LBS pass + Adam kernel per step, against the numpy oracle of the loop."""
     from posendf_amd import PoseNDF, amass_config
@@ -121,9 +122,9 @@ def test_fused_denoise_with_body_model_matches_oracle_loop(smpl_like, precision)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     S, T, iters, per = 2, 20, 2, 3
     th0 = _theta(S, T, seed=21) * 0.5
-    md = MotionDenoise(net, body_model=bm, device="cuda:0")
+    md = MotionDenoise(net, body_model=bm, device="cuda:0", schedule=schedule)      # partial_observation.py:29-35: other weights
     got, _ = md.optimize(torch.from_numpy(th0), iterations=iters, steps_per_iter=per, fused=True)
-    ref = denoise_np.optimize(th0, sd, iterations=iters, steps_per_iter=per, body_model=m)
+    ref = denoise_np.optimize(th0, sd, iterations=iters, steps_per_iter=per, body_model=m, schedule=schedule)
     diff = np.abs(got.cpu().numpy() - ref)
     moved = np.abs(ref - th0).max()
     print(f"fused denoise + LBS vs oracle loop: median {np.median(diff):.2e} p99 {np.percentile(diff, 99):.2e} max {diff.max():.2e} moved {moved:.3f}")

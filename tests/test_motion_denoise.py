@@ -284,3 +284,59 @@ def test_very_short_sequences(T):
     b, _ = md.optimize(noisy, iterations=2, steps_per_iter=3, fused=True)
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
     assert (a - b).abs().max().item() < 2e-4, (a - b).abs().max().item()
+
+
+def test_partial_observation_schedule_matches_reference_formulas():
+    """experiments/partial_observation.py:29-35: the copy of the loop with other weights -- pose prior LINEAR in c."""
+    from posendf_amd.motion_denoise import iteration_coefs, loss_weights
+    w = loss_weights("partial_observation")
+    c = torch.tensor(0.03)
+    for it in (0, 1, 4, 9):
+        assert torch.isclose(w["temp"](c, it), 10.0 ** 2 * c * (1 + it))
+        assert torch.isclose(w["data"](c, it), 10.0 ** 1 * c / (1 + it))
+        assert torch.isclose(w["pose_pr"](c, it), 10.0 ** 2 * c / (1 + it))
+        pc, pp, tc, dc = iteration_coefs("partial_observation", it)
+        assert pp == 1 and abs(pc - 100.0 / (1 + it)) < 1e-9 and abs(tc - 100.0 * (1 + it)) < 1e-9
+        assert dc == (10.0 / (1 + it) if it > 0 else 0.0)
+    pc, pp, tc, dc = iteration_coefs("motion_denoise", 3)
+    assert (pc, pp, tc, dc) == (1e7 / 4, 2, 40.0, 25.0)
+
+
+def test_oracle_step_gradient_under_the_partial_observation_schedule():
+    """numpy oracle of the step against torch autograd of the same objective (pose prior from the oracle network)."""
+    from oracle import denoise_np
+    from posendf_amd.motion_denoise import MotionDenoise
+    sd = golden_weights("live")
+    th0 = _noisy_sequences(1, 7, seed=5)[0].double()
+    th = (th0 + 0.01 * torch.randn(7, 69, dtype=torch.float64, generator=torch.Generator().manual_seed(1))).requires_grad_(True)
+    md = MotionDenoise(_OraclePrior("lrelu", sd).double(), device="cpu", schedule="partial_observation")
+    loss = md.losses(th[None], th0[None].reshape(1, 7, 23, 3)[:, :, :21], 2)
+    md.total(loss, 2).sum().backward()
+    g, _ = denoise_np.step_gradient(th.detach().numpy(), th0.numpy(), sd, 2, schedule="partial_observation")
+    assert np.abs(g - th.grad.numpy()).max() < 1e-8 * np.abs(g).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_fused_partial_observation_schedule_matches_oracle(precision):
+    """optimize(fused=True) under partial_observation.py's weights (pndf_denoise_update_w: linear pose prior) against the
+    numpy oracle of the loop."""
+    from oracle import denoise_np
+    from posendf_amd import PoseNDF, amass_config
+    from posendf_amd.motion_denoise import MotionDenoise
+    sd = golden_weights("live")
+    cfg = amass_config("lrelu", "cuda:0")
+    cfg["engine"] = {"precision": precision}
+    net = PoseNDF(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    noisy = _noisy_sequences(3, 14, seed=8)
+    md = MotionDenoise(net, device="cuda:0", schedule="partial_observation")
+    got, _ = md.optimize(noisy, iterations=2, steps_per_iter=4, fused=True)
+    ref = denoise_np.optimize(noisy.numpy(), sd, iterations=2, steps_per_iter=4, schedule="partial_observation")
+    diff = np.abs(got.cpu().numpy() - ref)
+    assert np.median(diff) < 1e-5 and (diff > 1e-3).mean() < 0.01, (np.median(diff), diff.max())
+    other, _ = MotionDenoise(net, device="cuda:0").optimize(noisy, iterations=2, steps_per_iter=4, fused=True)
+    assert (other - got).abs().max().item() > 1e-3          # the two schedules are different objectives
+    auto, _ = md.optimize(noisy, iterations=2, steps_per_iter=4, record=False)
+    d2 = (auto - got).abs().flatten()
+    assert d2.median().item() < 1e-5 and (d2 > 1e-3).float().mean().item() < 0.01
