@@ -163,3 +163,23 @@ def test_small_model_short_sequences_and_reference_nan_semantics():
     assert np.isnan(g64[2]).all() and np.isnan(g64[3]).all() and np.isfinite(g64[[0, 1, 4, 5]]).all()      # the reference's NaN
     assert np.isnan(g[2]).all() and np.isnan(g[3]).all() and np.isfinite(g[[0, 1, 4, 5]]).all()
     assert np.abs(g[[0, 1, 4, 5]] - g64[[0, 1, 4, 5]]).max() < TOL * np.abs(g64[[0, 1, 4, 5]]).max()
+
+
+def test_sample_pose_project_with_body_model(smpl_like):
+    """experiments/sample_poses.py:57-83 mirrored: project random poses (one persistent launch) and mesh them before / after."""
+    from posendf_amd import PoseNDF, amass_config
+    from posendf_amd.sample_poses import SamplePose, quaternion_to_axis_angle, random_poses
+    m, bm = smpl_like
+    sd = golden_weights("live")
+    net = PoseNDF(amass_config("lrelu", "cuda:0"))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    q0 = random_poses(10, "cuda:0", torch.Generator().manual_seed(3))
+    poses, dist, meshes = SamplePose(net, body_model=bm).project(q0, steps=10)
+    want, dwant = net.project(q0, steps=10)
+    assert torch.equal(poses, want) and torch.equal(dist, dwant)
+    assert meshes["vertices"].shape == (10, 6890, 3) and meshes["vertices_init"].shape == (10, 6890, 3)
+    aa = torch.zeros(10, 23, 3)
+    aa[:, :21] = quaternion_to_axis_angle(poses.cpu())
+    V64, _ = lbs_np.lbs(aa.reshape(10, 69).numpy(), m)
+    assert _rel(meshes["vertices"].cpu().numpy(), V64) < 1e-5
+    assert dist.mean() < net(q0, train=False)["dist_pred"].mean()

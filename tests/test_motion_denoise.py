@@ -340,3 +340,17 @@ def test_fused_partial_observation_schedule_matches_oracle(precision):
     auto, _ = md.optimize(noisy, iterations=2, steps_per_iter=4, record=False)
     d2 = (auto - got).abs().flatten()
     assert d2.median().item() < 1e-5 and (d2 > 1e-3).float().mean().item() < 0.01
+
+
+def test_quaternion_to_axis_angle_inverts_axis_angle_to_quaternion():
+    from posendf_amd.motion_denoise import axis_angle_to_quaternion
+    from posendf_amd.sample_poses import quaternion_to_axis_angle
+    g = torch.Generator().manual_seed(0)
+    aa = torch.randn(200, 3, dtype=torch.float64, generator=g)
+    aa = aa / aa.norm(dim=-1, keepdim=True) * (torch.rand(200, 1, dtype=torch.float64, generator=g) * 3.0)      # angles < pi
+    aa[0] = 0.0
+    aa[1] = torch.tensor([1e-9, 0.0, 0.0])
+    back = quaternion_to_axis_angle(axis_angle_to_quaternion(aa))
+    assert torch.allclose(back, aa, atol=1e-12)
+    assert torch.allclose(quaternion_to_axis_angle(torch.tensor([[0.0, 1.0, 0.0, 0.0]], dtype=torch.float64)),
+                          torch.tensor([[np.pi, 0.0, 0.0]], dtype=torch.float64))
