@@ -187,3 +187,36 @@ class MotionDenoise:
                     history.append({k: float(v.detach().mean()) for k, v in loss.items()})
         out = body_pose.detach()
         return (out[0] if single else out), history
+
+
+# ---- the script level of the reference (experiments/motion_denoise.py:108-121,124-153): motion files in, v2v error out
+def load_motion_npz(path, device="cuda:0"):
+    """`np.load(motion_file)['pose_body']` ([T,63] axis-angle of the 21 body joints) padded with the two (zero) hand joints
+    to the body model's [T,69] (motion_denoise.py:134-138)."""
+    import numpy as np
+    pose_body = np.load(path)["pose_body"].astype(np.float32)
+    if pose_body.ndim != 2 or pose_body.shape[1] not in (63, 69):
+        raise ValueError(f"{path}: pose_body must be [T,63] or [T,69], got {pose_body.shape}")
+    poses = torch.zeros((len(pose_body), 69), dtype=torch.float32)
+    poses[:, :pose_body.shape[1]] = torch.from_numpy(pose_body)
+    return poses.to(device)
+
+
+@torch.no_grad()
+def v2v_error_cm(body_model, poses, reference_poses):
+    """mean vertex-to-vertex distance in cm between the meshes of two pose sequences (motion_denoise.py:111,117-119)."""
+    v = body_model(pose_body=poses.reshape(-1, 69)).vertices
+    r = body_model(pose_body=reference_poses.reshape(-1, 69)).vertices
+    d = v - r
+    return float(torch.mean(torch.sqrt(torch.sum(d * d, dim=2))) * 100.0)
+
+
+def denoise_motion_file(posendf, body_model, motion_file, gt_file=None, device="cuda:0", iterations=10, steps_per_iter=50,
+                        fused=True, schedule="motion_denoise"):
+    """`main()` of experiments/motion_denoise.py:124-153 after the model is loaded: read the noisy motion, optimise it,
+    return (denoised poses [T,69], v2v error in cm against the ground truth if given, else against the noisy input)."""
+    noisy = load_motion_npz(motion_file, device)
+    md = MotionDenoise(posendf, body_model=body_model, device=device, schedule=schedule)
+    out, _ = md.optimize(noisy, iterations=iterations, steps_per_iter=steps_per_iter, record=False, fused=fused)
+    ref = load_motion_npz(gt_file, device) if gt_file is not None else noisy
+    return out, v2v_error_cm(body_model, out, ref)

@@ -183,3 +183,25 @@ def test_sample_pose_project_with_body_model(smpl_like):
     V64, _ = lbs_np.lbs(aa.reshape(10, 69).numpy(), m)
     assert _rel(meshes["vertices"].cpu().numpy(), V64) < 1e-5
     assert dist.mean() < net(q0, train=False)["dist_pred"].mean()
+
+
+def test_denoise_motion_file_script_level(smpl_like, tmp_path):
+    """experiments/motion_denoise.py:124-153 mirrored: noisy motion .npz in, denoised poses and the v2v error (cm) out."""
+    from posendf_amd import PoseNDF, amass_config
+    from posendf_amd.motion_denoise import denoise_motion_file, load_motion_npz, v2v_error_cm
+    m, bm = smpl_like
+    net = PoseNDF(amass_config("lrelu", "cuda:0"))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in golden_weights("live").items()})
+    gt = _theta(1, 24, seed=31)[0] * 0.5
+    gt[:, 63:] = 0
+    noisy = gt.copy()
+    noisy[:, :63] += np.random.default_rng(5).normal(size=(24, 63)).astype(np.float32) * 0.05
+    np.savez(tmp_path / "noisy.npz", pose_body=noisy[:, :63])
+    np.savez(tmp_path / "gt.npz", pose_body=gt[:, :63])
+    out, err = denoise_motion_file(net, bm, tmp_path / "noisy.npz", gt_file=tmp_path / "gt.npz", iterations=2, steps_per_iter=3)
+    assert out.shape == (24, 69) and torch.isfinite(out).all() and np.isfinite(err) and err > 0
+    V64, _ = lbs_np.lbs(out.cpu().numpy(), m)
+    G64, _ = lbs_np.lbs(gt, m)
+    want = np.sqrt(((V64 - G64) ** 2).sum(-1)).mean() * 100.0
+    assert abs(err - want) < 1e-3 * want
+    assert abs(v2v_error_cm(bm, load_motion_npz(tmp_path / "gt.npz"), load_motion_npz(tmp_path / "gt.npz"))) < 1e-6

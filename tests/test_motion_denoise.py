@@ -354,3 +354,14 @@ def test_quaternion_to_axis_angle_inverts_axis_angle_to_quaternion():
     assert torch.allclose(back, aa, atol=1e-12)
     assert torch.allclose(quaternion_to_axis_angle(torch.tensor([[0.0, 1.0, 0.0, 0.0]], dtype=torch.float64)),
                           torch.tensor([[np.pi, 0.0, 0.0]], dtype=torch.float64))
+
+
+def test_load_motion_npz_pads_hand_joints(tmp_path):
+    from posendf_amd.motion_denoise import load_motion_npz
+    body = np.random.default_rng(0).normal(size=(9, 63)).astype(np.float32)
+    np.savez(tmp_path / "m.npz", pose_body=body)
+    th = load_motion_npz(tmp_path / "m.npz", device="cpu")
+    assert th.shape == (9, 69) and torch.equal(th[:, :63], torch.from_numpy(body)) and (th[:, 63:] == 0).all()
+    np.savez(tmp_path / "bad.npz", pose_body=body[:, :60])
+    with pytest.raises(ValueError):
+        load_motion_npz(tmp_path / "bad.npz", device="cpu")
