@@ -182,6 +182,13 @@ int pndf_lbs_create(pndf_lbs_handle* out, int32_t V, int32_t NB, const float* v_
                     const float* betas, const float* posedirs, const float* J_regressor, const int32_t* parents,
                     const float* lbs_weights, const int32_t* extra_joint_vertex, int32_t n_extra, int device);
 int pndf_lbs_destroy(pndf_lbs_handle h);
+/* Arithmetic of the forward and fused-terms passes.  PNDF_LBS_F16X3 (default): the vertex-side contractions on fp16 MFMAs
+ * with every fp32 operand split into fp16 hi + lo (three products per block, fp32 accumulate) -- the arithmetic of the
+ * distance engine's f16x3 kernels, fp32-class accuracy; PNDF_LBS_FP32: the same on fp32 MFMAs (exact fp32 products).  The
+ * general reverse pass (pndf_lbs_backward) always runs on fp32.  Returns 0 or a negative pndf_status. */
+enum { PNDF_LBS_FP32 = 0, PNDF_LBS_F16X3 = 1 };
+int pndf_lbs_set_precision(pndf_lbs_handle h, int32_t precision);
+int32_t pndf_lbs_precision(pndf_lbs_handle h);         /* -1 for a NULL handle */
 int32_t pndf_lbs_num_joints(pndf_lbs_handle h);        /* 24 + n_extra */
 int32_t pndf_lbs_num_vertices(pndf_lbs_handle h);
 int64_t pndf_lbs_workspace_floats(pndf_lbs_handle h, int32_t S, int32_t T);

@@ -8,6 +8,10 @@ The reference builds `smplx.SMPL(bm_path)` from the licensed SMPL model file.  N
 here, so the model PARAMETERS are supplied by the caller as arrays with the shapes of the SMPL file (`from_arrays`, or
 `from_npz` for a converted model file); the algorithm is smplx's published lbs() restated -- parity unpinned.
 
+`precision` selects the arithmetic of the forward and fused-terms passes: "f16x3" (default; fp16 MFMAs on operands split
+into hi + lo halves, fp32 accumulate: the distance engine's split arithmetic, fp32-class accuracy) or "fp32" (fp32 MFMAs);
+the general reverse pass behind autograd always runs on fp32.
+
 `forward` is differentiable with respect to `pose_body` (first order, through `pndf_lbs_backward`); the betas and the global
 orientation are constants, as in the reference's optimisation (motion_denoise.py:27,67; root_orient=None).  There is no CPU
 or eager fallback: without the library or a gfx950 device the constructor raises.
@@ -65,8 +69,10 @@ class _Lbs(torch.autograd.Function):
 
 
 class BodyModel(torch.nn.Module):
+    PRECISIONS = {"fp32": 0, "f16x3": 1}      # PNDF_LBS_FP32 / PNDF_LBS_F16X3 (include/posendf_amd.h)
+
     def __init__(self, params, num_betas=10, batch_size=1, model_type="smpl", device="cuda:0", betas=None,
-                 extra_joint_vertex=None, faces=None):
+                 extra_joint_vertex=None, faces=None, precision="f16x3"):
         super().__init__()
         if model_type != "smpl":
             raise PndfError("only model_type='smpl' (24 joints, 23 x 9 pose feature) is implemented")
@@ -105,6 +111,10 @@ class BodyModel(torch.nn.Module):
             msg = self.lib.pndf_lbs_last_error(None).decode()
             self.handle = None
             raise PndfError(f"pndf_lbs_create failed ({rc}): {msg}")
+        if precision not in self.PRECISIONS:
+            raise PndfError(f"precision must be one of {sorted(self.PRECISIONS)}")
+        self._call("pndf_lbs_set_precision", self.PRECISIONS[precision])
+        self.precision = precision
         self.num_vertices = V
         self.num_joints = 24 + len(ex)
         self.faces_tensor = None if faces is None else torch.as_tensor(np.asarray(faces, dtype=np.int64), device=self.device)

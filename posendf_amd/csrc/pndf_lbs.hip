@@ -36,11 +36,14 @@
 
 #include <cmath>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/posendf_amd.h"
 #include "pndf_args.h"
 #include "pndf_host.h"
+#include "pndf_lbs_split.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -476,15 +479,613 @@ extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_backward_kernel(P
     }
 }
 
+// ====================================================================================== split precision
+// The same three stages with the two vertex-side contractions on v_mfma_f32_16x16x32_f16 (16 cycles for 16 x 16 x 32 MACs
+// against 32 cycles for 16 x 16 x 4 on the fp32 pipe), every fp32 operand carried as fp16 hi + fp16 lo and every product
+// as hi hi + hi lo + lo hi with fp32 accumulation (dropped lo lo term: 2^-22 relative) -- the arithmetic of the distance
+// engine's f16x3 kernels (pndf_kernel_split.hip).  Operands are scaled by powers of two so that they sit high in the fp16
+// range without leaving it: the model's by the packer (p_scale, w_scale from the largest |entry|), the pose feature by 2^12
+// (|R - I| <= 2), the joint transforms by a_scale (from the skeleton's extent), the reverse operands by g_scale / x_scale
+// from a-priori bounds the host derives from the term weights (|d L / d verts| <= 2 w_temp + w_data) and the model.
+// Per (16 vertex x 16 frame) tile: 63 + 36 MFMAs forward, 65 + 48 reverse = 3,392 matrix-pipe cycles against 15,360.
+//   * ONE copy of the model in LDS serves both contractions (pndf_lbs_split.h): planes [row][16 v] of halfs; the reverse
+//     pass (contraction over vertices) reads 4 v of a row per lane, the forward pass (contraction over rows) gets its
+//     operand -- one vertex per lane, four consecutive rows -- from ds_read_b64_tr_b16.
+//   * reverse k-blocks: a tile has 16 vertices, a k-block 32 slots.  d L / d pose_feature contracts (component, vertex):
+//     components 0, 1 fill one k-block (three MFMAs), component 2 half a k-block -- its other half carries the LO half of
+//     the gradient against the same (duplicated) weights, so hi hi + hi lo is ONE MFMA and lo hi the second.  The same
+//     trick serves d L / d A (contraction over the 16 vertices only): two MFMAs per (entry, joint tile).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int KB = PNDF_LBS_KB, SBB = PNDF_LBS_SB_BYTES, PLANE = PNDF_LBS_SB_PLANE;
+#ifndef PNDF_LBS_DIAG
+#define PNDF_LBS_DIAG 0     // timing diagnostics (WRONG results): 1 = no wait for the model fetch, 2 = no fetch, 4 = no barrier,
+#endif                      // 64 = no reverse MFMAs
+#ifndef PNDF_LBS_FLA
+#define PNDF_LBS_FLA 2      // forward steps / reverse row tiles whose LDS reads are in flight ahead of the MFMAs that use them
+#endif
+#ifndef PNDF_LBS_RLA
+#define PNDF_LBS_RLA 1
+#endif
+
+__device__ __forceinline__ f32x4 mf16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// (a, b) -> packed fp16 pairs: hi = rtz(a, b), lo = rne(a - hi_a, b - hi_b); the remainders are exact in fp32
+__device__ __forceinline__ void lbs_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+    hi = hp;
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hp), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hp), "v"(b));
+    f16x2 l;
+    l[0] = (_Float16)ra;
+    l[1] = (_Float16)rb;
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void lbs_split4(const f32x4& v, f16x4& hi, f16x4& lo) {
+    unsigned h0, l0, h1, l1;
+    lbs_split2(v[0], v[1], h0, l0);
+    lbs_split2(v[2], v[3], h1, l1);
+    hi = __builtin_bit_cast(f16x4, u32x2{h0, h1});
+    lo = __builtin_bit_cast(f16x4, u32x2{l0, l1});
+}
+__device__ __forceinline__ f16x8 cat(f16x4 a, f16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): an unrolled loop whose index is a constant by construction
+// (`#pragma unroll` leaves the 99-trip loop over the forward MFMAs rolled, with its index arithmetic at run time)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// ds_read_b64_tr_b16: within a 16-lane row, lane i element j <- element i % 4 of the 8 bytes addressed by lane 4 j + i / 4
+// (profiles/r02/tr_b16_probe.txt).  With lane m of row g pointing at plane row 4 g + m / 4, halfs 4 (m % 4) .. + 3, lane i
+// receives vertex i of rows 4 g .. 4 g + 3.
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ f16x4 lds_tr(const char* p) {
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p));
+}
+// One ds_read_b64 per row read, through LDS pointers whose lane offset is opaque to the compiler (one base register per
+// plane).  (hipcc still pairs the reads of two tiles off one base into ds_read2st64_b64, served in 16-lane groups over 32
+// banks at 128 B / clk: the tile layout of pndf_lbs_split.h is free of bank conflicts for that form.)
+typedef __attribute__((address_space(3))) const char lds_char;
+typedef __attribute__((address_space(3))) const f16x4 lds_f16x4;
+__device__ __forceinline__ lds_char* lds_opaque(lds_char* p) {
+    unsigned v = (unsigned)(size_t)p;
+    asm volatile("" : "+v"(v));
+    return (lds_char*)(size_t)v;
+}
+__device__ __forceinline__ f16x4 lds_row(lds_char* p) { return *(lds_f16x4*)p; }
+
+}  // namespace
+
+// ------------------------------------------------------------------ per-frame forward, split operands out
+extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_split_kernel(PndfLbsSplitArgs sa) {
+    const PndfLbsArgs& a = sa.base;
+    const long long n = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (n >= (long long)a.S * a.T) return;
+    float R[NJ][9], GR[NJ][9], Gt[NJ][3];
+    frame_transforms(a.theta + n * 69, a.model, R, GR, Gt);
+    // pose feature x 2^12, hi / lo, in B-operand order: element i of k-block kb in lane group g = entry 32 kb + 16 (i / 4) + 4 g + i % 4
+    float pf[PNDF_LBS_KP];
+    for (int k = 0; k < PNDF_LBS_KP; ++k)
+        pf[k] = (k < 9 * (NJ - 1)) ? (R[1 + k / 9][k % 9] - (((k % 9) % 4 == 0) ? 1.0f : 0.0f)) * PNDF_LBS_PF_SCALE : 0.f;
+    u32x4* dpf = (u32x4*)sa.pfs + n * (4 * KB * 2);
+    for (int g = 0; g < 4; ++g)
+        for (int kb = 0; kb < KB; ++kb) {
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k0 = kb * 32 + 16 * (q / 2) + 4 * g + 2 * (q % 2);
+                lbs_split2(pf[k0], pf[k0 + 1], h[q], l[q]);
+            }
+            dpf[(g * KB + kb) * 2] = u32x4{h[0], h[1], h[2], h[3]};
+            dpf[(g * KB + kb) * 2 + 1] = u32x4{l[0], l[1], l[2], l[3]};
+        }
+    // A_j = [G_R | G_t - G_R J_j] x a_scale: element i of entry e in lane group g = joint 16 (i / 4) + 4 g + i % 4
+    float Av[12][32];
+    for (int j = 0; j < 32; ++j)
+#pragma unroll
+        for (int e = 0; e < 12; ++e) Av[e][j] = 0.f;
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Av[e][j] = GR[j][e] * sa.a_scale;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            Av[9 + e][j] = (Gt[j][e] - (GR[j][3 * e] * a.model.J[j][0] + GR[j][3 * e + 1] * a.model.J[j][1] +
+                                        GR[j][3 * e + 2] * a.model.J[j][2])) * sa.a_scale;
+    }
+    u32x4* dA = (u32x4*)sa.Aps + n * (4 * 12 * 2);
+    for (int g = 0; g < 4; ++g)
+        for (int e = 0; e < 12; ++e) {
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j0 = 16 * (q / 2) + 4 * g + 2 * (q % 2);
+                lbs_split2(Av[e][j0], Av[e][j0 + 1], h[q], l[q]);
+            }
+            dA[(g * 12 + e) * 2] = u32x4{h[0], h[1], h[2], h[3]};
+            dA[(g * 12 + e) * 2 + 1] = u32x4{l[0], l[1], l[2], l[3]};
+        }
+    const int njt = NJ + a.NE;
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            if (a.Gt) a.Gt[n * (NJ * 3) + 3 * j + e] = Gt[j][e];
+            if (a.joints) a.joints[(n * njt + j) * 3 + e] = Gt[j][e];
+        }
+}
+
+// ------------------------------------------------------------------ per (16 vertices x 16 frames) tile, split precision
+template <int MODE>      // 0: vertices / vertex-picked joints out   1: the two fused terms and their reverse pass
+__device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa) {
+    static_assert(MODE == 0 || MODE == 1, "the general reverse pass (arbitrary d L / d verts: no a-priori bound) stays on fp32");
+    const PndfLbsArgs& a = sa.base;
+    extern __shared__ __attribute__((aligned(16))) char smem_s[];      // 3 x SBB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, p = lane & 15;
+    constexpr int STRIDE = (MODE == 1) ? 15 : 16;
+    const int T = a.T, cps = a.cps, nch = a.S * cps, njt = NJ + a.NE;
+    // 1-D grid, vertex range fastest (workgroup i runs on XCD i % 8: with a split of 8 every XCD streams one eighth of the model)
+    const int vs = (int)(blockIdx.x % (unsigned)a.vsplit);
+    int cid = (int)(blockIdx.x / (unsigned)a.vsplit) * 4 + wave;
+    const bool wave_on = cid < nch;
+    if (!wave_on) cid = nch - 1;
+    const int s = cid / cps, c = cid - s * cps, f0 = c * STRIDE;
+    const int t = f0 + p;
+    const bool t_ok = wave_on && t < T;
+    const long long n = (long long)s * T + (t < T ? t : T - 1);
+    const bool owned = t_ok && (MODE != 1 || p < 15 || t == T - 1);
+    const bool pair_ok = MODE == 1 && t_ok && p < 15 && t + 1 < T;
+    const long long N = (long long)a.S * T;
+
+    // ---- B operands of this wave's 16 frames
+    f16x8 pfh[KB], pfl[KB], Ah[12], Al[12];
+    {
+        const f16x8* src = (const f16x8*)sa.pfs + ((size_t)n * 4 + g) * (KB * 2);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            pfh[kb] = src[2 * kb];
+            pfl[kb] = src[2 * kb + 1];
+        }
+        const f16x8* srcA = (const f16x8*)sa.Aps + ((size_t)n * 4 + g) * 24;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            Ah[e] = srcA[2 * e];
+            Al[e] = srcA[2 * e + 1];
+        }
+        // make hipcc wait for these loads HERE: left to the first use, its vmcnt(N) waits sit inside the group loop, where they
+        // also count the model fetch (inline asm, invisible to it) and stall on it
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) asm volatile("" : : "v"(pfh[kb]), "v"(pfl[kb]));
+#pragma unroll
+        for (int e = 0; e < 12; ++e) asm volatile("" : : "v"(Ah[e]), "v"(Al[e]));
+    }
+    f32x4 gpf[KT], gA[12][2];
+    if constexpr (MODE != 0) {
+#pragma unroll
+        for (int i = 0; i < KT; ++i) gpf[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 12; ++i) gA[i][0] = gA[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int grp0 = (int)((long long)a.NG * vs / a.vsplit), grp1 = (int)((long long)a.NG * (vs + 1) / a.vsplit);
+    const int lane_tr = 8 * pndf_lbs_sb_unit(4 * g + (p >> 2), p & 3);      // transposed reads: tile row 4 g + p / 4, vertex quad p % 4
+    const int lane_rv = 8 * pndf_lbs_sb_unit(p, g);                         // row reads: tile row p, vertex quad g
+    // One wave per SIMD, in-order issue.  Two rules shape a group (tools/ubench/mfma_valu_overlap.hip, profiles/r03):
+    //   * an MFMA takes 4 cycles of issue and 16 of the matrix pipe; the ~3 instructions that sit DIRECTLY behind it in
+    //     program order run in its shadow, anything behind a second MFMA does not (the wave stalls at that MFMA until the
+    //     pipe is free): 12 MFMAs + 24 VALU instructions take 105 ns one-behind-one, 133 ns as MMM vvvvvv, 141 ns as blocks;
+    //   * LDS latency is hidden only by reads issued ahead in program order.
+    // Left alone hipcc does neither (tile reads right in front of their use, the VALU section as a block), so a group is laid
+    // out by hand, one MFMA at a time, pinned with sched_barriers -- the method of the distance engine's chunk epilogues
+    // (pndf_kernel_split.hip).  Behind every MFMA: at most two tile reads for a later MFMA, one piece of the model fetch
+    // (global_load_lds, the first MFMAs of the forward pass only: issued as a burst the 45 pieces stall all four waves for
+    // ~0.6 us per group), and a piece of two to four VALU instructions:
+    //   forward pass of group grp + 1 (63 + 36 MFMAs) <- the VALU section of group grp (v_posed, V, the temporal term);
+    //   reverse pass of group grp: d L / d A (48 MFMAs) <- the operand split of the next entry and T_R^T g; d L / d
+    //   pose_feature (65 MFMAs, from entry 6 on two row tiles behind every entry) <- row reads RLA tiles ahead and the hand-over
+    //   of the next group's accumulators.
+    struct PTile { f16x4 h0, h1, l0, l1; };
+    struct RTile { f16x4 c0h, c1h, c2h, c0l, c1l, c2l; };
+    constexpr int FSTEPS = 3 * KB, FMFMA = 3 * FSTEPS + 36, FLA = PNDF_LBS_FLA, RLA = PNDF_LBS_RLA;
+    constexpr int NP1 = (MODE == 0) ? 22 : 47;      // pieces of the VALU section
+    struct GState {
+        i32x4 fl;
+        f32x4 vs[3], vp[3], V[3], d[3], n2, inv, u[3], gV[3];
+    };
+    // model fetch: piece j (0 .. 11) of this wave -- KiB wave + 4 j of the 45 of blob `grp` -- into buffer `buf`; the twelfth
+    // piece exists for wave 0 only (KiB 44): the other waves fetch it as well (same bytes) rather than branch
+    constexpr int DMA_PIECES = (SBB / 1024 + 3) / 4;
+    static_assert(SBB / 1024 == 45 && DMA_PIECES == 12, "pieces of the model fetch");
+    // (inline asm, as in the distance engine: when hipcc sees the builtin it waits for the fetch -- vmcnt(0) -- in front of
+    // the next LDS read, whatever buffer that reads; the explicit wait at the top of a group is what orders fetch and use)
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_char*)smem_s);
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    auto dma_piece = [&](int grp, int buf, int j) __attribute__((always_inline)) {
+        const int kib = (j < DMA_PIECES - 1) ? wave + 4 * j : SBB / 1024 - 1;
+        const char* src = (const char*)sa.sblob + (size_t)grp * SBB + (size_t)kib * 1024;
+        const uint32_t dst = lds_base + (uint32_t)(buf * SBB + kib * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane16), "s"(src), "s"(dst) : "memory", "m0");
+    };
+    // half h (0: hi tiles, 1: lo tiles) of the operand of forward step `st` (k-block st / 3, component st % 3; st == FSTEPS: W)
+    auto fwd_ld = [&](const char* B, int st, int h, PTile& t) __attribute__((always_inline)) {
+        const char* q = (st < FSTEPS) ? B + (st % 3) * PLANE + (st / 3) * 1024 + lane_tr + (h ? PNDF_LBS_SB_PL : PNDF_LBS_SB_PH)
+                                      : B + lane_tr + (h ? PNDF_LBS_SB_WL : PNDF_LBS_SB_WH);
+        if (h == 0) { t.h0 = lds_tr(q); t.h1 = lds_tr(q + 512); }
+        else { t.l0 = lds_tr(q); t.l1 = lds_tr(q + 512); }
+    };
+    // forward MFMA m (0 .. FMFMA - 1): three per step, pose blend shapes first, then the 12 skinning-transform entries
+    auto fwd_mfma = [&](int m, const PTile (&tl)[FLA + 1], f32x4 (&off)[3], f32x4 (&Tm)[12]) __attribute__((always_inline)) {
+        const int st = m / 3, j = m % 3;
+        const PTile& tc = tl[(st < FSTEPS ? st : FSTEPS) % (FLA + 1)];
+        const f16x8 A = (j == 2) ? cat(tc.l0, tc.l1) : cat(tc.h0, tc.h1);
+        if (st < FSTEPS) {
+            const int c3 = st % 3, kb = st / 3;
+            off[c3] = mf16(A, (j == 1) ? pfl[kb] : pfh[kb], (kb == 0 && j == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : off[c3]);
+        } else {
+            const int e = st - FSTEPS;
+            Tm[e] = mf16(A, (j == 1) ? Al[e] : Ah[e], (j == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : Tm[e]);
+        }
+    };
+    // the tile reads that ride behind forward MFMA m: behind the first two MFMAs of a step, the halves of step st + FLA
+    auto fwd_reads = [&](const char* B, int m, PTile (&tl)[FLA + 1]) __attribute__((always_inline)) {
+        const int st = m / 3, j = m % 3;
+        if (j < 2 && st + FLA <= FSTEPS) fwd_ld(B, st + FLA, j, tl[(st + FLA) % (FLA + 1)]);
+    };
+    auto forward_all = [&](const char* B, f32x4 (&off)[3], f32x4 (&Tm)[12]) __attribute__((always_inline)) {      // (first group of a wave)
+        PTile tl[FLA + 1];
+#pragma unroll
+        for (int st = 0; st < FLA; ++st) { fwd_ld(B, st, 0, tl[st]); fwd_ld(B, st, 1, tl[st]); }
+        static_for<FMFMA>([&](auto mc) __attribute__((always_inline)) {
+            constexpr int m = decltype(mc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            fwd_mfma(m, tl, off, Tm);
+            __builtin_amdgcn_sched_barrier(0);
+            fwd_reads(B, m, tl);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // piece i of the VALU section: accumulators of the forward pass -> v_posed, V and (MODE 1) d L / d V of the temporal term
+    // (true scale; the arithmetic of the fp32 kernel).  No epsilon under the root, as in the reference (motion_denoise.py:89):
+    // two identical consecutive vertices give NaN there and here.
+    auto valu_piece = [&](int i, GState& q, const char* B, const f32x4 (&off)[3], const f32x4 (&Tm)[12]) __attribute__((always_inline)) {
+        if (i == 0) {
+            q.fl = *(const i32x4*)(B + PNDF_LBS_SB_FL + 16 * g);
+        } else if (i <= 3) {
+            q.vs[i - 1] = *(const f32x4*)(B + PNDF_LBS_SB_VS + (i - 1) * (GV * 4) + 16 * g);
+        } else if (i <= 6) {
+            q.vp[i - 4] = q.vs[i - 4] + off[i - 4] * sa.off_true;
+        } else if (i <= 21) {
+            const int a3 = (i - 7) / 5, sub = (i - 7) % 5;
+            if (sub == 0) q.V[a3] = Tm[3 * a3] * q.vp[0];
+            else if (sub <= 2) q.V[a3] = q.V[a3] + Tm[3 * a3 + sub] * q.vp[sub];
+            else if (sub == 3) q.V[a3] = q.V[a3] + Tm[9 + a3];
+            else q.V[a3] = q.V[a3] * sa.tm_true;
+        } else if (i <= 27) {
+            const int a3 = (i - 22) / 2, r0 = 2 * ((i - 22) % 2);
+#pragma unroll
+            for (int r = r0; r < r0 + 2; ++r) q.d[a3][r] = q.V[a3][r] - next_frame(q.V[a3][r]);      // frame p + 1: the next lane of the row
+        } else if (i <= 30) {
+            const int a3 = i - 28;
+            q.n2 = (a3 == 0) ? q.d[0] * q.d[0] : q.n2 + q.d[a3] * q.d[a3];
+        } else if (i <= 34) {
+            const int r = i - 31;
+            q.inv[r] = a.w_temp * __builtin_amdgcn_rsqf(q.n2[r]);      // 0 -> inf -> 0 * inf = NaN, as d / sqrt(0)
+        } else if (i <= 40) {
+            const int a3 = (i - 35) / 2, r0 = 2 * ((i - 35) % 2);
+#pragma unroll
+            for (int r = r0; r < r0 + 2; ++r) q.u[a3][r] = (pair_ok && q.fl[r] != -2) ? q.d[a3][r] * q.inv[r] : 0.f;
+        } else if (i <= 46) {
+            const int a3 = (i - 41) / 2, r0 = 2 * ((i - 41) % 2);
+#pragma unroll
+            for (int r = r0; r < r0 + 2; ++r) q.gV[a3][r] = q.u[a3][r] - prev_frame(q.u[a3][r]);      // lane 0: no pair inside this chunk
+        }
+    };
+    struct RBase { lds_char *c0h, *c1h, *c2h, *c0l, *c1l, *c2l, *wh, *wl; };      // row-read bases of a group, one register each
+    auto rev_base = [&](const char* B) __attribute__((always_inline)) {
+        lds_char* q = (lds_char*)B + lane_rv;
+        return RBase{lds_opaque(q + PNDF_LBS_SB_PH), lds_opaque(q + PNDF_LBS_SB_PH + PLANE), lds_opaque(q + PNDF_LBS_SB_PH + 2 * PLANE),
+                     lds_opaque(q + PNDF_LBS_SB_PL), lds_opaque(q + PNDF_LBS_SB_PL + PLANE), lds_opaque(q + PNDF_LBS_SB_PL + 2 * PLANE),
+                     lds_opaque(q + PNDF_LBS_SB_WH), lds_opaque(q + PNDF_LBS_SB_WL)};
+    };
+    // row read `w` (0 .. 5) of row tile kt
+    auto rev_ld = [&](const RBase& rb, int kt, int w, RTile& t) __attribute__((always_inline)) {
+        if (w == 0) t.c0h = lds_row(rb.c0h + kt * 512);
+        else if (w == 1) t.c1h = lds_row(rb.c1h + kt * 512);
+        else if (w == 2) t.c0l = lds_row(rb.c0l + kt * 512);
+        else if (w == 3) t.c1l = lds_row(rb.c1l + kt * 512);
+        else if (w == 4) t.c2h = lds_row(rb.c2h + kt * 512);
+        else t.c2l = lds_row(rb.c2l + kt * 512);
+    };
+
+    // One group.  HAS_NEXT: the forward pass of group grp + 1 runs through the VALU section of group grp -- the pose-blend
+    // MFMAs accumulate into off_n while `off` is still read, the skinning MFMAs come last and write Tm IN PLACE: by then every
+    // reader of this group's Tm (V, T_R^T g) is done.  The last group of a wave is its own instantiation (no branch around
+    // the forward pass in the loop body); FETCH: blob grp + 2 exists and is fetched here.
+    //   part 1a  forward MFMAs 0 .. 46  <- VALU pieces 0 .. 46 (v_posed, V, temporal term)
+    //   (rare branch: data term on the vertex-picked joints)
+    //   part 1b  forward MFMAs 47 .. 98 <- the 15 pieces of g_scale x T_R^T gV behind the first of them; skinning MFMAs bare
+    //   part 2   per entry e of d L / d A: four MFMAs <- the operand split of entry e + 1; one row tile of d L / d pose_feature
+    //            (five MFMAs) <- its row reads RLA tiles ahead; the thirteenth tile at the end
+    constexpr int NG1 = (MODE == 0) ? 0 : 15, M1A = (MODE == 0) ? FMFMA : NP1;
+    static_assert(NP1 + NG1 <= 3 * FSTEPS, "all readers of Tm sit behind pose-blend MFMAs, in front of the skinning MFMAs");
+    auto group = [&](auto has_next, auto has_fetch, int grp, f32x4 (&off)[3], f32x4 (&Tm)[12], f32x4 (&off_n)[3]) __attribute__((always_inline)) {
+        constexpr bool HAS_NEXT = decltype(has_next)::value;
+        constexpr bool FETCH = decltype(has_fetch)::value && !(PNDF_LBS_DIAG & 2);
+        const int k = grp - grp0;
+        const char* B = smem_s + (k % 3) * SBB;
+        const char* Bn = smem_s + ((k + 1) % 3) * SBB;
+        GState q;
+        PTile tl[FLA + 1];
+        f32x4 gt[3];
+        f16x4 gh[3], gl[3];
+        const float cgu = sa.tm_true * sa.g_scale;      // T_R = tm_true Tm; operand scale of d L / d v_posed
+        // g_scale x T_R^T gV, component b = i / 5: three products, two splits
+        auto g_piece = [&](int i) __attribute__((always_inline)) {
+            const int b = i / 5, pc = i % 5;
+            unsigned h, l;
+            if (pc == 0) gt[b] = Tm[b] * q.gV[0];
+            else if (pc == 1) gt[b] = gt[b] + Tm[3 + b] * q.gV[1];
+            else if (pc == 2) gt[b] = (gt[b] + Tm[6 + b] * q.gV[2]) * cgu;
+            else {
+                const int r0 = 2 * (pc - 3);
+                lbs_split2(gt[b][r0], gt[b][r0 + 1], h, l);
+                gh[b][r0] = __builtin_bit_cast(f16x2, h)[0]; gh[b][r0 + 1] = __builtin_bit_cast(f16x2, h)[1];
+                gl[b][r0] = __builtin_bit_cast(f16x2, l)[0]; gl[b][r0 + 1] = __builtin_bit_cast(f16x2, l)[1];
+            }
+        };
+        // forward MFMA m with what rides behind it
+        auto fwd_slot = [&](auto mc) __attribute__((always_inline)) {
+            constexpr int m = decltype(mc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            fwd_mfma(m, tl, off_n, Tm);
+            __builtin_amdgcn_sched_barrier(0);
+            fwd_reads(Bn, m, tl);
+            if constexpr (FETCH && m % 4 == 1 && m / 4 < DMA_PIECES) dma_piece(grp + 2, (k + 2) % 3, m / 4);
+            if constexpr (m < NP1) valu_piece(m, q, B, off, Tm);
+            else if constexpr (m < NP1 + NG1) g_piece(m - NP1);
+        };
+        if constexpr (HAS_NEXT) {
+            if (!(PNDF_LBS_DIAG & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of blob grp + 1 have landed ...
+            if (!(PNDF_LBS_DIAG & 4)) __syncthreads();            // ... everyone's have, and everyone has left buffer (k + 2) % 3
+#pragma unroll
+            for (int st = 0; st < FLA; ++st) { fwd_ld(Bn, st, 0, tl[st]); fwd_ld(Bn, st, 1, tl[st]); }
+            static_for<M1A>([&](auto mc) __attribute__((always_inline)) { fwd_slot(mc); });
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            static_for<NP1>([&](auto ic) __attribute__((always_inline)) { valu_piece(decltype(ic)::value, q, B, off, Tm); });
+        }
+
+        if constexpr (MODE == 0) {
+            if (t_ok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int v = grp * GV + 4 * g + r;
+                    if (v < a.V) {
+                        if (a.verts) {
+                            float* dst = a.verts + ((size_t)n * a.V + v) * 3;
+                            dst[0] = q.V[0][r]; dst[1] = q.V[1][r]; dst[2] = q.V[2][r];
+                        }
+                        if (q.fl[r] >= 0 && a.joints) {
+                            float* dst = a.joints + ((size_t)n * njt + NJ + q.fl[r]) * 3;
+                            dst[0] = q.V[0][r]; dst[1] = q.V[1][r]; dst[2] = q.V[2][r];
+                        }
+                    }
+                }
+            }
+        } else {
+            // data term on the vertex-picked joints (the 24 chain joints: pndf_lbs_pose_backward_kernel): 21 of SMPL's 6,890
+            // vertices -- one rarely taken branch per group
+            if (a.it_gt0 && owned && (q.fl[0] >= 0 || q.fl[1] >= 0 || q.fl[2] >= 0 || q.fl[3] >= 0)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (q.fl[r] >= 0) {
+                        const float* j0 = a.joints0 + ((size_t)n * njt + NJ + q.fl[r]) * 3;
+                        const float dx = q.V[0][r] - j0[0], dy = q.V[1][r] - j0[1], dz = q.V[2][r] - j0[2];
+                        const float inv = a.w_data / sqrtf(dx * dx + dy * dy + dz * dz);
+                        q.gV[0][r] += dx * inv; q.gV[1][r] += dy * inv; q.gV[2][r] += dz * inv;
+                    }
+                }
+            }
+            if constexpr (HAS_NEXT) {
+                static_for<FMFMA - M1A>([&](auto mc) __attribute__((always_inline)) { fwd_slot(std::integral_constant<int, M1A + decltype(mc)::value>{}); });
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                static_for<NG1>([&](auto ic) __attribute__((always_inline)) { g_piece(decltype(ic)::value); });
+            }
+
+            // ---- reverse pass
+            const f16x4 zero4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            const RBase rb = rev_base(B);
+            RTile rt[RLA + 1];
+            f16x8 AWh[2], AWl[2];      // W^T: rows = joints; hi: the tile's 16 vertices twice (hi hi + hi lo in one k-block), lo: once
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const f16x4 wh = lds_row(rb.wh + jt * 512), wl = lds_row(rb.wl + jt * 512);
+                AWh[jt] = cat(wh, wh);
+                AWl[jt] = cat(wl, zero4);
+            }
+#pragma unroll
+            for (int kt = 0; kt < RLA; ++kt)
+#pragma unroll
+                for (int w = 0; w < 6; ++w) rev_ld(rb, kt, w, rt[kt]);
+            f32x4 X;
+            f16x4 xh, xl;
+            f16x8 Xe[2];
+            f32x4 (&gVs)[3] = q.gV;      // from here on x_scale x d L / d verts
+            // d L / d verts (x) [v_posed, 1], entry e, split: three pieces
+            auto x_piece = [&](int e, int pc) __attribute__((always_inline)) {
+                unsigned h, l;
+                if (pc == 0) {
+                    X = (e < 9) ? gVs[e / 3] * q.vp[e % 3] : gVs[e - 9];
+                } else {
+                    const int r0 = 2 * (pc - 1);
+                    lbs_split2(X[r0], X[r0 + 1], h, l);
+                    xh[r0] = __builtin_bit_cast(f16x2, h)[0]; xh[r0 + 1] = __builtin_bit_cast(f16x2, h)[1];
+                    xl[r0] = __builtin_bit_cast(f16x2, l)[0]; xl[r0 + 1] = __builtin_bit_cast(f16x2, l)[1];
+                    if (pc == 2) Xe[e & 1] = cat(xh, xl);
+                }
+            };
+            const f16x8 B0h = cat(gh[0], gh[1]), B0l = cat(gl[0], gl[1]), B1 = cat(gh[2], gl[2]);
+            // MFMA t (0 .. 4) of row tile kt of d L / d pose_feature; behind it, row reads of tile kt + RLA
+            auto gpf_mfma = [&](int kt, int t) __attribute__((always_inline)) {
+                const RTile& tc = rt[kt % (RLA + 1)];
+                __builtin_amdgcn_sched_barrier(0);
+                if (PNDF_LBS_DIAG & 64) asm volatile("" : : "v"(tc.c0h), "v"(tc.c1h), "v"(tc.c0l), "v"(tc.c1l), "v"(tc.c2h), "v"(tc.c2l));
+                else if (t == 0) gpf[kt] = mf16(cat(tc.c0h, tc.c1h), B0h, gpf[kt]);
+                else if (t == 1) gpf[kt] = mf16(cat(tc.c0h, tc.c1h), B0l, gpf[kt]);
+                else if (t == 2) gpf[kt] = mf16(cat(tc.c0l, tc.c1l), B0h, gpf[kt]);
+                else if (t == 3) gpf[kt] = mf16(cat(tc.c2h, tc.c2h), B1, gpf[kt]);       // hi hi + hi lo of component 2 in one k-block
+                else gpf[kt] = mf16(cat(tc.c2l, zero4), B1, gpf[kt]);
+                __builtin_amdgcn_sched_barrier(0);
+                // (the registers of tile kt + RLA are those of tile kt - 1: free since its last MFMA)
+                if (kt + RLA < KT) {
+                    rev_ld(rb, kt + RLA, t, rt[(kt + RLA) % (RLA + 1)]);
+                    if (t == 4) rev_ld(rb, kt + RLA, 5, rt[(kt + RLA) % (RLA + 1)]);
+                }
+            };
+#pragma unroll
+            for (int a3 = 0; a3 < 3; ++a3) gVs[a3] = gVs[a3] * sa.x_scale;
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) x_piece(0, pc);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+#pragma unroll
+                for (int jm = 0; jm < 4; ++jm) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (PNDF_LBS_DIAG & 64) asm volatile("" : : "v"(AWh[jm / 2]), "v"(AWl[jm / 2]), "v"(Xe[i & 1]));
+                    else gA[i][jm / 2] = mf16((jm % 2) ? AWl[jm / 2] : AWh[jm / 2], Xe[i & 1], gA[i][jm / 2]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (jm < 3 && i + 1 < 12) x_piece(i + 1, jm);
+                }
+#pragma unroll
+                for (int t = 0; t < 5; ++t) gpf_mfma(i, t);
+            }
+#pragma unroll
+            for (int t = 0; t < 5; ++t) gpf_mfma(KT - 1, t);
+            __builtin_amdgcn_sched_barrier(0);
+            static_assert(KT == 13, "row tiles of d L / d pose_feature: one per entry of d L / d A, one left over");
+        }
+        if constexpr (HAS_NEXT) {
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) off[c3] = off_n[c3];
+        }
+    };
+    f32x4 off[3], Tm[12], off_n[3];      // accumulators: p_scale 2^12 x pose-blend offset, w_scale a_scale x sum_j W[v, j] A_j
+    if (grp0 < grp1) {
+#pragma unroll
+        for (int j = 0; j < DMA_PIECES; ++j) dma_piece(grp0, 0, j);
+        if (grp0 + 1 < grp1) {
+#pragma unroll
+            for (int j = 0; j < DMA_PIECES; ++j) dma_piece(grp0 + 1, 1, j);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        forward_all(smem_s, off, Tm);
+    }
+    for (int grp = grp0; grp + 2 < grp1; ++grp) group(std::true_type{}, std::true_type{}, grp, off, Tm, off_n);
+    if (grp0 + 1 < grp1) group(std::true_type{}, std::false_type{}, grp1 - 2, off, Tm, off_n);
+    if (grp0 < grp1) group(std::false_type{}, std::false_type{}, grp1 - 1, off, Tm, off_n);
+    if constexpr (MODE != 0) {
+        if (t_ok) {
+            float* o_pf = owned ? a.gpf + ((size_t)vs * N + n) * PF : a.halo_pf + ((size_t)vs * nch + cid) * PF;
+            float* o_A = owned ? a.gA + ((size_t)vs * N + n) * A_FLOATS : a.halo_A + ((size_t)vs * nch + cid) * A_FLOATS;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) *(f32x4*)(o_pf + 16 * kt + 4 * g) = gpf[kt] * sa.gpf_true;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                *(f32x4*)(o_A + e * 32 + 4 * g) = gA[e][0] * sa.gA_true;
+                *(f32x4*)(o_A + e * 32 + 16 + 4 * g) = gA[e][1] * sa.gA_true;
+            }
+        }
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(256, 1) pndf_lbs_vertex_split_forward_kernel(PndfLbsSplitArgs a) { lbs_vertex_split_body<0>(a); }
+extern "C" __global__ void __launch_bounds__(256, 1) pndf_lbs_vertex_split_terms_kernel(PndfLbsSplitArgs a) { lbs_vertex_split_body<1>(a); }
+
 // ------------------------------------------------------------------------------------------ host: handle, packing, launches
 struct pndf_lbs_model {
     int device = 0;
     int V = 0, NG = 0, NE = 0;
     float* d_blob = nullptr;
+    void* d_sblob = nullptr;          // the model for the split-precision kernels (pndf_lbs_split.h)
+    int precision = PNDF_LBS_F16X3;   // forward and fused-terms passes; the general reverse pass is always fp32
+    float p_scale = 1.f, w_scale = 1.f, a_scale = 1.f;      // powers of two: model and joint-transform operands
+    float w_rowsum = 1.f;             // max_v sum_j |W[v, j]|                        (bounds |T_R^T g|)
+    float vp_bound = 1.f;             // max_v,c |v_shaped| + 2 sum_k |posedirs|      (bounds |v_posed|)
     PndfLbsModel consts;
     int sm_count = 256;
     std::string err;
 };
+
+// fp32 -> fp16 bits, round to nearest even (host side of the split: any hi + lo = x decomposition serves the kernels)
+static uint16_t f32_to_f16(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    x &= 0x7fffffffu;
+    if (x > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                          // >= 65520: inf
+    if (x < 0x38800000u) {                                                            // below 2^-14: subnormal, units of 2^-24
+        float af;
+        memcpy(&af, &x, 4);
+        return (uint16_t)(sign | (uint16_t)std::nearbyint((double)af * 16777216.0));
+    }
+    uint32_t h = (((x >> 23) - 112u) << 10) | ((x & 0x7fffffu) >> 13);
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;                           // (a carry runs into the exponent)
+    return (uint16_t)(sign | h);
+}
+static float f16_to_f32(uint16_t h) {
+    const int e = (h >> 10) & 31, m = h & 1023;
+    const float v = (e == 0) ? std::ldexp((float)m, -24) : std::ldexp((float)(m | 1024), e - 25);
+    return (h & 0x8000u) ? -v : v;
+}
+// power of two s with bound * s in [2^13, 2^14): the operand's hi half cannot overflow (65504), and values down to 2^-16 of
+// the bound keep a normal lo half.  Clamped: a zero bound must not turn into an infinite factor.
+static float lbs_scale_for(float bound) {
+    if (!(bound > 1e-30f)) bound = 1e-30f;
+    if (bound > 1e30f) bound = 1e30f;
+    return std::ldexp(1.0f, 13 - std::ilogb(bound));
+}
+
+// the split-precision model from the fp32 one (same [row][16 v] order inside a plane)
+static void lbs_pack_split(const float* blob, int NG, float p_scale, float w_scale, uint8_t* out) {
+    memset(out, 0, (size_t)NG * PNDF_LBS_SB_BYTES);
+    for (int grp = 0; grp < NG; ++grp) {
+        const float* b = blob + (size_t)grp * BLOB;
+        uint8_t* o = out + (size_t)grp * PNDF_LBS_SB_BYTES;
+        auto put = [&](int hi_off, int lo_off, int row, int vi, float x) {
+            const uint16_t h = f32_to_f16(x);
+            const uint16_t l = f32_to_f16(x - f16_to_f32(h));
+            memcpy(o + hi_off + pndf_lbs_sb_at(row, vi), &h, 2);
+            memcpy(o + lo_off + pndf_lbs_sb_at(row, vi), &l, 2);
+        };
+        for (int c = 0; c < 3; ++c)
+            for (int k = 0; k < PF; ++k)
+                for (int vi = 0; vi < GV; ++vi)
+                    put(PNDF_LBS_SB_PH + c * PNDF_LBS_SB_PLANE, PNDF_LBS_SB_PL + c * PNDF_LBS_SB_PLANE, k, vi,
+                        b[PNDF_LBS_BLOB_P + c * C_STRIDE + k * GV + vi] * p_scale);
+        for (int j = 0; j < 32; ++j)
+            for (int vi = 0; vi < GV; ++vi)
+                put(PNDF_LBS_SB_WH, PNDF_LBS_SB_WL, j, vi, b[PNDF_LBS_BLOB_W + j * GV + vi] * w_scale);
+        memcpy(o + PNDF_LBS_SB_VS, b + PNDF_LBS_BLOB_VS, 3 * GV * 4);
+        memcpy(o + PNDF_LBS_SB_FL, b + PNDF_LBS_BLOB_FL, GV * 4);
+    }
+}
 
 static thread_local std::string g_lbs_create_err;
 static int lbs_fail(pndf_lbs_model* h, int code, const std::string& msg) {
@@ -582,6 +1183,48 @@ extern "C" int pndf_lbs_create(pndf_lbs_handle* out, int32_t V, int32_t NB, cons
     for (int j = 0; j < NJ; ++j) h->consts.parent[j] = parents[j];
     hipError_t e = hipMalloc((void**)&h->d_blob, blob.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
+    {
+        // operand scales and bounds of the split-precision kernels, from the packed model
+        float maxP = 0.f, maxW = 0.f, rowsum = 0.f, vpb = 0.f;
+        for (int grp = 0; grp < NG; ++grp) {
+            const float* b = blob.data() + (size_t)grp * BLOB;
+            for (int vi = 0; vi < GV; ++vi) {
+                float ws = 0.f;
+                for (int j = 0; j < NJ; ++j) {
+                    const float w = std::fabs(b[PNDF_LBS_BLOB_W + j * GV + vi]);
+                    ws += w;
+                    maxW = std::fmax(maxW, w);
+                }
+                rowsum = std::fmax(rowsum, ws);
+                for (int c = 0; c < 3; ++c) {
+                    float ps = 0.f;
+                    for (int k = 0; k < PF; ++k) {
+                        const float pv = std::fabs(b[PNDF_LBS_BLOB_P + c * C_STRIDE + k * GV + vi]);
+                        ps += pv;
+                        maxP = std::fmax(maxP, pv);
+                    }
+                    vpb = std::fmax(vpb, std::fabs(b[PNDF_LBS_BLOB_VS + c * GV + vi]) + 2.0f * ps);      // |R - I| <= 2
+                }
+            }
+        }
+        float extent = 0.f, maxJ = 0.f;      // |G_t[j]| <= sum of the bone lengths, |A_t| <= |G_t| + |J|
+        for (int j = 0; j < NJ; ++j) {
+            extent += std::sqrt(rel[3 * j] * rel[3 * j] + rel[3 * j + 1] * rel[3 * j + 1] + rel[3 * j + 2] * rel[3 * j + 2]);
+            maxJ = std::fmax(maxJ, std::sqrt(J[3 * j] * J[3 * j] + J[3 * j + 1] * J[3 * j + 1] + J[3 * j + 2] * J[3 * j + 2]));
+        }
+        h->p_scale = lbs_scale_for(maxP) * 0.5f;      // [2^12, 2^13): headroom for hi + hi products is not needed, for rounding up is
+        h->w_scale = lbs_scale_for(maxW) * 0.5f;
+        h->a_scale = lbs_scale_for(std::fmax(1.0f, extent + maxJ)) * 0.5f;
+        h->w_rowsum = std::fmax(rowsum, 1e-6f);
+        h->vp_bound = std::fmax(vpb, 1.0f);
+        std::vector<uint8_t> sblob((size_t)NG * PNDF_LBS_SB_BYTES);
+        lbs_pack_split(blob.data(), NG, h->p_scale, h->w_scale, sblob.data());
+        if (e == hipSuccess) e = hipMalloc(&h->d_sblob, sblob.size());
+        if (e == hipSuccess) e = hipMemcpy(h->d_sblob, sblob.data(), sblob.size(), hipMemcpyHostToDevice);
+        const int lds_s = 3 * PNDF_LBS_SB_BYTES;
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pndf_lbs_vertex_split_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pndf_lbs_vertex_split_terms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s);
+    }
     const int lds = 3 * BLOB * (int)sizeof(float);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pndf_lbs_vertex_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pndf_lbs_vertex_terms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -589,6 +1232,7 @@ extern "C" int pndf_lbs_create(pndf_lbs_handle* out, int32_t V, int32_t NB, cons
     if (e != hipSuccess) {
         const std::string m = std::string("pndf_lbs_create: ") + hipGetErrorString(e);
         if (h->d_blob) (void)hipFree(h->d_blob);
+        if (h->d_sblob) (void)hipFree(h->d_sblob);
         delete h;
         return lbs_fail(nullptr, PNDF_ERR_HIP, m);
     }
@@ -600,9 +1244,18 @@ extern "C" int pndf_lbs_destroy(pndf_lbs_handle h) {
     if (!h) return PNDF_OK;
     DeviceGuard guard(h->device);
     if (h->d_blob) (void)hipFree(h->d_blob);
+    if (h->d_sblob) (void)hipFree(h->d_sblob);
     delete h;
     return PNDF_OK;
 }
+
+extern "C" int pndf_lbs_set_precision(pndf_lbs_handle h, int32_t precision) {
+    if (!h) return PNDF_ERR_BAD_ARG;
+    if (precision != PNDF_LBS_FP32 && precision != PNDF_LBS_F16X3) return lbs_fail(h, PNDF_ERR_BAD_ARG, "precision: PNDF_LBS_FP32 or PNDF_LBS_F16X3");
+    h->precision = precision;
+    return PNDF_OK;
+}
+extern "C" int32_t pndf_lbs_precision(pndf_lbs_handle h) { return h ? h->precision : -1; }
 
 extern "C" int32_t pndf_lbs_num_joints(pndf_lbs_handle h) { return h ? NJ + h->NE : 0; }
 extern "C" int32_t pndf_lbs_num_vertices(pndf_lbs_handle h) { return h ? h->V : 0; }
@@ -614,6 +1267,10 @@ extern "C" int32_t pndf_lbs_num_vertices(pndf_lbs_handle h) { return h ? h->V : 
 static int lbs_vsplit(const pndf_lbs_model* h, int nch) {
     const long long quads = (nch + 3) / 4, sm = h->sm_count;
     const int vmax = h->NG < 8 ? h->NG : 8;
+    if (const char* e = getenv("PNDF_LBS_VSPLIT")) {      // (experiment)
+        const int v = atoi(e);
+        if (v >= 1 && v <= vmax) return v;
+    }
     if (quads * vmax <= sm) return vmax;          // less than one round whatever the split: take all the parallelism there is
     int best = 1;
     double best_fill = 0.0;
@@ -626,7 +1283,8 @@ static int lbs_vsplit(const pndf_lbs_model* h, int nch) {
 }
 
 // workspace layout (floats): pfp | Ap | Gt | gpf | gA | halo_pf | halo_A   (sized for the fused-terms mode, the largest)
-static int64_t lbs_workspace(const pndf_lbs_model* h, int64_t S, int64_t T, PndfLbsArgs* a, float* base, int mode) {
+static int64_t lbs_workspace(const pndf_lbs_model* h, int64_t S, int64_t T, PndfLbsArgs* a, float* base, int mode,
+                             PndfLbsSplitArgs* sa = nullptr) {
     const int64_t N = S * T;
     const int cps = (mode == 1) ? chunks_pairs((int)T) : chunks_fwd((int)T);
     const int64_t nch = S * cps;
@@ -640,11 +1298,14 @@ static int64_t lbs_workspace(const pndf_lbs_model* h, int64_t S, int64_t T, Pndf
     float* gA = take((int64_t)vsplit * N * A_FLOATS);
     float* hpf = take((int64_t)vsplit * nch * PF);
     float* hA = take((int64_t)vsplit * nch * A_FLOATS);
+    float* pfs = take(N * (PNDF_LBS_PFS_HALFS / 2));       // split-precision B operands (halfs)
+    float* Aps = take(N * (PNDF_LBS_APS_HALFS / 2));
     if (a) {
         a->pfp = pfp; a->Ap = Ap; a->Gt = Gt; a->gpf = gpf; a->gA = gA;
         a->halo_pf = (mode == 1) ? hpf : nullptr; a->halo_A = (mode == 1) ? hA : nullptr;
         a->cps = cps; a->vsplit = vsplit;
     }
+    if (sa) { sa->pfs = pfs; sa->Aps = Aps; }
     return off;
 }
 
@@ -657,14 +1318,44 @@ extern "C" int64_t pndf_lbs_workspace_floats(pndf_lbs_handle h, int32_t S, int32
 static int lbs_launch(pndf_lbs_model* h, int mode, PndfLbsArgs& a, void* workspace, void* stream) {
     if (((uintptr_t)workspace) & 15) return lbs_fail(h, PNDF_ERR_BAD_ARG, "workspace must be 16-byte aligned");
     a.blob = h->d_blob; a.V = h->V; a.NG = h->NG; a.NE = h->NE; a.model = h->consts;
-    (void)lbs_workspace(h, a.S, a.T, &a, (float*)workspace, mode);
+    const bool split = h->precision == PNDF_LBS_F16X3 && mode != 2;
+    PndfLbsSplitArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    (void)lbs_workspace(h, a.S, a.T, &a, (float*)workspace, mode, &sa);
     DeviceGuard guard(h->device);
     if (!guard.ok) return lbs_fail(h, PNDF_ERR_HIP, "hipSetDevice failed");
     const long long N = (long long)a.S * a.T;
     const dim3 fgrid((unsigned)((N + 63) / 64)), fblock(64);
     const dim3 vgrid((unsigned)(((long long)a.S * a.cps + 3) / 4), (unsigned)(mode == 0 ? 1 : a.vsplit)), vblock(256);
     const int lds = 3 * BLOB * (int)sizeof(float);
-    if (mode == 0) a.vsplit = 1;
+    if (mode == 0) a.vsplit = split ? (h->NG < 8 ? h->NG : 8) : 1;      // (forward: the vertex ranges are independent outputs)
+    if (split) {
+        const dim3 sgrid((unsigned)(vgrid.x * (unsigned)a.vsplit));
+        // operand scales (powers of two) from a-priori bounds: |d L / d verts| <= 2 w_temp + w_data per component (two pairs
+        // share a vertex; the data term touches the picked vertices), |T_R^T g| <= 3 max_v sum_j |W| |g|, |v_posed| <= vp_bound
+        const float gb = 2.0f * std::fabs(a.w_temp) + std::fabs(a.w_data);
+        sa.base = a;
+        sa.sblob = h->d_sblob;
+        sa.a_scale = h->a_scale;
+        sa.off_true = 1.0f / (h->p_scale * PNDF_LBS_PF_SCALE);
+        sa.tm_true = 1.0f / (h->w_scale * h->a_scale);
+        sa.g_scale = lbs_scale_for(3.0f * h->w_rowsum * gb);
+        sa.x_scale = lbs_scale_for(gb * h->vp_bound);
+        sa.gpf_true = (1.0f / h->p_scale) / sa.g_scale;
+        sa.gA_true = (1.0f / h->w_scale) / sa.x_scale;
+        const int lds_s = 3 * PNDF_LBS_SB_BYTES;
+        hipLaunchKernelGGL(pndf_lbs_pose_split_kernel, fgrid, fblock, 0, (hipStream_t)stream, sa);
+        if (mode == 0) {
+            if (a.verts || (a.joints && a.NE > 0))
+                hipLaunchKernelGGL(pndf_lbs_vertex_split_forward_kernel, sgrid, vblock, lds_s, (hipStream_t)stream, sa);
+        } else {
+            hipLaunchKernelGGL(pndf_lbs_vertex_split_terms_kernel, sgrid, vblock, lds_s, (hipStream_t)stream, sa);
+            hipLaunchKernelGGL(pndf_lbs_pose_backward_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return lbs_fail(h, PNDF_ERR_HIP, std::string("launch: ") + hipGetErrorString(e));
+        return PNDF_OK;
+    }
     hipLaunchKernelGGL(pndf_lbs_pose_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
     if (mode == 0) {
         if (a.verts || (a.joints && a.NE > 0))

@@ -14,13 +14,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.fixture(scope="module")
-def smpl_like():
+@pytest.fixture(scope="module", params=["f16x3", "fp32"])
+def smpl_like(request):
+    """both arithmetics of the forward / fused-terms passes (split fp16 MFMAs, the default, and fp32 MFMAs): same tolerances"""
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a visible MI355X (no CPU fallback exists)")
     from posendf_amd import BodyModel
     m = lbs_np.synthetic_model(seed=11)                       # V = 6890, SMPL tree, 21 vertex-picked joints
-    bm = BodyModel(m, device="cuda:0", extra_joint_vertex=m["extra_joint_vertex"])
+    bm = BodyModel(m, device="cuda:0", extra_joint_vertex=m["extra_joint_vertex"], precision=request.param)
+    assert bm.precision == request.param and bm.lib.pndf_lbs_precision(bm.handle) == BodyModel.PRECISIONS[request.param]
     return m, bm
 
 
@@ -138,13 +140,14 @@ def test_fused_denoise_with_body_model_matches_oracle_loop(smpl_like, precision,
     assert {"pose_pr", "temp"} <= set(hist[0]) and "data" in hist[-1]
 
 
-def test_small_model_short_sequences_and_reference_nan_semantics():
+@pytest.mark.parametrize("lbs_precision", ["f16x3", "fp32"])
+def test_small_model_short_sequences_and_reference_nan_semantics(lbs_precision):
     """A 41-vertex model (three vertex groups, the last one padded), sequences of 2, 15, 16 and 17 frames (one pair; one
     chunk exactly; a chunk boundary with and without a shared frame), and the reference's behaviour for two IDENTICAL
     consecutive frames: no epsilon under the root (motion_denoise.py:89), so the temporal gradient of those frames is NaN."""
     from posendf_amd import BodyModel
     m = lbs_np.synthetic_model(V=41, seed=5, extra=(3, 17, 40))
-    bm = BodyModel(m, device="cuda:0")
+    bm = BodyModel(m, device="cuda:0", precision=lbs_precision)
     assert bm.num_joints == 27 and bm.num_vertices == 41
     for T in (2, 15, 16, 17):
         th = _theta(2, T, seed=T)

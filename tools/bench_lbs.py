@@ -21,6 +21,7 @@ from posendf_amd.motion_denoise import MotionDenoise  # noqa: E402
 
 FLOP_PER_FRAME = 2 * (2 * 207 * 20670 + 2 * 6890 * 24 * 12)
 PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_FP16_MFMA_TFLOPS = 2500.0
 
 
 def timed(fn, n):
@@ -40,11 +41,14 @@ def main():
     ap.add_argument("--seqs", type=int, default=64)
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--precision", default="f16x3")
+    ap.add_argument("--precision", default="f16x3", help="precision of the distance engine")
+    ap.add_argument("--terms-only", action="store_true", help="time the fused body-model pass only (diagnostic builds)")
+    ap.add_argument("--lbs-precision", default="f16x3", choices=("f16x3", "fp32"), help="arithmetic of the body-model passes")
     args = ap.parse_args()
     S, T = args.seqs, args.frames
     m = synth.make_body_model(seed=11)
-    bm = BodyModel(m, device="cuda:0", extra_joint_vertex=m["extra_joint_vertex"])
+    bm = BodyModel(m, device="cuda:0", extra_joint_vertex=m["extra_joint_vertex"], precision=args.lbs_precision)
+    peak = PEAK_FP32_MFMA_TFLOPS if args.lbs_precision == "fp32" else PEAK_FP16_MFMA_TFLOPS
     g = torch.Generator().manual_seed(0)
     theta = (torch.cumsum(0.02 * torch.randn(S, T, 69, generator=g), dim=1) + 0.3 * torch.randn(S, 1, 69, generator=g)
              + 0.1 * torch.randn(S, T, 69, generator=g)).cuda()
@@ -52,6 +56,9 @@ def main():
     out = torch.empty_like(theta)
     ms_terms = timed(lambda: bm.terms_grad(theta, j0, 2, out=out), args.reps)
     ms_joints = timed(lambda: bm.joints_of(theta), args.reps)
+    if args.terms_only:
+        print(json.dumps({"lbs_terms_grad_ms": ms_terms, "lbs_forward_joints_only_ms": ms_joints}))
+        return
     cfg = amass_config("lrelu", "cuda:0")
     cfg["engine"] = {"precision": args.precision}
     net = PoseNDF(cfg)
@@ -71,10 +78,11 @@ def main():
     torch.cuda.synchronize()
     ms_step0 = (time.perf_counter() - t0) / 10 * 1e3
     tf = S * T * FLOP_PER_FRAME / (ms_terms * 1e-3) / 1e12
-    print(json.dumps({"workload": f"{S} sequences x {T} frames, SMPL-shaped body model (6,890 vertices), precision {args.precision}",
+    print(json.dumps({"workload": f"{S} sequences x {T} frames, SMPL-shaped body model (6,890 vertices), body model {args.lbs_precision}, engine {args.precision}",
                       "lbs_terms_grad_ms": ms_terms, "lbs_frames_per_s": S * T / (ms_terms * 1e-3),
-                      "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": tf / PEAK_FP32_MFMA_TFLOPS, "algorithmic_flop_per_frame": FLOP_PER_FRAME},
+                      "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+                                   "frac": tf / peak, "algorithmic_flop_per_frame": FLOP_PER_FRAME,
+                                   "mfma_issued_per_algorithmic_flop": 1 if args.lbs_precision == "fp32" else 3},
                       "lbs_forward_joints_only_ms": ms_joints,
                       "fused_adam_step_ms_reference_objective": ms_step,
                       "fused_adam_step_ms_pose_space_surrogates": ms_step0,
