@@ -359,12 +359,15 @@ def main():
         ms_step = (time.perf_counter() - t) / 10 * 1e3
         flop = 2 * (2 * 207 * 20670 + 2 * 6890 * 24 * 12)                 # per frame, forward + reverse
         tf = S * T * flop / (ms_lbs * 1e-3) / 1e12
+        split = bm.precision == "f16x3"
+        peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
         return {"workload": f"BASELINE.json configs[4], one GPU's share: {S} sequences x {T} frames, reference objective (pose prior + "
                             "SMPL vertex temporal term + joint data term), synthetic SMPL-shaped body model, fused Adam steps",
                 "fused_adam_step_ms": ms_step, "frames_per_s": S * T / (ms_step * 1e-3),
-                "body_model_pass": {"kernel": "pndf_lbs_vertex_terms_kernel (+ pose kernels)", "ms": ms_lbs, "bound": "mfma",
-                                    "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
-                                    "algorithmic_flop_per_frame": flop},
+                "body_model_pass": {"kernel": ("pndf_lbs_vertex_split_terms_kernel" if split else "pndf_lbs_vertex_terms_kernel") + " (+ pose kernels)",
+                                    "precision": bm.precision, "ms": ms_lbs, "bound": "mfma",
+                                    "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                                    "mfma_issued_per_algorithmic_flop": 3 if split else 1, "algorithmic_flop_per_frame": flop},
                 "finite": bool(torch.isfinite(res).all()), "parity": "unpinned (smplx is third-party and absent; oracle/lbs_np.py)"}
 
     denoise = motion_denoise_block() if (side and not args.no_motion_denoise and args.act != "softplus") else None

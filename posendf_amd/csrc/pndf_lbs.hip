@@ -213,6 +213,12 @@ __device__ __forceinline__ void lbs_vertex_body(const PndfLbsArgs& a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) AB[4 * i + r] = v[r];
         }
+        // make hipcc wait for these loads HERE: left to the first use, its vmcnt(N) waits sit inside the group loop, where they
+        // also count the model fetch (inline asm, invisible to it) and stall on it
+#pragma unroll
+        for (int i = 0; i < KS; ++i) asm volatile("" : : "v"(pfB[i]));
+#pragma unroll
+        for (int i = 0; i < 72; ++i) asm volatile("" : : "v"(AB[i]));
     }
     f32x4 gpf[KT], gA[12][2];
     if constexpr (MODE != 0) {
@@ -225,12 +231,16 @@ __device__ __forceinline__ void lbs_vertex_body(const PndfLbsArgs& a) {
     const int vs = blockIdx.y;
     const int grp0 = (int)((long long)a.NG * vs / a.vsplit), grp1 = (int)((long long)a.NG * (vs + 1) / a.vsplit);
     // model stream: one blob = 42 pieces of 1 KiB, piece i moved by wave i % 4 (LDS destination = wave-uniform base + lane * 16)
+    // (inline asm, as in the distance engine: when hipcc sees the builtin it waits for the whole fetch -- vmcnt(0) -- in front of
+    // the next LDS read, whatever buffer that reads; the explicit waits below are what order fetch and use)
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) float*)smem);
+    const uint32_t lane16 = (uint32_t)lane * 16u;
     auto dma = [&](int grp, int buf) {
-        const float* src = a.blob + (size_t)grp * BLOB + lane * 4;
-        float* dst = smem + buf * BLOB;
-        for (int i = wave; i < BLOB / 256; i += 4)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 256),
-                                             (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
+        for (int i = wave; i < BLOB / 256; i += 4) {
+            const float* src = a.blob + (size_t)grp * BLOB + (size_t)i * 256;
+            const uint32_t dst = lds_base + (uint32_t)(buf * BLOB + i * 256) * 4u;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane16), "s"(src), "s"(dst) : "memory", "m0");
+        }
     };
     // The forward contractions of a group (pose blend shapes, skinning transforms: MFMA only) and the VALU section that
     // turns them into vertices and vertex gradients are independent ACROSS groups, so the loop is software-pipelined:
@@ -1267,10 +1277,6 @@ extern "C" int32_t pndf_lbs_num_vertices(pndf_lbs_handle h) { return h ? h->V : 
 static int lbs_vsplit(const pndf_lbs_model* h, int nch) {
     const long long quads = (nch + 3) / 4, sm = h->sm_count;
     const int vmax = h->NG < 8 ? h->NG : 8;
-    if (const char* e = getenv("PNDF_LBS_VSPLIT")) {      // (experiment)
-        const int v = atoi(e);
-        if (v >= 1 && v <= vmax) return v;
-    }
     if (quads * vmax <= sm) return vmax;          // less than one round whatever the split: take all the parallelism there is
     int best = 1;
     double best_fill = 0.0;

@@ -1,8 +1,9 @@
 """GPU tests of the HIP linear-blend-skinning path (posendf_amd/csrc/pndf_lbs.hip, C ABI pndf_lbs_*) against
 the numpy oracle oracle/lbs_np.py -- parity UNPINNED (smplx and the SMPL files are third-party and absent): the oracle
 restates the published algorithm, model parameters are synthetic with SMPL's shapes (6,890 vertices, 24 joints, 21 picked
-joints).  Tolerances: the kernels compute in fp32 (fp32 MFMA); errors are measured against the fp64 oracle and held to
-1e-4 relative (north_star's bar) and to a multiple of the fp32 oracle's own error."""
+joints).  Both arithmetics of the forward / fused-terms passes run every test: "f16x3" (the default: fp16 MFMAs on operands
+split into hi + lo halves, fp32 accumulate) and "fp32" (fp32 MFMAs).  Tolerances are the same for both: errors are measured
+against the fp64 oracle and held to 1e-4 relative (north_star's bar) and to a multiple of the fp32 oracle's own error."""
 import numpy as np
 import pytest
 import torch
