@@ -17,6 +17,10 @@
 // joints in the reverse pass), D columns = 16 FRAMES of one wave.  Vertices, skinning matrices and vertex gradients of a
 // (16 vertex x 16 frame) tile live in registers only; nothing per-vertex ever goes to HBM in the fused-terms mode.
 //
+// Two arithmetics for the vertex-side contractions: fp32 MFMAs as described here (PNDF_LBS_FP32), and -- the default for the
+// forward and fused-terms passes -- fp16 MFMAs on operands split into hi + lo halves (PNDF_LBS_F16X3, "split precision" below:
+// 212 MFMAs of 16 cycles per tile instead of 480 of 32).
+//
 // Three kernels:
 //   pndf_lbs_pose_kernel            one thread per frame: Rodrigues, transform chain -> pose feature, A, posed joints
 //   pndf_lbs_vertex_kernel<MODE>    one wave per chunk of 16 frames, four chunks per workgroup sharing the model stream:
