@@ -214,6 +214,11 @@ int64_t pndf_lbs_packed_floats(int32_t V);
 int pndf_lbs_pack_host(int32_t V, int32_t NB, const float* v_template, const float* shapedirs, const float* betas,
                        const float* posedirs, const float* J_regressor, const int32_t* parents, const float* lbs_weights,
                        const int32_t* extra_joint_vertex, int32_t n_extra, float* blob, float* J_out, float* rel_out);
+/* The model for PNDF_LBS_F16X3 from the packed fp32 one (host only): sblob takes pndf_lbs_packed_split_bytes(V) bytes -- per
+ * 16 vertices, planes of fp16 hi / lo halves [row][16 v] of posedirs x p_scale and weights x w_scale (powers of two, returned in
+ * scales_out[0..1], may be NULL), laid out in bank-conflict-free tiles (csrc/pndf_lbs_split.h). */
+int64_t pndf_lbs_packed_split_bytes(int32_t V);
+int pndf_lbs_pack_split_host(int32_t V, const float* blob, void* sblob, float* scales_out);
 const char* pndf_lbs_last_error(pndf_lbs_handle h);    /* h may be NULL: last error of a failed pndf_lbs_create */
 
 /* ---- quaternion pose distance + k nearest candidates (data/dist_utils.py:9-50, classes euc / geo; caller

@@ -1167,6 +1167,48 @@ extern "C" int pndf_lbs_pack_host(int32_t V, int32_t NB, const float* v_template
     return PNDF_OK;
 }
 
+// operand scales of the split-precision model (powers of two, from the largest |entry|: [2^12, 2^13)) and the bounds the
+// host derives the reverse operand scales from
+struct LbsSplitScales { float p_scale, w_scale, w_rowsum, vp_bound; };
+static LbsSplitScales lbs_split_scales(const float* blob, int NG) {
+    float maxP = 0.f, maxW = 0.f, rowsum = 0.f, vpb = 0.f;
+    for (int grp = 0; grp < NG; ++grp) {
+        const float* b = blob + (size_t)grp * BLOB;
+        for (int vi = 0; vi < GV; ++vi) {
+            float ws = 0.f;
+            for (int j = 0; j < NJ; ++j) {
+                const float w = std::fabs(b[PNDF_LBS_BLOB_W + j * GV + vi]);
+                ws += w;
+                maxW = std::fmax(maxW, w);
+            }
+            rowsum = std::fmax(rowsum, ws);
+            for (int c = 0; c < 3; ++c) {
+                float ps = 0.f;
+                for (int k = 0; k < PF; ++k) {
+                    const float pv = std::fabs(b[PNDF_LBS_BLOB_P + c * C_STRIDE + k * GV + vi]);
+                    ps += pv;
+                    maxP = std::fmax(maxP, pv);
+                }
+                vpb = std::fmax(vpb, std::fabs(b[PNDF_LBS_BLOB_VS + c * GV + vi]) + 2.0f * ps);      // |R - I| <= 2
+            }
+        }
+    }
+    return LbsSplitScales{lbs_scale_for(maxP) * 0.5f, lbs_scale_for(maxW) * 0.5f, std::fmax(rowsum, 1e-6f), std::fmax(vpb, 1.0f)};
+}
+
+extern "C" int64_t pndf_lbs_packed_split_bytes(int32_t V) { return V < 1 ? 0 : (int64_t)((V + GV - 1) / GV) * PNDF_LBS_SB_BYTES; }
+
+// Host-only: the split-precision model (what pndf_lbs_create uploads for PNDF_LBS_F16X3) from the fp32 one of
+// pndf_lbs_pack_host.  scales_out (may be null): p_scale, w_scale.
+extern "C" int pndf_lbs_pack_split_host(int32_t V, const float* blob, void* sblob, float* scales_out) {
+    if (V < 1 || !blob || !sblob) return PNDF_ERR_BAD_ARG;
+    const int NG = (V + GV - 1) / GV;
+    const LbsSplitScales sc = lbs_split_scales(blob, NG);
+    lbs_pack_split(blob, NG, sc.p_scale, sc.w_scale, (uint8_t*)sblob);
+    if (scales_out) { scales_out[0] = sc.p_scale; scales_out[1] = sc.w_scale; }
+    return PNDF_OK;
+}
+
 extern "C" int pndf_lbs_create(pndf_lbs_handle* out, int32_t V, int32_t NB, const float* v_template, const float* shapedirs,
                                const float* betas, const float* posedirs, const float* J_regressor, const int32_t* parents,
                                const float* lbs_weights, const int32_t* extra_joint_vertex, int32_t n_extra, int device) {
@@ -1199,38 +1241,17 @@ extern "C" int pndf_lbs_create(pndf_lbs_handle* out, int32_t V, int32_t NB, cons
     if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
     {
         // operand scales and bounds of the split-precision kernels, from the packed model
-        float maxP = 0.f, maxW = 0.f, rowsum = 0.f, vpb = 0.f;
-        for (int grp = 0; grp < NG; ++grp) {
-            const float* b = blob.data() + (size_t)grp * BLOB;
-            for (int vi = 0; vi < GV; ++vi) {
-                float ws = 0.f;
-                for (int j = 0; j < NJ; ++j) {
-                    const float w = std::fabs(b[PNDF_LBS_BLOB_W + j * GV + vi]);
-                    ws += w;
-                    maxW = std::fmax(maxW, w);
-                }
-                rowsum = std::fmax(rowsum, ws);
-                for (int c = 0; c < 3; ++c) {
-                    float ps = 0.f;
-                    for (int k = 0; k < PF; ++k) {
-                        const float pv = std::fabs(b[PNDF_LBS_BLOB_P + c * C_STRIDE + k * GV + vi]);
-                        ps += pv;
-                        maxP = std::fmax(maxP, pv);
-                    }
-                    vpb = std::fmax(vpb, std::fabs(b[PNDF_LBS_BLOB_VS + c * GV + vi]) + 2.0f * ps);      // |R - I| <= 2
-                }
-            }
-        }
+        const LbsSplitScales sc = lbs_split_scales(blob.data(), NG);
         float extent = 0.f, maxJ = 0.f;      // |G_t[j]| <= sum of the bone lengths, |A_t| <= |G_t| + |J|
         for (int j = 0; j < NJ; ++j) {
             extent += std::sqrt(rel[3 * j] * rel[3 * j] + rel[3 * j + 1] * rel[3 * j + 1] + rel[3 * j + 2] * rel[3 * j + 2]);
             maxJ = std::fmax(maxJ, std::sqrt(J[3 * j] * J[3 * j] + J[3 * j + 1] * J[3 * j + 1] + J[3 * j + 2] * J[3 * j + 2]));
         }
-        h->p_scale = lbs_scale_for(maxP) * 0.5f;      // [2^12, 2^13): headroom for hi + hi products is not needed, for rounding up is
-        h->w_scale = lbs_scale_for(maxW) * 0.5f;
+        h->p_scale = sc.p_scale;
+        h->w_scale = sc.w_scale;
         h->a_scale = lbs_scale_for(std::fmax(1.0f, extent + maxJ)) * 0.5f;
-        h->w_rowsum = std::fmax(rowsum, 1e-6f);
-        h->vp_bound = std::fmax(vpb, 1.0f);
+        h->w_rowsum = sc.w_rowsum;
+        h->vp_bound = sc.vp_bound;
         std::vector<uint8_t> sblob((size_t)NG * PNDF_LBS_SB_BYTES);
         lbs_pack_split(blob.data(), NG, h->p_scale, h->w_scale, sblob.data());
         if (e == hipSuccess) e = hipMalloc(&h->d_sblob, sblob.size());

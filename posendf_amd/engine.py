@@ -94,6 +94,10 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.pndf_lbs_packed_floats.restype = c_int64
     lib.pndf_lbs_pack_host.argtypes = [c_int32, c_int32] + [c_void_p] * 8 + [c_int32, c_void_p, c_void_p, c_void_p]
     lib.pndf_lbs_pack_host.restype = c_int
+    lib.pndf_lbs_packed_split_bytes.argtypes = [c_int32]
+    lib.pndf_lbs_packed_split_bytes.restype = c_int64
+    lib.pndf_lbs_pack_split_host.argtypes = [c_int32, c_void_p, c_void_p, c_void_p]
+    lib.pndf_lbs_pack_split_host.restype = c_int
     lib.pndf_lbs_set_precision.argtypes = [LH, c_int32]
     lib.pndf_lbs_set_precision.restype = c_int
     lib.pndf_lbs_precision.argtypes = [LH]
@@ -119,7 +123,7 @@ EXPORTS = ("pndf_default_config", "pndf_create", "pndf_destroy", "pndf_load_weig
            "pndf_debug_project_timing", "pndf_debug_timing_regions",
            "pndf_packed_sizes", "pndf_pack_host", "pndf_pack_host_split", "pndf_aa2quat", "pndf_denoise_update", "pndf_denoise_update_body", "pndf_denoise_update_w", "pndf_lbs_terms_grad_w", "pndf_quat_topk",
            "pndf_lbs_create", "pndf_lbs_destroy", "pndf_lbs_set_precision", "pndf_lbs_precision", "pndf_lbs_num_joints", "pndf_lbs_num_vertices", "pndf_lbs_workspace_floats",
-           "pndf_lbs_forward", "pndf_lbs_terms_grad", "pndf_lbs_backward", "pndf_lbs_packed_floats", "pndf_lbs_pack_host",
+           "pndf_lbs_forward", "pndf_lbs_terms_grad", "pndf_lbs_backward", "pndf_lbs_packed_floats", "pndf_lbs_pack_host", "pndf_lbs_packed_split_bytes", "pndf_lbs_pack_split_host",
            "pndf_lbs_last_error", "pndf_last_error", "pndf_version", "pndf_kernel_name")
 
 
