@@ -77,7 +77,9 @@ __device__ __forceinline__ void rodrigues(float rx, float ry, float rz, float* R
     const float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
     const float th = sqrtf(ax * ax + ay * ay + az * az);
     const float nx = rx / th, ny = ry / th, nz = rz / th;
-    const float s = sinf(th), c1 = 1.0f - cosf(th);
+    float s, c;
+    sincosf(th, &s, &c);
+    const float c1 = 1.0f - c;
     R[0] = 1.0f - c1 * (nz * nz + ny * ny); R[1] = -s * nz + c1 * nx * ny;          R[2] = s * ny + c1 * nx * nz;
     R[3] = s * nz + c1 * nx * ny;          R[4] = 1.0f - c1 * (nz * nz + nx * nx); R[5] = -s * nx + c1 * ny * nz;
     R[6] = -s * ny + c1 * nx * nz;         R[7] = s * nx + c1 * ny * nz;           R[8] = 1.0f - c1 * (nx * nx + ny * ny);
@@ -88,7 +90,9 @@ __device__ __forceinline__ void rodrigues_vjp(float rx, float ry, float rz, cons
     const float a[3] = {rx + 1e-8f, ry + 1e-8f, rz + 1e-8f};
     const float th = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
     const float nx = rx / th, ny = ry / th, nz = rz / th;
-    const float s = sinf(th), c = cosf(th), c1 = 1.0f - c;
+    float s, c;
+    sincosf(th, &s, &c);
+    const float c1 = 1.0f - c;
     const float K[9] = {0.f, -nz, ny, nz, 0.f, -nx, -ny, nx, 0.f};
     const float KK[9] = {-(nz * nz + ny * ny), nx * ny, nx * nz, nx * ny, -(nz * nz + nx * nx), ny * nz,
                          nx * nz, ny * nz, -(nx * nx + ny * ny)};
@@ -112,17 +116,54 @@ __device__ __forceinline__ void rodrigues_vjp(float rx, float ry, float rz, cons
     for (int i = 0; i < 3; ++i) gr[i] = gn[i] / th + g_th * a[i] / th;
 }
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): an unrolled loop whose index is a constant by construction
+// (`#pragma unroll` may leave a long loop rolled, with its index arithmetic -- and every array it indexes -- at run time)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// The kinematic tree of the per-frame kernels.  SMPL's own tree as a compile-time table: with every joint loop unrolled over
+// constants the per-frame arrays (24 rotations, 24 global transforms, their gradients) are REGISTERS (up to ~500 of the 512
+// a lone wave has); with the tree read from the model at run time they are dynamically indexed, i.e. 2 - 4 KB of scratch
+// memory per frame, and the kernels are bound by its latency (0.83 + 1.57 ms at 153,600 frames against the time below).
+struct SmplTree {
+    static constexpr int tab[NJ] = {-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21};
+    static constexpr bool STATIC = true;
+    static __device__ __forceinline__ constexpr int parent(const PndfLbsModel&, int j) { return tab[j]; }
+};
+struct ModelTree {
+    static constexpr bool STATIC = false;
+    static __device__ __forceinline__ int parent(const PndfLbsModel& m, int j) { return m.parent[j]; }
+};
+// loop over joints j0 .. NJ - 1: unrolled over constants for the static tree, a plain loop otherwise
+template <class Tree, int J0, class F>
+__device__ __forceinline__ void for_joints(F&& f) {
+    if constexpr (Tree::STATIC) static_for<NJ - J0>([&](auto jc) __attribute__((always_inline)) { f(J0 + decltype(jc)::value); });
+    else for (int j = J0; j < NJ; ++j) f(j);
+}
+template <class Tree, int J0, class F>
+__device__ __forceinline__ void for_joints_reverse(F&& f) {
+    if constexpr (Tree::STATIC) static_for<NJ - J0>([&](auto jc) __attribute__((always_inline)) { f(NJ - 1 - decltype(jc)::value); });
+    else for (int j = NJ - 1; j >= J0; --j) f(j);
+}
+
 // rotations, global rotations and global translations of the 24 joints of one frame (smplx batch_rigid_transform)
+template <class Tree>
 __device__ __forceinline__ void frame_transforms(const float* th, const PndfLbsModel& m, float (&R)[NJ][9], float (&GR)[NJ][9],
                                                  float (&Gt)[NJ][3]) {
     rodrigues(0.f, 0.f, 0.f, R[0]);          // SMPL's global_orient parameter: zeros (body_model.py:35-40 passes None)
-    for (int j = 1; j < NJ; ++j) rodrigues(th[3 * j - 3], th[3 * j - 2], th[3 * j - 1], R[j]);
+    for_joints<Tree, 1>([&](int j) __attribute__((always_inline)) { rodrigues(th[3 * j - 3], th[3 * j - 2], th[3 * j - 1], R[j]); });
 #pragma unroll
     for (int i = 0; i < 9; ++i) GR[0][i] = R[0][i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) Gt[0][i] = m.rel[0][i];
-    for (int j = 1; j < NJ; ++j) {
-        const int p = m.parent[j];
+    for_joints<Tree, 1>([&](int j) __attribute__((always_inline)) {
+        const int p = Tree::parent(m, j);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
 #pragma unroll
@@ -130,7 +171,7 @@ __device__ __forceinline__ void frame_transforms(const float* th, const PndfLbsM
                 GR[j][3 * a + b] = GR[p][3 * a] * R[j][b] + GR[p][3 * a + 1] * R[j][3 + b] + GR[p][3 * a + 2] * R[j][6 + b];
             Gt[j][a] = GR[p][3 * a] * m.rel[j][0] + GR[p][3 * a + 1] * m.rel[j][1] + GR[p][3 * a + 2] * m.rel[j][2] + Gt[p][a];
         }
-    }
+    });
 }
 
 // chunks of frames per sequence: fused-terms mode walks 15 pairs per chunk (consecutive chunks share a frame)
@@ -140,38 +181,41 @@ __host__ __device__ inline int chunks_pairs(int T) { return T > 1 ? (T - 1 + 14)
 }  // namespace
 
 // ------------------------------------------------------------------ per-frame forward
-extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_kernel(PndfLbsArgs a) {
+template <class Tree>
+__device__ __forceinline__ void lbs_pose_body(const PndfLbsArgs& a) {
     const long long n = (long long)blockIdx.x * 64 + threadIdx.x;
     if (n >= (long long)a.S * a.T) return;
     float R[NJ][9], GR[NJ][9], Gt[NJ][3];
-    frame_transforms(a.theta + n * 69, a.model, R, GR, Gt);
+    frame_transforms<Tree>(a.theta + n * 69, a.model, R, GR, Gt);
     // pose feature, k-permuted so that lane group g of the vertex kernel reads its 52 values contiguously:
     // pfp[g * 52 + s] = pose_feature[4 s + g]
     float* pf = a.pfp + n * PF;
-    for (int k = 0; k < PF; ++k) {
-        float v = 0.f;
-        if (k < 9 * (NJ - 1)) v = R[1 + k / 9][k % 9] - (((k % 9) % 4 == 0) ? 1.0f : 0.0f);
-        pf[(k & 3) * KS + (k >> 2)] = v;
-    }
+    for_joints<Tree, 1>([&](int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            const int k = 9 * (j - 1) + e;
+            pf[(k & 3) * KS + (k >> 2)] = R[j][e] - ((e % 4 == 0) ? 1.0f : 0.0f);
+        }
+    });
+    pf[3 * KS + KS - 1] = 0.f;      // k = 207: padding
     // A_j = [G_R | G_t - G_R J_j] in B-operand order: Ap[g][entry][s] = A[joint 4 s + g][entry]
     float* Ap = a.Ap + n * 288;
-    for (int j = 0; j < NJ; ++j) {
+    const int njt = NJ + a.NE;
+    for_joints<Tree, 0>([&](int j) __attribute__((always_inline)) {
         const int g = j & 3, s = j >> 2;
 #pragma unroll
         for (int e = 0; e < 9; ++e) Ap[g * 72 + e * 6 + s] = GR[j][e];
 #pragma unroll
-        for (int e = 0; e < 3; ++e)
+        for (int e = 0; e < 3; ++e) {
             Ap[g * 72 + (9 + e) * 6 + s] = Gt[j][e] - (GR[j][3 * e] * a.model.J[j][0] + GR[j][3 * e + 1] * a.model.J[j][1] +
                                                         GR[j][3 * e + 2] * a.model.J[j][2]);
-    }
-    const int njt = NJ + a.NE;
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
             if (a.Gt) a.Gt[n * (NJ * 3) + 3 * j + e] = Gt[j][e];
             if (a.joints) a.joints[(n * njt + j) * 3 + e] = Gt[j][e];
         }
+    });
 }
+extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_kernel(PndfLbsArgs a) { lbs_pose_body<ModelTree>(a); }
+extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_smpl_kernel(PndfLbsArgs a) { lbs_pose_body<SmplTree>(a); }
 
 __device__ __forceinline__ void lbs_rotate(f32x4 (&off)[3], f32x4 (&Tm)[12], const f32x4 (&off_n)[3], const f32x4 (&Tm_n)[12]) {
 #pragma unroll
@@ -418,25 +462,26 @@ extern "C" __global__ void __launch_bounds__(256, 1) pndf_lbs_vertex_terms_kerne
 extern "C" __global__ void __launch_bounds__(256, 1) pndf_lbs_vertex_reverse_kernel(PndfLbsArgs a) { lbs_vertex_body<2>(a); }
 
 // ------------------------------------------------------------------ per-frame reverse
-extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_backward_kernel(PndfLbsArgs a) {
+template <class Tree>
+__device__ __forceinline__ void lbs_pose_backward_body(const PndfLbsArgs& a) {
     const long long N = (long long)a.S * a.T;
     const long long n = (long long)blockIdx.x * 64 + threadIdx.x;
     if (n >= N) return;
     const int T = a.T, s = (int)(n / T), t = (int)(n - (long long)s * T), njt = NJ + a.NE;
     const int nch = a.S * a.cps;
     float R[NJ][9], GR[NJ][9], Gt[NJ][3];
-    frame_transforms(a.theta + n * 69, a.model, R, GR, Gt);
+    frame_transforms<Tree>(a.theta + n * 69, a.model, R, GR, Gt);
     // the frame a chunk of pairs shares with the next chunk got a second partial result there
     const bool halo = a.halo_pf && t > 0 && t % 15 == 0 && t / 15 < a.cps;
     const long long hidx = (long long)s * a.cps + t / 15 - 1;
-    auto sum_pf = [&](int k) {
+    auto sum_pf = [&](int k) __attribute__((always_inline)) {
         float acc = 0.f;
         for (int v = 0; v < a.vsplit; ++v) acc += a.gpf[((size_t)v * N + n) * PF + k];
         if (halo)
             for (int v = 0; v < a.vsplit; ++v) acc += a.halo_pf[((size_t)v * nch + hidx) * PF + k];
         return acc;
     };
-    auto sum_A = [&](int e, int j) {
+    auto sum_A = [&](int e, int j) __attribute__((always_inline)) {
         float acc = 0.f;
         for (int v = 0; v < a.vsplit; ++v) acc += a.gA[((size_t)v * N + n) * A_FLOATS + e * 32 + j];
         if (halo)
@@ -444,7 +489,7 @@ extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_backward_kernel(P
         return acc;
     };
     float gGR[NJ][9], gGt[NJ][3], gR[NJ][9];
-    for (int j = 0; j < NJ; ++j) {
+    for_joints<Tree, 0>([&](int j) __attribute__((always_inline)) {
         float gAt[3];
 #pragma unroll
         for (int e = 0; e < 3; ++e) gAt[e] = sum_A(9 + e, j);
@@ -465,9 +510,9 @@ extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_backward_kernel(P
         for (int e = 0; e < 3; ++e) gGt[j][e] = gAt[e] + gj[e];
 #pragma unroll
         for (int e = 0; e < 9; ++e) gR[j][e] = (j > 0) ? sum_pf(9 * (j - 1) + e) : 0.f;                // pose_feature = R_1.. - I
-    }
-    for (int i = NJ - 1; i >= 1; --i) {          // reverse of G_i = G_parent [R_i | rel_i]
-        const int pj = a.model.parent[i];
+    });
+    for_joints_reverse<Tree, 1>([&](int i) __attribute__((always_inline)) {          // reverse of G_i = G_parent [R_i | rel_i]
+        const int pj = Tree::parent(a.model, i);
 #pragma unroll
         for (int x = 0; x < 3; ++x)
 #pragma unroll
@@ -483,14 +528,152 @@ extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_backward_kernel(P
             }
 #pragma unroll
         for (int e = 0; e < 3; ++e) gGt[pj][e] += gGt[i][e];
-    }
-    for (int j = 1; j < NJ; ++j) {
+    });
+    for_joints<Tree, 1>([&](int j) __attribute__((always_inline)) {
         float gr[3];
         const float* th = a.theta + n * 69 + 3 * (j - 1);
         rodrigues_vjp(th[0], th[1], th[2], gR[j], gr);
 #pragma unroll
         for (int e = 0; e < 3; ++e) a.g_theta[n * 69 + 3 * (j - 1) + e] = gr[e];
+    });
+}
+extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_backward_kernel(PndfLbsArgs a) { lbs_pose_backward_body<ModelTree>(a); }
+
+// The same for SMPL's own tree, laid out for registers: the generic form above keeps ~1,000 values alive (R, G_R, G_t and
+// their gradients for 24 joints), which does not fit even with the tree as constants.  Here a joint's rotation is recovered
+// from the stored global rotations (R_i = G_R[p]^T G_R[i]), its partial results are read when the reverse sweep reaches
+// it, d L / d R_i goes through the Rodrigues reverse pass at once, and what a joint hands to its parent lives in a pending
+// slot that exists only between the parent's last child and the parent itself (a handful at a time): ~300 live values.
+constexpr bool smpl_last_child(int i) {      // no later joint has the same parent: the reverse sweep meets this child first
+    for (int k = i + 1; k < NJ; ++k)
+        if (SmplTree::tab[k] == SmplTree::tab[i]) return false;
+    return true;
+}
+constexpr bool smpl_has_children(int i) {
+    for (int k = i + 1; k < NJ; ++k)
+        if (SmplTree::tab[k] == i) return true;
+    return false;
+}
+extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_backward_smpl_kernel(PndfLbsArgs a) {
+    const long long N = (long long)a.S * a.T;
+    const long long n = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    const int T = a.T, s = (int)(n / T), t = (int)(n - (long long)s * T), njt = NJ + a.NE;
+    const int nch = a.S * a.cps;
+    float GR[NJ][9], Gt[NJ][3];
+    {
+        float R[NJ][9];
+        frame_transforms<SmplTree>(a.theta + n * 69, a.model, R, GR, Gt);
     }
+    const bool halo = a.halo_pf && t > 0 && t % 15 == 0 && t / 15 < a.cps;
+    const long long hidx = (long long)s * a.cps + t / 15 - 1;
+    // partial results of joint i, summed over the vertex ranges (and the chunk that shares this frame) in a fixed order
+    auto gather = [&](int i, float (&sA)[12], float (&sP)[9]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 12; ++e) sA[e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) sP[e] = 0.f;
+        for (int v = 0; v < a.vsplit; ++v) {
+            const float* qA = a.gA + ((size_t)v * N + n) * A_FLOATS + i;
+            const float* qP = a.gpf + ((size_t)v * N + n) * PF + 9 * (i - 1);
+#pragma unroll
+            for (int e = 0; e < 12; ++e) sA[e] += qA[e * 32];
+            if (i >= 1) {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) sP[e] += qP[e];
+            }
+        }
+        if (halo) {
+            for (int v = 0; v < a.vsplit; ++v) {
+                const float* qA = a.halo_A + ((size_t)v * nch + hidx) * A_FLOATS + i;
+                const float* qP = a.halo_pf + ((size_t)v * nch + hidx) * PF + 9 * (i - 1);
+#pragma unroll
+                for (int e = 0; e < 12; ++e) sA[e] += qA[e * 32];
+                if (i >= 1) {
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) sP[e] += qP[e];
+                }
+            }
+        }
+    };
+    float pGR[NJ][9], pGt[NJ][3];      // pending: what a joint's children handed up (static indices: only the live ones cost registers)
+    static_for<NJ>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = NJ - 1 - decltype(ic)::value;
+        float sA[12], sP[9], gAt[3], gGR[9], gGt[3];
+        gather(i, sA, sP);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) gAt[e] = sA[9 + e];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) gGR[e] = sA[e] - gAt[e / 3] * a.model.J[i][e % 3];      // A_t = G_t - G_R J
+        float gj[3] = {0.f, 0.f, 0.f};      // joints[:, :24] = G_t: data term (motion_denoise.py:93-94) or the caller's d L / d joints
+        if (a.g_joints) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) gj[e] = a.g_joints[((size_t)n * njt + i) * 3 + e];
+        } else if (a.it_gt0 && a.joints0) {
+            const float* j0 = a.joints0 + ((size_t)n * njt + i) * 3;
+            const float dx = Gt[i][0] - j0[0], dy = Gt[i][1] - j0[1], dz = Gt[i][2] - j0[2];
+            const float inv = a.w_data / sqrtf(dx * dx + dy * dy + dz * dz);
+            gj[0] = dx * inv; gj[1] = dy * inv; gj[2] = dz * inv;
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) gGt[e] = gAt[e] + gj[e];
+        if constexpr (smpl_has_children(i)) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) gGR[e] += pGR[i][e];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) gGt[e] += pGt[i][e];
+        }
+        if constexpr (i >= 1) {
+            constexpr int pj = SmplTree::tab[i];
+            float Ri[9], gRi[9];
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+#pragma unroll
+                for (int y = 0; y < 3; ++y) {
+                    float r = 0.f, acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        r += GR[pj][3 * k + x] * GR[i][3 * k + y];             // R_i = G_R[p]^T G_R[i]
+                        acc += GR[pj][3 * k + x] * gGR[3 * k + y];            // G_R[p]^T gG_R[i]
+                    }
+                    Ri[3 * x + y] = r;
+                    gRi[3 * x + y] = sP[3 * x + y] + acc;                     // pose_feature = R_1.. - I
+                }
+            // d L / d R_i takes the place of this frame's (first) partial d L / d pose_feature[9 (i - 1) ..]: the Rodrigues reverse
+            // pass is its own kernel, one thread per (frame, joint)
+            float* outR = a.gpf + (size_t)n * PF + 9 * (i - 1);
+#pragma unroll
+            for (int e = 0; e < 9; ++e) outR[e] = gRi[e];
+            // to the parent: gG_R[i] R_i^T + gG_t[i] (x) rel_i, and gG_t[i]
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+#pragma unroll
+                for (int y = 0; y < 3; ++y) {
+                    float acc2 = gGt[x] * a.model.rel[i][y];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc2 += gGR[3 * x + k] * Ri[3 * y + k];
+                    pGR[pj][3 * x + y] = smpl_last_child(i) ? acc2 : pGR[pj][3 * x + y] + acc2;
+                }
+                pGt[pj][x] = smpl_last_child(i) ? gGt[x] : pGt[pj][x] + gGt[x];
+            }
+        }
+    });
+}
+
+// d L / d R_i [S*T, 23, 9] (in the first partial-result slice, see above) -> d L / d theta: one thread per (frame, joint)
+extern "C" __global__ void __launch_bounds__(256) pndf_lbs_rodrigues_vjp_kernel(PndfLbsArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)a.S * a.T * (NJ - 1)) return;
+    const long long n = idx / (NJ - 1);
+    const int j = (int)(idx - n * (NJ - 1));
+    const float* gRp = a.gpf + (size_t)n * PF + 9 * j;
+    float gRi[9], gr[3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) gRi[e] = gRp[e];
+    const float* th = a.theta + n * 69 + 3 * j;
+    rodrigues_vjp(th[0], th[1], th[2], gRi, gr);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) a.g_theta[n * 69 + 3 * j + e] = gr[e];
 }
 
 // ====================================================================================== split precision
@@ -551,16 +734,7 @@ __device__ __forceinline__ void lbs_split4(const f32x4& v, f16x4& hi, f16x4& lo)
     lo = __builtin_bit_cast(f16x4, u32x2{l0, l1});
 }
 __device__ __forceinline__ f16x8 cat(f16x4 a, f16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): an unrolled loop whose index is a constant by construction
-// (`#pragma unroll` leaves the 99-trip loop over the forward MFMAs rolled, with its index arithmetic at run time)
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
+// (static_for: see the top of the file -- `#pragma unroll` leaves the 99-trip loop over the forward MFMAs rolled)
 
 // ds_read_b64_tr_b16: within a 16-lane row, lane i element j <- element i % 4 of the 8 bytes addressed by lane 4 j + i / 4
 // (profiles/r02/tr_b16_probe.txt).  With lane m of row g pointing at plane row 4 g + m / 4, halfs 4 (m % 4) .. + 3, lane i
@@ -584,61 +758,63 @@ __device__ __forceinline__ f16x4 lds_row(lds_char* p) { return *(lds_f16x4*)p; }
 }  // namespace
 
 // ------------------------------------------------------------------ per-frame forward, split operands out
-extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_split_kernel(PndfLbsSplitArgs sa) {
+template <class Tree>
+__device__ __forceinline__ void lbs_pose_split_body(const PndfLbsSplitArgs& sa) {
     const PndfLbsArgs& a = sa.base;
     const long long n = (long long)blockIdx.x * 64 + threadIdx.x;
     if (n >= (long long)a.S * a.T) return;
     float R[NJ][9], GR[NJ][9], Gt[NJ][3];
-    frame_transforms(a.theta + n * 69, a.model, R, GR, Gt);
+    frame_transforms<Tree>(a.theta + n * 69, a.model, R, GR, Gt);
     // pose feature x 2^12, hi / lo, in B-operand order: element i of k-block kb in lane group g = entry 32 kb + 16 (i / 4) + 4 g + i % 4
-    float pf[PNDF_LBS_KP];
-    for (int k = 0; k < PNDF_LBS_KP; ++k)
-        pf[k] = (k < 9 * (NJ - 1)) ? (R[1 + k / 9][k % 9] - (((k % 9) % 4 == 0) ? 1.0f : 0.0f)) * PNDF_LBS_PF_SCALE : 0.f;
+    auto pf_at = [&](int k) __attribute__((always_inline)) {
+        return (k < 9 * (NJ - 1)) ? (R[1 + k / 9][k % 9] - (((k % 9) % 4 == 0) ? 1.0f : 0.0f)) * PNDF_LBS_PF_SCALE : 0.f;
+    };
     u32x4* dpf = (u32x4*)sa.pfs + n * (4 * KB * 2);
-    for (int g = 0; g < 4; ++g)
-        for (int kb = 0; kb < KB; ++kb) {
-            unsigned h[4], l[4];
+    auto pf_block = [&](int blk) __attribute__((always_inline)) {      // blk = g * KB + kb
+        const int g = blk / KB, kb = blk % KB;
+        unsigned h[4], l[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k0 = kb * 32 + 16 * (q / 2) + 4 * g + 2 * (q % 2);
-                lbs_split2(pf[k0], pf[k0 + 1], h[q], l[q]);
-            }
-            dpf[(g * KB + kb) * 2] = u32x4{h[0], h[1], h[2], h[3]};
-            dpf[(g * KB + kb) * 2 + 1] = u32x4{l[0], l[1], l[2], l[3]};
+        for (int q = 0; q < 4; ++q) {
+            const int k0 = kb * 32 + 16 * (q / 2) + 4 * g + 2 * (q % 2);
+            lbs_split2(pf_at(k0), pf_at(k0 + 1), h[q], l[q]);
         }
+        dpf[blk * 2] = u32x4{h[0], h[1], h[2], h[3]};
+        dpf[blk * 2 + 1] = u32x4{l[0], l[1], l[2], l[3]};
+    };
+    if constexpr (Tree::STATIC) static_for<4 * KB>([&](auto bc) __attribute__((always_inline)) { pf_block(decltype(bc)::value); });
+    else for (int blk = 0; blk < 4 * KB; ++blk) pf_block(blk);
     // A_j = [G_R | G_t - G_R J_j] x a_scale: element i of entry e in lane group g = joint 16 (i / 4) + 4 g + i % 4
-    float Av[12][32];
-    for (int j = 0; j < 32; ++j)
-#pragma unroll
-        for (int e = 0; e < 12; ++e) Av[e][j] = 0.f;
-    for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-        for (int e = 0; e < 9; ++e) Av[e][j] = GR[j][e] * sa.a_scale;
-#pragma unroll
-        for (int e = 0; e < 3; ++e)
-            Av[9 + e][j] = (Gt[j][e] - (GR[j][3 * e] * a.model.J[j][0] + GR[j][3 * e + 1] * a.model.J[j][1] +
-                                        GR[j][3 * e + 2] * a.model.J[j][2])) * sa.a_scale;
-    }
+    auto A_at = [&](int e, int j) __attribute__((always_inline)) {
+        if (j >= NJ) return 0.f;
+        if (e < 9) return GR[j][e] * sa.a_scale;
+        const int c = e - 9;
+        return (Gt[j][c] - (GR[j][3 * c] * a.model.J[j][0] + GR[j][3 * c + 1] * a.model.J[j][1] + GR[j][3 * c + 2] * a.model.J[j][2])) * sa.a_scale;
+    };
     u32x4* dA = (u32x4*)sa.Aps + n * (4 * 12 * 2);
-    for (int g = 0; g < 4; ++g)
-        for (int e = 0; e < 12; ++e) {
-            unsigned h[4], l[4];
+    auto A_block = [&](int blk) __attribute__((always_inline)) {      // blk = g * 12 + e
+        const int g = blk / 12, e = blk % 12;
+        unsigned h[4], l[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j0 = 16 * (q / 2) + 4 * g + 2 * (q % 2);
-                lbs_split2(Av[e][j0], Av[e][j0 + 1], h[q], l[q]);
-            }
-            dA[(g * 12 + e) * 2] = u32x4{h[0], h[1], h[2], h[3]};
-            dA[(g * 12 + e) * 2 + 1] = u32x4{l[0], l[1], l[2], l[3]};
+        for (int q = 0; q < 4; ++q) {
+            const int j0 = 16 * (q / 2) + 4 * g + 2 * (q % 2);
+            lbs_split2(A_at(e, j0), A_at(e, j0 + 1), h[q], l[q]);
         }
+        dA[blk * 2] = u32x4{h[0], h[1], h[2], h[3]};
+        dA[blk * 2 + 1] = u32x4{l[0], l[1], l[2], l[3]};
+    };
+    if constexpr (Tree::STATIC) static_for<48>([&](auto bc) __attribute__((always_inline)) { A_block(decltype(bc)::value); });
+    else for (int blk = 0; blk < 48; ++blk) A_block(blk);
     const int njt = NJ + a.NE;
-    for (int j = 0; j < NJ; ++j)
+    for_joints<Tree, 0>([&](int j) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
             if (a.Gt) a.Gt[n * (NJ * 3) + 3 * j + e] = Gt[j][e];
             if (a.joints) a.joints[(n * njt + j) * 3 + e] = Gt[j][e];
         }
+    });
 }
+extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_split_kernel(PndfLbsSplitArgs sa) { lbs_pose_split_body<ModelTree>(sa); }
+extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_split_smpl_kernel(PndfLbsSplitArgs sa) { lbs_pose_split_body<SmplTree>(sa); }
 
 // ------------------------------------------------------------------ per (16 vertices x 16 frames) tile, split precision
 template <int MODE>      // 0: vertices / vertex-picked joints out   1: the two fused terms and their reverse pass
@@ -1040,6 +1216,7 @@ struct pndf_lbs_model {
     float p_scale = 1.f, w_scale = 1.f, a_scale = 1.f;      // powers of two: model and joint-transform operands
     float w_rowsum = 1.f;             // max_v sum_j |W[v, j]|                        (bounds |T_R^T g|)
     float vp_bound = 1.f;             // max_v,c |v_shaped| + 2 sum_k |posedirs|      (bounds |v_posed|)
+    bool smpl_tree = false;           // the kinematic tree is SMPL's own: per-frame kernels with the tree as a compile-time table
     PndfLbsModel consts;
     int sm_count = 256;
     std::string err;
@@ -1236,7 +1413,11 @@ extern "C" int pndf_lbs_create(pndf_lbs_handle* out, int32_t V, int32_t NB, cons
     h->sm_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     memcpy(h->consts.J, J, sizeof(J));
     memcpy(h->consts.rel, rel, sizeof(rel));
-    for (int j = 0; j < NJ; ++j) h->consts.parent[j] = parents[j];
+    h->smpl_tree = true;
+    for (int j = 0; j < NJ; ++j) {
+        h->consts.parent[j] = parents[j];
+        h->smpl_tree = h->smpl_tree && (j == 0 || parents[j] == SmplTree::tab[j]);
+    }
     hipError_t e = hipMalloc((void**)&h->d_blob, blob.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(h->d_blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
     {
@@ -1375,26 +1556,34 @@ static int lbs_launch(pndf_lbs_model* h, int mode, PndfLbsArgs& a, void* workspa
         sa.gpf_true = (1.0f / h->p_scale) / sa.g_scale;
         sa.gA_true = (1.0f / h->w_scale) / sa.x_scale;
         const int lds_s = 3 * PNDF_LBS_SB_BYTES;
-        hipLaunchKernelGGL(pndf_lbs_pose_split_kernel, fgrid, fblock, 0, (hipStream_t)stream, sa);
+        if (h->smpl_tree) hipLaunchKernelGGL(pndf_lbs_pose_split_smpl_kernel, fgrid, fblock, 0, (hipStream_t)stream, sa);
+        else hipLaunchKernelGGL(pndf_lbs_pose_split_kernel, fgrid, fblock, 0, (hipStream_t)stream, sa);
         if (mode == 0) {
             if (a.verts || (a.joints && a.NE > 0))
                 hipLaunchKernelGGL(pndf_lbs_vertex_split_forward_kernel, sgrid, vblock, lds_s, (hipStream_t)stream, sa);
         } else {
             hipLaunchKernelGGL(pndf_lbs_vertex_split_terms_kernel, sgrid, vblock, lds_s, (hipStream_t)stream, sa);
-            hipLaunchKernelGGL(pndf_lbs_pose_backward_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
+            if (h->smpl_tree) {
+                hipLaunchKernelGGL(pndf_lbs_pose_backward_smpl_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
+                hipLaunchKernelGGL(pndf_lbs_rodrigues_vjp_kernel, dim3((unsigned)((N * (NJ - 1) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+            } else hipLaunchKernelGGL(pndf_lbs_pose_backward_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
         }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return lbs_fail(h, PNDF_ERR_HIP, std::string("launch: ") + hipGetErrorString(e));
         return PNDF_OK;
     }
-    hipLaunchKernelGGL(pndf_lbs_pose_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
+    if (h->smpl_tree) hipLaunchKernelGGL(pndf_lbs_pose_smpl_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(pndf_lbs_pose_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
     if (mode == 0) {
         if (a.verts || (a.joints && a.NE > 0))
             hipLaunchKernelGGL(pndf_lbs_vertex_forward_kernel, vgrid, vblock, lds, (hipStream_t)stream, a);
     } else {
         if (mode == 1) hipLaunchKernelGGL(pndf_lbs_vertex_terms_kernel, vgrid, vblock, lds, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(pndf_lbs_vertex_reverse_kernel, vgrid, vblock, lds, (hipStream_t)stream, a);
-        hipLaunchKernelGGL(pndf_lbs_pose_backward_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
+        if (h->smpl_tree) {
+            hipLaunchKernelGGL(pndf_lbs_pose_backward_smpl_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
+            hipLaunchKernelGGL(pndf_lbs_rodrigues_vjp_kernel, dim3((unsigned)((N * (NJ - 1) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+        } else hipLaunchKernelGGL(pndf_lbs_pose_backward_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lbs_fail(h, PNDF_ERR_HIP, std::string("launch: ") + hipGetErrorString(e));

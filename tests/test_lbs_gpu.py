@@ -209,3 +209,24 @@ def test_denoise_motion_file_script_level(smpl_like, tmp_path):
     want = np.sqrt(((V64 - G64) ** 2).sum(-1)).mean() * 100.0
     assert abs(err - want) < 1e-3 * want
     assert abs(v2v_error_cm(bm, load_motion_npz(tmp_path / "gt.npz"), load_motion_npz(tmp_path / "gt.npz"))) < 1e-6
+
+
+@pytest.mark.parametrize("lbs_precision", ["f16x3", "fp32"])
+def test_other_kinematic_tree_takes_the_generic_per_frame_kernels(lbs_precision):
+    """SMPL's own tree runs on per-frame kernels that hold it as a compile-time table (everything in registers); any other valid
+    tree (parents before children) on the generic ones.  A chain with two side branches, against the oracle."""
+    from posendf_amd import BodyModel
+    parents = (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 3, 20, 7, 22)
+    m = lbs_np.synthetic_model(V=137, seed=9, parents=parents, extra=(5, 60, 136))
+    bm = BodyModel(m, device="cuda:0", precision=lbs_precision)
+    th = _theta(2, 19, seed=4) * 0.4
+    out = bm(pose_body=torch.from_numpy(th.reshape(-1, 69)))
+    V64, J64 = lbs_np.lbs(th.reshape(-1, 69), m)
+    assert _rel(out.vertices.cpu().numpy(), V64) < 1e-5 and _rel(out.Jtr.cpu().numpy(), J64) < 1e-5
+    th0 = th + 0.03
+    j0 = bm.joints_of(torch.from_numpy(th0))
+    g = bm.terms_grad(torch.from_numpy(th).cuda(), j0, 2).cpu().numpy()
+    for s_ in range(2):
+        _, J0 = lbs_np.lbs(th0[s_], m)
+        g64, _ = lbs_np.body_terms(th[s_], J0, m, 2)
+        assert np.abs(g[s_] - g64).max() < TOL * np.abs(g64).max()
