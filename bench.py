@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpu-torch-baseline", action="store_true")
+    ap.add_argument("--lbs-torch-baseline", action="store_true", help="also time a PyTorch restatement of the body-model terms (4 x 300 frames)")
     ap.add_argument("--no-motion-denoise", action="store_true", help="skip the configs[4] side block")
     ap.add_argument("--no-parity-sample", action="store_true", help="skip the oracle check of a sample of the timed result")
     args = ap.parse_args()
@@ -361,6 +362,40 @@ def main():
         tf = S * T * flop / (ms_lbs * 1e-3) / 1e12
         split = bm.precision == "f16x3"
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+        torch_ref = None
+        if args.lbs_torch_baseline:
+            # (opt-in: PyTorch 2.10+rocm7.0 dies with a GPU memory-access fault in this pass at 4,800 frames and above)
+            # the same body-model terms + autograd as stock PyTorch-ROCm executes them (oracle/lbs_torch.py: smplx's lbs() restated
+            # op by op, fp32) on the same GPU and the same poses -- a comparator, like `gpu_torch_baseline` of the headline
+            from oracle.lbs_torch import torch_lbs
+            bm_np = synth.make_body_model(seed=11)
+
+            St = 4       # 1,200 frames: the largest size tried that stock PyTorch survives (16 x 300 and 64 x 300 fault)
+
+            def torch_pass():
+                th = theta[:St].reshape(-1, 69).detach().clone().requires_grad_(True)
+                verts, joints = torch_lbs(th, bm_np, torch.float32)
+                verts, joints = verts.view(St, T, -1, 3), joints.view(St, T, -1, 3)
+                loss = 30.0 * torch.mean(torch.sqrt(torch.sum((verts[:, :-1] - verts[:, 1:]) ** 2, dim=3))) \
+                    + 100.0 / 3.0 * torch.mean(torch.sqrt(torch.sum((joints - j0.view(S, T, -1, 3)[:St]) ** 2, dim=3)))
+                loss.backward()
+                return th.grad
+
+            g_t = torch_pass()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(2):
+                g_t = torch_pass()
+            e1.record()
+            torch.cuda.synchronize()
+            ms_t = e0.elapsed_time(e1) / 2
+            scale = out[:St].abs().max().item()
+            torch_ref = {"what": f"PyTorch-ROCm fp32 restatement of smplx lbs() + the two terms + autograd (oracle/lbs_torch.py), same GPU, "
+                                 f"the first {St} of the {S} sequences (larger calls end in a GPU memory-access fault inside PyTorch), "
+                                 "weights of iteration 2",
+                         "sequences": St, "ms": ms_t, "ms_per_sequence": ms_t / St,
+                         "speedup_of_body_model_pass_per_sequence": (ms_t / St) / (ms_lbs / S), "torch": torch.__version__,
+                         "max_abs_diff_of_gradient_rel": (g_t.view(St, T, 69) * St - out[:St]).abs().max().item() / max(scale, 1e-30)}
         return {"workload": f"BASELINE.json configs[4], one GPU's share: {S} sequences x {T} frames, reference objective (pose prior + "
                             "SMPL vertex temporal term + joint data term), synthetic SMPL-shaped body model, fused Adam steps",
                 "fused_adam_step_ms": ms_step, "frames_per_s": S * T / (ms_step * 1e-3),
@@ -368,6 +403,7 @@ def main():
                                     "precision": bm.precision, "ms": ms_lbs, "bound": "mfma",
                                     "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                                     "mfma_issued_per_algorithmic_flop": 3 if split else 1, "algorithmic_flop_per_frame": flop},
+                "gpu_torch_baseline": torch_ref,
                 "finite": bool(torch.isfinite(res).all()), "parity": "unpinned (smplx is third-party and absent; oracle/lbs_np.py)"}
 
     denoise = motion_denoise_block() if (side and not args.no_motion_denoise and args.act != "softplus") else None

@@ -10,42 +10,7 @@ import torch
 
 from lane_model import G, LANES, P, mfma_16x16x4
 from oracle import lbs_np
-
-
-def torch_lbs(theta, m):
-    """smplx lbs() / SMPL.forward restated with torch ops (fp64), for autograd."""
-    dt = torch.float64
-    pad = torch.nn.functional.pad
-    vt, sd, b = (torch.tensor(m[k], dtype=dt) for k in ("v_template", "shapedirs", "betas"))
-    v_shaped = vt + torch.einsum("l,mkl->mk", b, sd)
-    Jr = torch.tensor(m["J_regressor"], dtype=dt) @ v_shaped
-    N = theta.shape[0]
-    full = torch.cat([torch.zeros(N, 3, dtype=dt), theta], 1).reshape(-1, 3)
-    angle = torch.norm(full + 1e-8, dim=1, keepdim=True)
-    rd = full / angle
-    cos, sin = torch.cos(angle)[:, None], torch.sin(angle)[:, None]
-    rx, ry, rz = rd[:, 0:1], rd[:, 1:2], rd[:, 2:3]
-    z = torch.zeros_like(rx)
-    K = torch.cat([z, -rz, ry, rz, z, -rx, -ry, rx, z], 1).view(-1, 3, 3)
-    R = (torch.eye(3, dtype=dt)[None] + sin * K + (1 - cos) * torch.bmm(K, K)).view(N, 24, 3, 3)
-    pf = (R[:, 1:] - torch.eye(3, dtype=dt)).reshape(N, -1)
-    v_posed = (pf @ torch.tensor(m["posedirs"], dtype=dt)).view(N, -1, 3) + v_shaped[None]
-    parents = m["parents"]
-    rel = Jr.clone()
-    rel[1:] = rel[1:] - Jr[parents[1:]]
-    M = torch.cat([pad(R.reshape(-1, 3, 3), [0, 0, 0, 1]),
-                   pad(rel[None].expand(N, -1, -1).reshape(-1, 3, 1), [0, 0, 0, 1], value=1)], dim=2).reshape(N, 24, 4, 4)
-    chain = [M[:, 0]]
-    for i in range(1, 24):
-        chain.append(chain[parents[i]] @ M[:, i])
-    Gm = torch.stack(chain, 1)
-    jh = pad(Jr[None, :, :, None].expand(N, -1, -1, -1), [0, 0, 0, 1])
-    A = Gm - pad(Gm @ jh, [3, 0, 0, 0, 0, 0, 0, 0])
-    Tm = (torch.tensor(m["lbs_weights"], dtype=dt)[None] @ A.view(N, 24, 16)).view(N, -1, 4, 4)
-    vh = torch.cat([v_posed, torch.ones(N, v_posed.shape[1], 1, dtype=dt)], 2)
-    verts = (Tm @ vh[..., None])[:, :, :3, 0]
-    joints = torch.cat([Gm[:, :, :3, 3], verts[:, torch.tensor(m["extra_joint_vertex"]).long()]], 1)
-    return verts, joints
+from oracle.lbs_torch import torch_lbs
 
 
 def _theta(T, seed=0, scale=0.3):
