@@ -21,8 +21,9 @@
 // forward and fused-terms passes -- fp16 MFMAs on operands split into hi + lo halves (PNDF_LBS_F16X3, "split precision" below:
 // 212 MFMAs of 16 cycles per tile instead of 480 of 32).
 //
-// Three kernels:
+// Three stages (fp32 form; the split-precision vertex kernels are described at their section):
 //   pndf_lbs_pose_kernel            one thread per frame: Rodrigues, transform chain -> pose feature, A, posed joints
+//                                   (_smpl_: SMPL's own tree as a compile-time table -- arrays in registers, no scratch)
 //   pndf_lbs_vertex_kernel<MODE>    one wave per chunk of 16 frames, four chunks per workgroup sharing the model stream:
 //       the packed model ("blob": 42 KiB per 16 vertices, lane-linear MFMA tiles) is streamed global -> LDS by DMA into
 //       three buffers (the loop is software-pipelined one group deep), and read TWICE from LDS: as A operand of the forward pose-blend contraction (rows = vertices) and,
@@ -31,6 +32,7 @@
 //       registers (neighbouring frames are neighbouring lanes) and pushed straight back: d L / d pose_feature and
 //       d L / d A accumulate in registers over all vertices.  MODE 2: general reverse pass for given d L / d verts.
 //   pndf_lbs_pose_backward_kernel   one thread per frame: reverse of the transform chain and of Rodrigues -> d L / d theta
+//                                   (SMPL's tree: pndf_lbs_pose_backward_smpl_kernel + pndf_lbs_rodrigues_vjp_kernel)
 // In MODE 1 a chunk is 16 frames = 15 pairs; consecutive chunks share a frame, whose two partial results ("halo") are summed
 // by the last kernel.  Small problems split the vertex range over blockIdx.y (`vsplit`) and sum the partials there too, in
 // a fixed order: results are deterministic.
