@@ -181,3 +181,28 @@ def test_packed_split_model_through_lane_model_of_the_vertex_kernel():
                 got = gA[e][jt][:, r] / (w_scale * X_SCALE)
                 assert np.abs(got[ok] - want_gA[P[ok], j[ok], e]).max() < 1e-5 * np.abs(want_gA).max()
                 assert np.all(got[~ok] == 0)
+
+
+def test_split_packer_scales_for_extreme_magnitudes_and_null_handle_calls():
+    """The operand scales are powers of two that bring the largest |entry| into [2^12, 2^13) whatever the model's magnitudes
+    (pose-corrective dirs of 1e-9 or 1e+3, weights of 1e-6), an all-zero model does not turn into infinities, and the
+    precision calls refuse a null handle (no device needed)."""
+    from posendf_amd.engine import load_library
+    from test_lbs_oracle import _pack
+    lib = load_library()
+    for pscale, wscale in ((1e-9, 1.0), (1e3, 1e-6), (0.0, 0.0)):
+        m = dict(lbs_np.synthetic_model(V=20, seed=3, extra=(1,)))
+        m["posedirs"] = np.asarray(m["posedirs"], np.float32) * np.float32(pscale)
+        m["lbs_weights"] = np.asarray(m["lbs_weights"], np.float32) * np.float32(wscale)
+        blob, _, _ = _pack(m)
+        sb = np.zeros(lib.pndf_lbs_packed_split_bytes(20), np.uint8)
+        sc = np.zeros(2, np.float32)
+        assert lib.pndf_lbs_pack_split_host(20, blob.ctypes.data, sb.ctypes.data, sc.ctypes.data) == 0
+        assert np.isfinite(sc).all() and (sc > 0).all() and np.all(np.log2(sc.astype(np.float64)) % 1 == 0)
+        halfs16 = sb.reshape(-1, SBB)[:, :SB_VS].reshape(-1).view(np.float16)
+        assert np.isfinite(halfs16.astype(np.float32)).all() and np.abs(halfs16.astype(np.float32)).max() < 2.0 ** 13
+        if pscale > 0:
+            pmax = np.abs(m["posedirs"]).max() * float(sc[0])
+            assert 2.0 ** 12 <= pmax < 2.0 ** 13
+    assert lib.pndf_lbs_set_precision(None, 1) == -1 and lib.pndf_lbs_precision(None) == -1
+    assert lib.pndf_lbs_packed_split_bytes(0) == 0 and lib.pndf_lbs_packed_split_bytes(17) == 2 * SBB
