@@ -47,10 +47,13 @@ def _cpu_model():
     return "unknown CPU"
 
 
-def cpu_baseline(act, sd, proj_steps, budget_s=20.0, runs=3):
-    """The reference's CPU PyTorch path (restated in oracle/posendf_torch.py) on this box's host cores, on a
-    bounded sample of the same workload: the full 100-step projection of as many poses as fit in ~budget_s / runs,
-    `runs` times (median reported), plus BASELINE.json configs[0] (B = 256, forward only, median of 10)."""
+def cpu_baseline(act, sd, proj_steps, budget_s=24.0, runs=3, batch=4096):
+    """The reference's CPU PyTorch path (restated in oracle/posendf_torch.py) on this box's host cores, SURVEY.md 8d:
+    B = 4,096 poses (fixed: matmuls large enough for the threads to have work), thread count chosen by a short
+    calibration over {8, 16, 32, 64} (64 threads on a [742 x 1024] matmul was oversubscription), then
+    `runs` timed projections (median reported).  Every projection step does identical work, so when the full 100 steps
+    at B = 4,096 do not fit the budget the timed run does fewer steps and is scaled linearly -- the sample says so.
+    Plus BASELINE.json configs[0] (B = 256, forward only, median of 10)."""
     import statistics
     import torch
     from oracle.posendf_torch import RefNet, project
@@ -59,23 +62,26 @@ def cpu_baseline(act, sd, proj_steps, budget_s=20.0, runs=3):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
-    torch.set_num_threads(threads)
     net = RefNet(act)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    q = torch.from_numpy(synth.make_poses(4096, seed=1234))
-    for _ in range(3):
-        project(net, q[:256], 1)                                # warm-ups
-    t0 = time.perf_counter()
-    project(net, q[:512], 2)                                    # calibration: pose-steps per second
-    rate = 512 * 2 / (time.perf_counter() - t0)
-    sample_b = int(min(4096, max(64, rate * budget_s / runs / proj_steps)))
+    q = torch.from_numpy(synth.make_poses(batch, seed=1234))
+    candidates = sorted({t for t in (8, 16, 32, 64) if t <= cores} or {max(1, cores)})
+    calib = {}
+    for t in candidates:                                        # calibration: pose-steps per second at B = 4,096, 1 step
+        torch.set_num_threads(t)
+        project(net, q, 1)                                      # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        project(net, q, 1)
+        calib[t] = batch / (time.perf_counter() - t0)
+    threads = max(calib, key=calib.get)
+    torch.set_num_threads(threads)
+    timed_steps = int(min(proj_steps, max(5, calib[threads] * budget_s / runs / batch)))
     times = []
     for _ in range(runs):
         t0 = time.perf_counter()
-        project(net, q[:sample_b], proj_steps)
+        project(net, q, timed_steps)
         times.append(time.perf_counter() - t0)
-    dt = statistics.median(times)
+    dt = statistics.median(times) * proj_steps / timed_steps   # seconds per full projection of the batch
     # configs[0]: batch = 256, PoseNDF.forward() distance only, PyTorch CPU
     q0 = q[:256]
     with torch.no_grad():
@@ -87,13 +93,88 @@ def cpu_baseline(act, sd, proj_steps, budget_s=20.0, runs=3):
             net(q0)
             f_t.append(time.perf_counter() - t0)
     f_med = statistics.median(f_t)
-    return {"value": sample_b / dt, "unit": "projected poses/s", "cores": threads, "kind": "port", "cpu": _cpu_model(),
-            "runs_s": [round(t, 3) for t in times],
-            "sample": f"B={sample_b} poses x {proj_steps} steps, median of {runs} runs = {dt:.1f} s; PyTorch-CPU restatement "
-                      f"of the reference (oracle/posendf_torch.py), {threads} threads on {cores} visible cores of a "
-                      f"{_cpu_model()}",
+    scaled = "" if timed_steps == proj_steps else f" ({timed_steps} steps timed, scaled linearly to {proj_steps}: every step does identical work)"
+    return {"value": batch / dt, "unit": "projected poses/s", "cores": threads, "kind": "port", "cpu": _cpu_model(),
+            "batch": batch, "timed_steps": timed_steps, "runs_s": [round(t, 3) for t in times],
+            "thread_calibration_pose_steps_per_s": {str(t): round(v, 1) for t, v in calib.items()},
+            "sample": f"B={batch} poses x {proj_steps} steps{scaled}, median of {runs} runs = {dt:.1f} s per projection; "
+                      f"PyTorch-CPU restatement of the reference (oracle/posendf_torch.py), {threads} threads (best of "
+                      f"{candidates} in a one-step calibration) on {cores} visible cores of a {_cpu_model()}",
             "config0_forward_only": {"workload": "BASELINE.json configs[0]: batch=256, forward() distance only, PyTorch CPU",
                                      "ms": f_med * 1e3, "poses_per_s": 256 / f_med, "runs": 10}}
+
+
+class GpuTelemetry:
+    """Shader clock and package power of the device while the timed loop runs, sampled by a host thread from the amdgpu
+    hwmon files (no subprocess inside the timed region; rocm-smi --showpower --showclocks once as the fallback).  The
+    split kernels are power-bound: two boxes can only be compared with these beside the time."""
+
+    def __init__(self, index=0, period_s=0.05):
+        import glob
+        self.period = period_s
+        self.samples = []
+        self.src = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        amd = [c for c in cards if os.path.exists(os.path.join(c, "freq1_input"))
+               and (os.path.exists(os.path.join(c, "power1_average")) or os.path.exists(os.path.join(c, "power1_input")))]
+        if amd:
+            h = amd[min(index, len(amd) - 1)]
+            self.src = (os.path.join(h, "freq1_input"),
+                        os.path.join(h, "power1_average" if os.path.exists(os.path.join(h, "power1_average")) else "power1_input"))
+        self._stop = None
+        self._thread = None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def start(self):
+        if self.src is None:
+            return
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                f, p = self._read(self.src[0]), self._read(self.src[1])
+                if f is not None and p is not None:
+                    self.samples.append((f / 1e6, p / 1e6))      # Hz -> MHz, uW -> W
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+
+    def summary(self):
+        import statistics
+        if self.samples:
+            return {"sclk_mhz": statistics.median(s[0] for s in self.samples),
+                    "package_w": statistics.median(s[1] for s in self.samples), "telemetry_samples": len(self.samples),
+                    "telemetry_source": "amdgpu hwmon (freq1_input, power1_average), median over the timed loop"}
+        return {"sclk_mhz": None, "package_w": None, "telemetry_samples": 0, "telemetry_source": "unavailable"}
+
+
+def smi_snapshot():
+    """One rocm-smi reading (fallback when the hwmon files are absent); called while a launch is in flight."""
+    import re
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+    except (OSError, subprocess.SubprocessError):
+        return None
+    sclk = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+    power = re.search(r"Package Power \(W\): ([0-9.]+)", out)
+    if not (sclk and power):
+        return None
+    return {"sclk_mhz": float(sclk.group(1)), "package_w": float(power.group(1)), "telemetry_samples": 1,
+            "telemetry_source": "rocm-smi --showpower --showclocks, one reading during the timed loop"}
 
 
 def gpu_torch_baseline(act, sd, B, proj_steps, dev, timed_steps=5):
@@ -127,7 +208,7 @@ def self_launch(args):
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not (have and os.environ.get("PNDF_BENCH_SHARE_DEVICE") == "1"):      # (tests: ranks share devices)
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible; refusing to report a smaller job as N={args.gpus}")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -152,7 +233,13 @@ def main():
                          "headline")
     ap.add_argument("--no-fp32-ref", action="store_true",
                     help="skip the short exact-fp32 and plain-f16 runs reported beside f16x3")
-    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work")
+    ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of CPU baseline work")
+    ap.add_argument("--workload", default="project", choices=["project", "denoise"],
+                    help="project (default): BASELINE.json configs[2]/[3], the headline; denoise: configs[4], whole sequences "
+                         "sharded over the ranks, fused Adam steps of the reference's objective, final gather of the poses")
+    ap.add_argument("--seqs", type=int, default=64, help="--workload denoise: sequences per GPU (configs[4]: 512 over 8 GPUs)")
+    ap.add_argument("--frames", type=int, default=300, help="--workload denoise: frames per sequence")
+    ap.add_argument("--adam-steps", type=int, default=10, help="--workload denoise: Adam steps per harness step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpu-torch-baseline", action="store_true")
     ap.add_argument("--lbs-torch-baseline", action="store_true", help="also time a PyTorch restatement of the body-model terms (4 x 300 frames)")
@@ -180,21 +267,33 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs; the engine has no CPU path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # One rank per GPU.  PNDF_BENCH_SHARE_DEVICE=1 (tests only) lets several ranks share the visible devices round-robin:
+    # a one-GPU box can then run the REAL multi-process path -- N processes, rank / offset / gather / max-over-ranks --
+    # with PNDF_BENCH_BACKEND=gloo (RCCL refuses two ranks on one device; gloo does not).  The line then says so.
+    shared = os.environ.get("PNDF_BENCH_SHARE_DEVICE") == "1"
+    ndev = torch.cuda.device_count()
+    if local >= ndev and not shared:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {ndev} device(s) visible")
+    dev_index = local % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
+    backend = os.environ.get("PNDF_BENCH_BACKEND", "nccl")                   # nccl IS RCCL on ROCm
     use_dist = world > 1 or os.environ.get("PNDF_BENCH_FORCE_DIST") == "1"   # the flag exercises RCCL with 1 rank
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     sd = synth.make_weights(0, 2.0, 0.1)                        # BASELINE.md section 3 "live regime"
     precision = "fp32" if (args.act == "softplus" and args.precision == "f16") else args.precision
 
     def build(prec, act=None, weights=None):
-        cfg = amass_config(act or args.act, f"cuda:{local}")
+        cfg = amass_config(act or args.act, f"cuda:{dev_index}")
         cfg["engine"] = {"precision": prec}
         m = PoseNDF(cfg)
         m.load_state_dict({k: torch.from_numpy(v) for k, v in (weights or sd).items()})
@@ -203,43 +302,115 @@ def main():
 
     net = build(precision)
     B = args.batch
-    # shard `rank` of the global batch: reference input distribution (sample_poses.py:96-97), seeded
-    q0 = torch.from_numpy(synth.make_poses(B, seed=1234, offset=rank)).to(dev)
     from posendf_amd.sharding import all_gather_blocks
+    if args.workload == "project":
+        # shard `rank` of the global batch: reference input distribution (sample_poses.py:96-97), seeded
+        q0 = torch.from_numpy(synth.make_poses(B, seed=1234, offset=rank)).to(dev)
+        rows = B                                                # rows of the gathered tensor this rank contributes
+
+        def hot():                                              # the dominant kernel: ONE persistent launch
+            return net.project(q0, steps=args.proj_steps)
+        out_shape = (21, 4)
+    else:
+        # BASELINE.json configs[4]: whole sequences per rank (experiments/motion_denoise.py:171-188 loops sequences), the
+        # reference's objective (pose prior on the engine + SMPL-shaped body model terms), fused Adam steps, no collective
+        # until the final gather of the denoised poses (sharding.denoise_sharded)
+        from posendf_amd import BodyModel
+        from posendf_amd.motion_denoise import MotionDenoise
+        S, T = args.seqs, args.frames
+        bm = BodyModel(synth.make_body_model(seed=11), device=f"cuda:{dev_index}")
+        gen = torch.Generator().manual_seed(1000 + rank)
+        theta = (torch.cumsum(0.02 * torch.randn(S, T, 69, generator=gen), dim=1) + 0.3 * torch.randn(S, 1, 69, generator=gen)
+                 + 0.1 * torch.randn(S, T, 69, generator=gen)).to(dev)
+        md = MotionDenoise(net, body_model=bm, device=f"cuda:{dev_index}")
+        rows = S
+        half = max(1, args.adam_steps // 2)                     # two outer iterations: the second one has the data term (:92)
+
+        def hot():
+            out, _ = md.denoise(theta, iterations=2, steps_per_iter=half, fused=True, record=False)
+            return out, None
+        out_shape = (T, 69)
     # receive buffer of the final gather, allocated once: equal blocks go straight into it (all_gather_into_tensor)
-    gathered = torch.empty((B * world, 21, 4), device=dev, dtype=torch.float32) if use_dist else None
+    gathered = torch.empty((rows * world,) + out_shape, device=dev, dtype=torch.float32) if use_dist else None
 
     def one_pass():
-        qp, d = net.project(q0, steps=args.proj_steps)
+        qp, d = hot()
         if use_dist:
-            all_gather_blocks(qp, B * world, out=gathered)      # the only collective: final gather over xGMI
+            all_gather_blocks(qp, rows * world, out=gathered)   # the only collective: final gather over xGMI
         return qp, d
 
     for _ in range(args.warmup):
         one_pass()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
+    tele = GpuTelemetry(dev_index)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    tele.start()
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        qp, d = net.project(q0, steps=args.proj_steps)          # the dominant kernel, bracketed by HIP events
+        qp, d = hot()                                           # bracketed by HIP events on the launch stream
         ev[k][1].record()
         if use_dist:
-            all_gather_blocks(qp, B * world, out=gathered)
+            all_gather_blocks(qp, rows * world, out=gathered)
+        ev[k][2].record()
+    smi = smi_snapshot() if (tele.src is None and rank == 0 and args.steps) else None      # (launches still in flight)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    tele.stop()
+    telemetry = tele.summary() if tele.samples or smi is None else smi
+    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) if args.steps else float("nan")
+    gather_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if (args.steps and use_dist) else 0.0
+    per_rank = None
     if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        # every rank's own numbers travel to rank 0, so that the line PROVES its rank count
+        # the gathered buffer holds every rank's block in rank order: each rank finds its own result in its own window
+        own = bool(torch.equal(gathered[rank * rows:(rank + 1) * rows], qp)) if args.steps else None
+        mine = {"rank": rank, "local_rank": local, "device": dev_index, "pid": os.getpid(), "elapsed_s": elapsed,
+                "kernel_ms": kern_ms, "gather_ms": gather_ms, "rows": rows, "own_block_in_gather": own}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        t = torch.tensor([elapsed, kern_ms], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        k = torch.tensor([kern_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kern_ms = float(k.item())
+        elapsed, kern_ms = float(t[0].item()), float(t[1].item())
+        if rank == 0 and args.steps and not all(r["own_block_in_gather"] for r in per_rank):
+            raise SystemExit(f"final gather misplaced a block: {per_rank}")
+    dist_info = None
+    if use_dist:
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices_visible": ndev,
+                     "ranks_share_devices": bool(shared and world > ndev), "gather_ms": gather_ms, "per_rank": per_rank,
+                     "gathered_rows": int(gathered.shape[0])}
+
+    if args.workload == "denoise":
+        if rank == 0:
+            frames = S * T * world
+            steps_done = 2 * half
+            out = {"metric": "motion-denoise frame-steps/sec (configs[4]: Adam steps of the reference's objective)",
+                   "value": frames * steps_done * args.steps / elapsed, "unit": "frame-steps/s", "n_gpus": world,
+                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": KERNELS[precision][2], "data": "synthetic",
+                   "config": {"workload": f"BASELINE.json configs[4]: {S} sequences/GPU x {T} frames, {steps_done} fused Adam steps per "
+                                          f"harness step (2 outer iterations), pose prior ({precision}, act={args.act}) + "
+                                          "SMPL-shaped synthetic body model (vertex temporal + joint data terms), whole sequences "
+                                          "sharded over the ranks, final all_gather of the denoised poses",
+                              "sequences_total": S * world, "frames": T, "adam_steps_per_step": steps_done,
+                              "parallelism": f"sequence-sharded x{world}, final all_gather" if world > 1 else "single GPU"},
+                   "adam_step_ms": elapsed / max(args.steps, 1) * 1e3 / steps_done,
+                   "finite": bool(torch.isfinite(qp).all()), "telemetry": telemetry,
+                   "parity": "pose prior pinned; body model unpinned (smplx is third-party and absent; oracle/lbs_np.py)"}
+            if dist_info is not None:
+                out["distributed"] = dist_info
+            json_line = json.dumps(out)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            os.write(json_fd, (json_line + "\n").encode())
+        os.close(json_fd)
+        return
 
     # What was timed is also CHECKED: a sample of the projected poses of the last timed pass against the oracle's fp64
     # trajectory of the same inputs, with the reference arithmetic's own fp32 trajectory beside it (outside the timed region;
@@ -336,7 +507,7 @@ def main():
     def motion_denoise_block(S=64, T=300):
         from posendf_amd import BodyModel
         from posendf_amd.motion_denoise import MotionDenoise
-        bm = BodyModel(synth.make_body_model(seed=11), device=f"cuda:{local}")
+        bm = BodyModel(synth.make_body_model(seed=11), device=f"cuda:{dev_index}")
         g = torch.Generator().manual_seed(0)
         theta = (torch.cumsum(0.02 * torch.randn(S, T, 69, generator=g), dim=1) + 0.3 * torch.randn(S, 1, 69, generator=g)
                  + 0.1 * torch.randn(S, T, 69, generator=g)).to(dev)
@@ -351,11 +522,11 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms_lbs = e0.elapsed_time(e1) / 5
-        md = MotionDenoise(net, body_model=bm, device=f"cuda:{local}")
-        md.optimize(theta, iterations=1, steps_per_iter=2, fused=True)
+        md = MotionDenoise(net, body_model=bm, device=f"cuda:{dev_index}")
+        md.denoise(theta, iterations=1, steps_per_iter=2, fused=True)
         torch.cuda.synchronize()
         t = time.perf_counter()
-        res, _ = md.optimize(theta, iterations=2, steps_per_iter=5, fused=True)
+        res, _ = md.denoise(theta, iterations=2, steps_per_iter=5, fused=True)
         torch.cuda.synchronize()
         ms_step = (time.perf_counter() - t) / 10 * 1e3
         flop = 2 * (2 * 207 * 20670 + 2 * 6890 * 24 * 12)                 # per frame, forward + reverse
@@ -481,9 +652,12 @@ def main():
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)",
                          "algorithmic_bytes_per_launch": B * 676 + 10720 * 1024,
                          "kernel": kname, "kernel_ms": kern_ms,
-                         "kernel_ms_median": float(np.median([a.elapsed_time(b) for a, b in ev])) if args.steps else None,
+                         "kernel_ms_median": float(np.median([e[0].elapsed_time(e[1]) for e in ev])) if args.steps else None,
+                         **telemetry,
                          "algorithmic_flop_per_launch": B * args.proj_steps * FLOP_PER_POSE_STEP},
         }
+        if dist_info is not None:
+            out["distributed"] = dist_info
         if parity is not None:
             out["parity_sample"] = parity
         if host_ms is not None:
@@ -496,6 +670,12 @@ def main():
         if f16_ref is not None:
             out["f16_single"] = f16_ref
         if sp_ref is not None:
+            if not args.no_gpu_torch_baseline:
+                # the reference's scripts load softplus checkpoints (sample_poses.py:115, motion_denoise.py:162-163): the >= 10x
+                # denominator for THIS activation too
+                gts = gpu_torch_baseline("softplus", sd, B, args.proj_steps, dev)
+                gts["speedup_of_softplus_kernel"] = sp_ref["poses_per_s_per_gpu"] / gts["value"]
+                sp_ref["gpu_torch_baseline"] = gts
             out["softplus"] = sp_ref
         if denoise is not None:
             out["motion_denoise_config4"] = denoise

@@ -5,8 +5,8 @@ the HIP linear-blend-skinning kernels of posendf_amd/csrc/pndf_lbs.hip through t
 `pndf_lbs_*`).
 
 The reference builds `smplx.SMPL(bm_path)` from the licensed SMPL model file.  Neither smplx nor the file is reachable
-here, so the model PARAMETERS are supplied by the caller as arrays with the shapes of the SMPL file (`from_arrays`, or
-`from_npz` for a converted model file); the algorithm is smplx's published lbs() restated -- parity unpinned.
+here, so the model PARAMETERS are supplied by the caller as arrays with the shapes of the SMPL file (the constructor
+takes the dict, `from_arrays` keyword arguments, `from_npz` a converted model file); the algorithm is smplx's published lbs() restated -- parity unpinned.
 
 `precision` selects the arithmetic of the forward and fused-terms passes: "f16x3" (default; fp16 MFMAs on operands split
 into hi + lo halves, fp32 accumulate: the distance engine's split arithmetic, fp32-class accuracy) or "fp32" (fp32 MFMAs);
@@ -81,19 +81,27 @@ class BodyModel(torch.nn.Module):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise PndfError("BodyModel runs on the HIP kernels only; no CPU path exists")
+        self.device = torch.device("cuda", self.device.index or 0)      # indexed: compared with tensor.device below
         missing = [k for k in _KEYS if k not in params]
         if missing:
             raise PndfError(f"body-model parameters lack {missing}")
+        if precision not in self.PRECISIONS:      # (before anything is created: nothing to leak on a bad value)
+            raise PndfError(f"precision must be one of {sorted(self.PRECISIONS)}")
         vt = _f32(params["v_template"])
         V = vt.shape[0]
         sd = _f32(params["shapedirs"])[:, :, :num_betas]
         nb = sd.shape[2]
-        b = np.zeros(nb, np.float32) if betas is None else _f32(betas).reshape(-1)[:nb]
+        if betas is None:                         # the model file's own betas, as the oracle's rest_shape() uses them
+            betas = params.get("betas")
+        b = np.zeros(nb, np.float32)
+        if betas is not None:
+            given = _f32(betas).reshape(-1)[:nb]  # shorter than nb: the remaining shape coefficients are zero
+            b[:len(given)] = given
         pd = _f32(params["posedirs"])
         if pd.shape != (207, V * 3):
             raise PndfError(f"posedirs must be [207, {V * 3}] (smplx layout), got {pd.shape}")
         jr, w = _f32(params["J_regressor"]), _f32(params["lbs_weights"])
-        par = np.ascontiguousarray(np.asarray(params["parents"], dtype=np.int32))
+        par = np.array(params["parents"], dtype=np.int32)      # a copy: the caller's table keeps its root entry
         par[0] = -1
         if extra_joint_vertex is None:      # smplx's SMPL always appends its 21 vertex-picked joints (45 in all)
             from .synth import SMPL_EXTRA_JOINT_VERTICES, SMPL_V
@@ -111,8 +119,6 @@ class BodyModel(torch.nn.Module):
             msg = self.lib.pndf_lbs_last_error(None).decode()
             self.handle = None
             raise PndfError(f"pndf_lbs_create failed ({rc}): {msg}")
-        if precision not in self.PRECISIONS:
-            raise PndfError(f"precision must be one of {sorted(self.PRECISIONS)}")
         self._call("pndf_lbs_set_precision", self.PRECISIONS[precision])
         self.precision = precision
         self.num_vertices = V
@@ -120,6 +126,7 @@ class BodyModel(torch.nn.Module):
         self.faces_tensor = None if faces is None else torch.as_tensor(np.asarray(faces, dtype=np.int64), device=self.device)
         self.register_buffer("betas", torch.from_numpy(b.copy()).to(self.device))
         self._ws = {}
+        self._betas_ok = None
 
     @classmethod
     def from_npz(cls, path, **kw):
@@ -128,7 +135,14 @@ class BodyModel(torch.nn.Module):
         z = dict(np.load(path))
         if "weights" in z and "lbs_weights" not in z:
             z["lbs_weights"] = z["weights"]
-        return cls(z, faces=z.get("f"), **kw)
+        kw.setdefault("faces", z.get("f"))
+        return cls(z, **kw)
+
+    @classmethod
+    def from_arrays(cls, v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights, **kw):
+        """The six arrays of an SMPL model file by name (shapes as in smplx: [V,3], [V,3,NB], [207,3V], [24,V], [24], [V,24])."""
+        return cls(dict(v_template=v_template, shapedirs=shapedirs, posedirs=posedirs, J_regressor=J_regressor,
+                        parents=parents, lbs_weights=lbs_weights), **kw)
 
     # ---- plumbing -------------------------------------------------------------------------------
     def _stream(self, device):
@@ -142,6 +156,17 @@ class BodyModel(torch.nn.Module):
         if buf is None or buf.numel() < need:
             buf = self._ws[device] = torch.empty(need, device=device, dtype=torch.float32)
         return buf.data_ptr()
+
+    def _device_f32(self, t, what, coerce=True):
+        """The C ABI takes raw pointers: float32, contiguous, on this model's device.  Inputs are coerced (a copy when
+        needed); an output buffer must already be right, a copy would swallow the result."""
+        ok = t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device
+        if ok:
+            return t
+        if not coerce:
+            raise PndfError(f"{what} must be a contiguous float32 tensor on {self.device}, got {t.dtype} "
+                            f"{'contiguous' if t.is_contiguous() else 'strided'} on {t.device}")
+        return t.detach().to(self.device, torch.float32).contiguous()
 
     def _call(self, name, *args):
         rc = getattr(self.lib, name)(self.handle, *args)
@@ -163,13 +188,21 @@ class BodyModel(torch.nn.Module):
     def forward(self, root_orient=None, pose_body=None, betas=None, return_dict=False, **kwargs):
         if root_orient is not None:
             raise PndfError("root_orient is SMPL's zero global_orient parameter here (the reference passes None)")
-        if (betas is not None and self.betas.numel() > 0
-                and torch.count_nonzero(betas.to(self.betas.device).reshape(-1, self.betas.numel()) - self.betas)):
-            raise PndfError("betas are fixed at construction (motion_denoise.py:27,67: zeros, requires_grad False)")
+        if betas is not None and self.betas.numel() > 0:
+            # the reference passes the same (zero) betas tensor every step (motion_denoise.py:27,86): compared once per
+            # tensor version, not once per call -- the comparison is a host sync
+            key = (betas.data_ptr(), betas._version, tuple(betas.shape))
+            if key != self._betas_ok:
+                if torch.count_nonzero(betas.detach().to(self.betas.device).reshape(-1, self.betas.numel()) - self.betas):
+                    raise PndfError("betas are fixed at construction (motion_denoise.py:27,67: zeros, requires_grad False)")
+                self._betas_ok = key
         pose_body = pose_body.to(self.device)
         verts, joints = _Lbs.apply(pose_body, self)
+        # smplx hands back the caller's own tensor: the reference feeds `smpl_init.body_pose` into the next step (:86), and a
+        # fresh view per step would chain one ViewBackward node per step onto the leaf
+        body_pose = pose_body if (pose_body.dim() == 2 and pose_body.shape[1] == 69) else pose_body.reshape(-1, 69)
         out = {"vertices": verts, "faces": self.faces_tensor, "betas": self.betas, "Jtr": joints,
-               "body_pose": pose_body.reshape(-1, 69), "full_pose": None}
+               "body_pose": body_pose, "full_pose": None}
         return out if return_dict else SimpleNamespace(**out)
 
     # ---- fused objective terms (motion_denoise.py:86-94 with their reverse pass, one launch sequence) -------------------
@@ -186,8 +219,17 @@ class BodyModel(torch.nn.Module):
     def terms_grad(self, theta, joints0, it, out=None, coefs=None):
         """theta [S,T,69], joints0 [S*T, num_joints, 3] -> d (10 (1+it) temp + [it>0] 100/(1+it) data) / d theta [S,T,69];
         `coefs` = (temp_coef, data_coef) replaces the motion_denoise.py schedule (data_coef 0: no data term)."""
+        if theta.dim() != 3 or theta.shape[-1] != 69:
+            raise PndfError(f"theta must be [S, T, 69], got {tuple(theta.shape)}")
         S, T = theta.shape[:2]
-        g = torch.empty_like(theta) if out is None else out
+        theta = self._device_f32(theta, "theta")
+        g = torch.empty_like(theta) if out is None else self._device_f32(out, "out", coerce=False)
+        if g.shape != theta.shape:
+            raise PndfError(f"out must have theta's shape {tuple(theta.shape)}, got {tuple(g.shape)}")
+        if joints0 is not None:
+            joints0 = self._device_f32(joints0, "joints0")
+            if joints0.numel() != S * T * self.num_joints * 3:
+                raise PndfError(f"joints0 must hold S*T*{self.num_joints}*3 = {S * T * self.num_joints * 3} floats, got {joints0.numel()}")
         j0 = None if joints0 is None else joints0.data_ptr()
         if coefs is None:
             self._call("pndf_lbs_terms_grad", theta.data_ptr(), j0, S, T, int(it), g.data_ptr(),

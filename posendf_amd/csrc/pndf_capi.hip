@@ -558,16 +558,19 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
 }
 
 extern "C" int pndf_forward(pndf_handle h, const float* q, float* d, int64_t B, void* stream) {
+    PndfRange range("pndf_forward");
     return launch(h, MODE_FORWARD, q, nullptr, nullptr, d, B, 1, nullptr, stream);
 }
 
 extern "C" int pndf_forward_grad(pndf_handle h, const float* q, const float* grad_out, float* d, float* dq,
                                  int64_t B, void* stream) {
+    PndfRange range("pndf_forward_grad");
     return launch(h, MODE_FORWARD_GRAD, q, grad_out, dq, d, B, 1, nullptr, stream);
 }
 
 extern "C" int pndf_project(pndf_handle h, const float* q_in, float* q_out, float* d_last, int64_t B, int steps,
                             void* stream) {
+    PndfRange range("pndf_project");
     return launch(h, MODE_PROJECT, q_in, nullptr, q_out, d_last, B, steps, nullptr, stream);
 }
 

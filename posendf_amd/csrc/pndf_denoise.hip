@@ -148,6 +148,7 @@ extern "C" __global__ void __launch_bounds__(WG) pndf_denoise_update_kernel(Pndf
 
 // ------------------------------------------------------------------ C ABI (include/posendf_amd.h)
 extern "C" int pndf_aa2quat(const float* theta, float* q, int64_t N, void* stream) {
+    PndfRange range("pndf_aa2quat");
     if (N < 0 || (N > 0 && (!theta || !q))) return -1;
     if (((uintptr_t)q) & 15) return -1;
     if (N == 0) return 0;
@@ -199,6 +200,7 @@ extern "C" int pndf_denoise_update(const float* theta_in, float* theta_out, cons
 extern "C" int pndf_denoise_update_w(const float* theta_in, float* theta_out, const float* theta0, const float* d, const float* dq,
                                      const float* g_body, float* m, float* v, float* q_next, int32_t S, int32_t T,
                                      const pndf_denoise_weights* w, int32_t adam_step, float lr, void* stream) {
+    PndfRange range("pndf_denoise_update_w");
     if (!w) return -1;
     return denoise_update(theta_in, theta_out, theta0, d, dq, m, v, q_next, g_body, S, T, *w, adam_step, lr, stream);
 }

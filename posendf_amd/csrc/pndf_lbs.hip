@@ -1326,7 +1326,13 @@ extern "C" int pndf_lbs_pack_host(int32_t V, int32_t NB, const float* v_template
     const int NG = (V + GV - 1) / GV;
     std::vector<int> flag((size_t)NG * GV, -2);
     for (int v = 0; v < V; ++v) flag[v] = -1;
-    for (int e = 0; e < n_extra; ++e) flag[extra_joint_vertex[e]] = e;      // (a vertex picked twice keeps the last index)
+    // The vertex kernels find a vertex-picked joint through this per-vertex flag, i.e. one joint per vertex: a vertex named
+    // twice would leave the earlier joint's row unwritten (smplx's VertexJointSelector is an index_select and would serve
+    // both).  SMPL's own table has no duplicates; anything else is refused rather than half served.
+    for (int e = 0; e < n_extra; ++e) {
+        if (flag[extra_joint_vertex[e]] >= 0) return PNDF_ERR_BAD_ARG;
+        flag[extra_joint_vertex[e]] = e;
+    }
     memset(blob, 0, (size_t)NG * BLOB * sizeof(float));
     const int npf = 9 * (NJ - 1);
     for (int grp = 0; grp < NG; ++grp) {
@@ -1407,7 +1413,7 @@ extern "C" int pndf_lbs_create(pndf_lbs_handle* out, int32_t V, int32_t NB, cons
                                       extra_joint_vertex, n_extra, blob.data(), J, rel);
     if (rc == PNDF_ERR_UNSUPPORTED)
         return lbs_fail(nullptr, rc, "kinematic tree: 24 joints, parents[0] = -1 and every parent before its children (SMPL)");
-    if (rc != PNDF_OK) return lbs_fail(nullptr, rc, "null pointer, or an extra-joint vertex outside [0, V), or more than 32 of them");
+    if (rc != PNDF_OK) return lbs_fail(nullptr, rc, "null pointer, or an extra-joint vertex outside [0, V) or named twice, or more than 32 of them");
     DeviceGuard guard(device);
     if (!guard.ok) return lbs_fail(nullptr, PNDF_ERR_HIP, "hipSetDevice failed");
     pndf_lbs_model* h = new pndf_lbs_model();
@@ -1596,6 +1602,7 @@ static void lbs_clear(PndfLbsArgs& a) { memset(&a, 0, sizeof(a)); }
 
 extern "C" int pndf_lbs_forward(pndf_lbs_handle h, const float* theta, int64_t N, float* verts, float* joints, void* workspace,
                                 void* stream) {
+    PndfRange range("pndf_lbs_forward");
     if (!h) return PNDF_ERR_BAD_ARG;
     if (N < 0 || N > 0x7fffffff) return lbs_fail(h, PNDF_ERR_BAD_ARG, "bad frame count");
     if (N == 0) return PNDF_OK;
@@ -1608,6 +1615,7 @@ extern "C" int pndf_lbs_forward(pndf_lbs_handle h, const float* theta, int64_t N
 
 extern "C" int pndf_lbs_terms_grad_w(pndf_lbs_handle h, const float* theta, const float* joints0, int32_t S, int32_t T,
                                      float temp_coef, float data_coef, float* g_theta, void* workspace, void* stream) {
+    PndfRange range("pndf_lbs_terms_grad_w");
     if (!h) return PNDF_ERR_BAD_ARG;
     if (S < 0 || T < 0) return lbs_fail(h, PNDF_ERR_BAD_ARG, "negative size");
     if (S == 0 || T == 0) return PNDF_OK;
@@ -1633,6 +1641,7 @@ extern "C" int pndf_lbs_terms_grad(pndf_lbs_handle h, const float* theta, const 
 
 extern "C" int pndf_lbs_backward(pndf_lbs_handle h, const float* theta, const float* g_verts, const float* g_joints, int64_t N,
                                  float* g_theta, void* workspace, void* stream) {
+    PndfRange range("pndf_lbs_backward");
     if (!h) return PNDF_ERR_BAD_ARG;
     if (N < 0 || N > 0x7fffffff) return lbs_fail(h, PNDF_ERR_BAD_ARG, "bad frame count");
     if (N == 0) return PNDF_OK;

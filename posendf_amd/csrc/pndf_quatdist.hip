@@ -99,6 +99,7 @@ extern "C" __global__ void __launch_bounds__(WG) pndf_quat_topk_kernel(PndfQuatD
 // (unweighted mean over joints).  vals [B,k] ascending, idx [B,k] int64 (ties -> lower index).
 extern "C" int pndf_quat_topk(const float* noise, const float* valid, int64_t B, int32_t K, int32_t metric,
                               const float* weights, int32_t k, float* vals, long long* idx, void* stream) {
+    PndfRange range("pndf_quat_topk");
     if (B < 0 || K < 1 || k < 1 || k > K || k > MAX_K_OUT || (metric != 0 && metric != 1)) return -1;
     if (B == 0) return 0;
     if (!noise || !valid || !vals || !idx) return -1;

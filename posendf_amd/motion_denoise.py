@@ -65,13 +65,27 @@ def iteration_coefs(schedule, it):
 
 
 class MotionDenoise:
-    def __init__(self, posendf, body_model=None, device="cuda:0", schedule="motion_denoise"):
+    """Positional arguments are the reference's (experiments/motion_denoise.py:21: `MotionDenoise(posendf, body_model,
+    out_path, debug, device, batch_size, gender)`), so `MotionDenoise(net, body_model=bm, batch_size=len(poses),
+    out_path=path)` (:151) constructs this class unchanged.  `out_path`, `debug` and `gender` only feed the reference's mesh
+    export / renderer (:47-56, SURVEY.md section 2: out of scope) and are kept as attributes; `batch_size` sized the
+    reference's zero betas (:27) -- the betas are fixed at the body model's construction here.  `schedule` (keyword only)
+    selects the weights of experiments/partial_observation.py:29-35 instead.
+
+    Two entry points: `optimize(noisy_poses, gt_poses=None, iterations=10, steps_per_iter=50)` is the reference's (:58):
+    one sequence [T,69] (or a batch [S,T,69]) in, the vertex-to-vertex error in cm out; `denoise(...)` is the batched
+    form the rest of this package uses (poses and loss history out, autograd or fused driver)."""
+
+    def __init__(self, posendf, body_model=None, out_path="./experiment_results/motion_denoise", debug=False, device="cuda:0",
+                 batch_size=1, gender="male", *, schedule="motion_denoise"):
         if schedule not in SCHEDULES:
             raise ValueError(f"unknown weight schedule {schedule!r} ({', '.join(SCHEDULES)})")
         self.pose_prior = posendf
         self.body_model = body_model
+        self.out_path, self.debug, self.batch_size, self.gender = out_path, debug, batch_size, gender
         self.device = device
         self.schedule = schedule          # "partial_observation": the weights of experiments/partial_observation.py:29-35
+        self.last_poses = None            # denoised poses of the last optimize() call
 
     # ---- loss terms -----------------------------------------------------------------------------
     def pose_prior_term(self, body_pose):
@@ -127,6 +141,8 @@ class MotionDenoise:
         S, T = pose.shape[:2]
         N = S * T
         dev = pose.device
+        if bm is not None and torch.device(dev.type, dev.index or 0) != bm.device:
+            raise ValueError(f"poses on {dev} but the body model lives on {bm.device}: the fused step hands raw pointers to both")
         eng = self.pose_prior._engine_for(dev)
         lib = eng.lib
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -159,7 +175,31 @@ class MotionDenoise:
                 bufs.reverse()
         return bufs[0]
 
-    def optimize(self, noisy_poses, iterations=10, steps_per_iter=50, lr=0.02, record=True, fused=False):
+    def optimize(self, noisy_poses, gt_poses=None, iterations=10, steps_per_iter=50, *, fused=None):
+        """The reference's entry point, argument for argument (experiments/motion_denoise.py:58): optimise the poses and
+        return the mean vertex-to-vertex error in cm as a 0-d numpy array -- against the ground-truth poses when given
+        (:113-117), else against the meshes of the noisy input (:110).  Needs a body model with `.vertices` (the
+        reference's always has one); the denoised poses are left in `self.last_poses`.  The HIP body model takes the fused
+        driver (engine launch + fused LBS pass + Adam kernel per step), any other callable the autograd driver."""
+        from .body_model import BodyModel
+        if self.body_model is None:
+            raise ValueError("optimize() returns the reference's v2v error and needs a body model; denoise() runs without one")
+        if fused is None:
+            fused = isinstance(self.body_model, BodyModel)
+        noisy = noisy_poses.to(self.device, torch.float32)
+        out, _ = self.denoise(noisy.reshape(-1, noisy.shape[-2], 69) if noisy.dim() > 2 else noisy.reshape(-1, 69),
+                              iterations=iterations, steps_per_iter=steps_per_iter, record=False, fused=fused)
+        self.last_poses = out.reshape(noisy.shape)
+        ref = noisy if gt_poses is None else gt_poses.to(self.device, torch.float32)
+        with torch.no_grad():
+            def verts(p):
+                res = self.body_model(pose_body=p.reshape(-1, 69))
+                return res.vertices if hasattr(res, "vertices") else res[0]
+            d = verts(self.last_poses) - verts(ref)
+            v2v = torch.mean(torch.sqrt(torch.sum(d * d, dim=2))) * 100.0                # :118
+        return v2v.detach().cpu().numpy()                                               # :120
+
+    def denoise(self, noisy_poses, iterations=10, steps_per_iter=50, lr=0.02, record=True, fused=False):
         """noisy_poses: [T,69] or [S,T,69] axis-angle.  Returns (denoised poses, history of per-step mean losses;
         empty with fused=True)."""
         if fused:
@@ -216,7 +256,7 @@ def denoise_motion_file(posendf, body_model, motion_file, gt_file=None, device="
     """`main()` of experiments/motion_denoise.py:124-153 after the model is loaded: read the noisy motion, optimise it,
     return (denoised poses [T,69], v2v error in cm against the ground truth if given, else against the noisy input)."""
     noisy = load_motion_npz(motion_file, device)
-    md = MotionDenoise(posendf, body_model=body_model, device=device, schedule=schedule)
-    out, _ = md.optimize(noisy, iterations=iterations, steps_per_iter=steps_per_iter, record=False, fused=fused)
-    ref = load_motion_npz(gt_file, device) if gt_file is not None else noisy
-    return out, v2v_error_cm(body_model, out, ref)
+    md = MotionDenoise(posendf, body_model, device=device, batch_size=len(noisy), schedule=schedule)
+    gt = load_motion_npz(gt_file, device) if gt_file is not None else None
+    v2v = md.optimize(noisy, gt, iterations, steps_per_iter, fused=fused)          # the reference's call (:152)
+    return md.last_poses, float(v2v)

@@ -24,6 +24,15 @@ def all_gather_blocks(x: torch.Tensor, total: int, group=None, out: torch.Tensor
         return x
     world = dist.get_world_size(group)
     x = x.contiguous()
+    if x.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo is the CPU / test backend (RCCL refuses two ranks on one device, gloo does not: bench.py
+        # PNDF_BENCH_BACKEND=gloo): device blocks are staged through the host explicitly instead of relying on gloo's
+        # own device-tensor support
+        host = all_gather_blocks(x.cpu(), total, group)
+        if out is None:
+            return host.to(x.device)
+        out.copy_(host)
+        return out
     if total % world == 0:
         assert x.shape[0] == total // world, (x.shape, total, world)
         if out is None:

@@ -110,7 +110,18 @@ def make_body_model(V=SMPL_V, n_betas=10, seed=0, parents=SMPL_PARENTS, extra=SM
         idx = rng.choice(J, max_influences, replace=False)
         w[v, idx] = rng.random(max_influences) + 0.05
     lbs_weights = (w / w.sum(1, keepdims=True)).astype(np.float32)
-    extra = tuple(int(e) % V for e in extra)
+    # a smaller cloud than SMPL's folds the table's vertex ids into range; folded ids that collide move on to the next free
+    # vertex (the kernels serve one picked joint per vertex and pndf_lbs_pack_host refuses duplicates)
+    if len(extra) > V:
+        raise ValueError(f"{len(extra)} vertex-picked joints need at least as many vertices, V = {V}")
+    taken, uniq = set(), []
+    for e in extra:
+        e = int(e) % V
+        while e in taken:
+            e = (e + 1) % V
+        taken.add(e)
+        uniq.append(e)
+    extra = tuple(uniq)
     return dict(v_template=v_template, shapedirs=shapedirs, posedirs=posedirs, J_regressor=J_regressor,
                 parents=np.asarray(parents, np.int32), lbs_weights=lbs_weights,
                 extra_joint_vertex=np.asarray(extra, np.int32), betas=np.zeros(n_betas, np.float32))

@@ -157,8 +157,10 @@ def pose_gate(err, sigma, what="", factor=8.0, floor=8e-6, exempt=None, tol=1e-4
     assert np.median(err) <= max(tol / 10, factor * float(np.median(sigma))), (what, float(np.median(err)))
     keep = np.ones(len(err), bool) if exempt is None else ~np.asarray(exempt)
     ratio = err[keep] / (factor * sigma[keep] + floor)
+    worst = float(ratio.max()) if ratio.size else 0.0
     print(f"[pose_gate {what}] n {len(err)} median {np.median(err):.2e} max {err.max():.2e} | largest error / bound "
-          f"{ratio.max() if ratio.size else 0:.2f} (1.00 = at the gate), exempt {0 if exempt is None else int(np.sum(exempt))}")
+          f"{worst:.2f} (1.00 = at the gate), exempt {0 if exempt is None else int(np.sum(exempt))}")
+    return worst
 
 
 def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0, margin=None, kink_tol=1e-5, cap=10.0, sigma=None):

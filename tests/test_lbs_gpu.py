@@ -126,7 +126,7 @@ def test_fused_denoise_with_body_model_matches_oracle_loop(smpl_like, precision,
     S, T, iters, per = 2, 20, 2, 3
     th0 = _theta(S, T, seed=21) * 0.5
     md = MotionDenoise(net, body_model=bm, device="cuda:0", schedule=schedule)      # partial_observation.py:29-35: other weights
-    got, _ = md.optimize(torch.from_numpy(th0), iterations=iters, steps_per_iter=per, fused=True)
+    got, _ = md.denoise(torch.from_numpy(th0), iterations=iters, steps_per_iter=per, fused=True)
     ref = denoise_np.optimize(th0, sd, iterations=iters, steps_per_iter=per, body_model=m, schedule=schedule)
     diff = np.abs(got.cpu().numpy() - ref)
     moved = np.abs(ref - th0).max()
@@ -135,7 +135,7 @@ def test_fused_denoise_with_body_model_matches_oracle_loop(smpl_like, precision,
     assert np.median(diff) < 1e-5 and (diff > 1e-3).mean() < 0.01 and diff.max() < 0.5 * moved
     assert np.abs(got.cpu().numpy()[..., 63:] - th0[..., 63:]).max() > 1e-3      # the hand joints are optimised too
     # the autograd driver around the same engine and body model takes the same steps
-    auto, hist = md.optimize(torch.from_numpy(th0), iterations=iters, steps_per_iter=per)
+    auto, hist = md.denoise(torch.from_numpy(th0), iterations=iters, steps_per_iter=per)
     d2 = (auto - got).abs().flatten()
     assert d2.median().item() < 1e-5 and (d2 > 1e-3).float().mean().item() < 0.01
     assert {"pose_pr", "temp"} <= set(hist[0]) and "data" in hist[-1]

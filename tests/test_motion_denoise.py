@@ -57,7 +57,7 @@ def test_loop_runs_on_cpu_with_oracle_prior():
     from posendf_amd.motion_denoise import MotionDenoise
     md = MotionDenoise(_OraclePrior("lrelu", golden_weights("live")), device="cpu")
     noisy = _noisy_sequences(2, 8)
-    out, hist = md.optimize(noisy, iterations=2, steps_per_iter=3)
+    out, hist = md.denoise(noisy, iterations=2, steps_per_iter=3)
     assert out.shape == noisy.shape and len(hist) == 6
     assert "data" not in hist[0] and "data" in hist[-1]                # data term only for it > 0 (:92)
     assert hist[2]["pose_pr"] < hist[0]["pose_pr"]                     # the (dominant) prior term is descended
@@ -75,8 +75,8 @@ def test_denoise_matches_oracle_loop(precision):
     net = PoseNDF(cfg)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     noisy = _noisy_sequences(3, 12, seed=1)
-    got, h_gpu = MotionDenoise(net, device="cuda:0").optimize(noisy, iterations=2, steps_per_iter=10)
-    ref, h_cpu = MotionDenoise(_OraclePrior("lrelu", sd), device="cpu").optimize(noisy, iterations=2, steps_per_iter=10)
+    got, h_gpu = MotionDenoise(net, device="cuda:0").denoise(noisy, iterations=2, steps_per_iter=10)
+    ref, h_cpu = MotionDenoise(_OraclePrior("lrelu", sd), device="cpu").denoise(noisy, iterations=2, steps_per_iter=10)
     assert abs(h_gpu[0]["pose_pr"] - h_cpu[0]["pose_pr"]) < 1e-5 * abs(h_cpu[0]["pose_pr"]) + 1e-8
     # Adam normalises gradients, so tiny gradient differences are not amplified; 20 steps stay close
     err = (got.cpu() - ref).abs().max().item()
@@ -101,11 +101,11 @@ def test_fused_step_matches_autograd_driver(precision):
     noisy[0, 3, 6:9] = 0.0                                   # a zero rotation: small-angle branch and its Jacobian
     md = MotionDenoise(net, device="cuda:0")
     # one step: the update is lr * sign-like, so compare the step itself tightly
-    a1, _ = md.optimize(noisy, iterations=1, steps_per_iter=1, record=False)
-    f1, _ = md.optimize(noisy, iterations=1, steps_per_iter=1, fused=True)
+    a1, _ = md.denoise(noisy, iterations=1, steps_per_iter=1, record=False)
+    f1, _ = md.denoise(noisy, iterations=1, steps_per_iter=1, fused=True)
     assert (a1 - f1).abs().max().item() < 2e-4               # Adam's first step is lr * g / (|g| + eps): +-lr unless g ~ 0
-    ref, _ = md.optimize(noisy, iterations=2, steps_per_iter=10, record=False)
-    got, _ = md.optimize(noisy, iterations=2, steps_per_iter=10, fused=True)
+    ref, _ = md.denoise(noisy, iterations=2, steps_per_iter=10, record=False)
+    got, _ = md.denoise(noisy, iterations=2, steps_per_iter=10, fused=True)
     assert torch.isfinite(got).all()
     # 20 steps: d d / d q is discontinuous at activation kinks and Adam turns a flipped gradient component into a
     # +-lr step, so a few elements drift apart; the bulk must agree to rounding
@@ -164,10 +164,10 @@ def test_denoise_matches_reference_loop(act, precision, fused):
     md = MotionDenoise(_engine_net(act, precision), device="cuda:0")
     theta0 = torch.from_numpy(g["theta0"])
     # first step: Adam's bias-corrected first update is lr * g / (|g| + eps), i.e. -+lr for every element with a gradient
-    one, _ = md.optimize(theta0, iterations=1, steps_per_iter=1, fused=fused, record=False)
+    one, _ = md.denoise(theta0, iterations=1, steps_per_iter=1, fused=fused, record=False)
     want1 = g[f"{act}_theta_f64"][0]
     assert np.abs(one.cpu().numpy() - want1).max() < 1e-5
-    out, _ = md.optimize(theta0, iterations=2, steps_per_iter=4, fused=fused, record=False)
+    out, _ = md.denoise(theta0, iterations=2, steps_per_iter=4, fused=fused, record=False)
     want = g[f"{act}_theta_f64"][-1]
     err = np.abs(out.cpu().numpy() - want)
     ref_err = np.abs(g[f"{act}_theta_f32"][-1] - want)            # the reference loop's own fp32 run
@@ -192,12 +192,12 @@ def test_denoise_config5_size():
     sd = golden_weights("live")
     md = MotionDenoise(_engine_net("lrelu", "f16x3", sd), device="cuda:0")
     noisy = _noisy_sequences(S, T, seed=7)
-    out, _ = md.optimize(noisy, iterations=1, steps_per_iter=steps, fused=True)
+    out, _ = md.denoise(noisy, iterations=1, steps_per_iter=steps, fused=True)
     assert out.shape == (S, T, 69) and torch.isfinite(out).all()
     perm = torch.randperm(S, generator=torch.Generator().manual_seed(1))
-    out_p, _ = md.optimize(noisy[perm], iterations=1, steps_per_iter=steps, fused=True)
+    out_p, _ = md.denoise(noisy[perm], iterations=1, steps_per_iter=steps, fused=True)
     assert torch.equal(out[perm.cuda()], out_p)
-    auto, _ = md.optimize(noisy[:16], iterations=1, steps_per_iter=steps, fused=False, record=False)
+    auto, _ = md.denoise(noisy[:16], iterations=1, steps_per_iter=steps, fused=False, record=False)
     diff = (auto - out[:16]).abs()
     assert diff.median().item() < 1e-6 and (diff > 1e-3).float().mean().item() < 0.01
     s = 37
@@ -205,7 +205,7 @@ def test_denoise_config5_size():
     err = np.abs(out[s].cpu().numpy() - want)
     assert np.median(err) < 1e-6 and (err > 1e-3).mean() < 0.01, (np.median(err), err.max())
     # second outer iteration switches the data term on (:92) and changes the weights
-    out2, _ = md.optimize(noisy[:64], iterations=2, steps_per_iter=2, fused=True)
+    out2, _ = md.denoise(noisy[:64], iterations=2, steps_per_iter=2, fused=True)
     want2 = dn.optimize(noisy[5].numpy().astype(np.float64), sd, iterations=2, steps_per_iter=2)
     err2 = np.abs(out2[5].cpu().numpy() - want2)
     assert np.median(err2) < 1e-6 and (err2 > 1e-3).mean() < 0.01
@@ -237,18 +237,18 @@ def test_body_model_terms_are_pluggable(precision):
     sd = golden_weights("live")
     net = _engine_net("lrelu", precision, sd)
     noisy = _noisy_sequences(2, 10, seed=11)
-    got, h = MotionDenoise(net, body_model=_LinearBlendBody("cuda:0"), device="cuda:0").optimize(
+    got, h = MotionDenoise(net, body_model=_LinearBlendBody("cuda:0"), device="cuda:0").denoise(
         noisy, iterations=2, steps_per_iter=5)
-    ref, h_ref = MotionDenoise(_OraclePrior("lrelu", sd), body_model=_LinearBlendBody("cpu"), device="cpu").optimize(
+    ref, h_ref = MotionDenoise(_OraclePrior("lrelu", sd), body_model=_LinearBlendBody("cpu"), device="cpu").denoise(
         noisy, iterations=2, steps_per_iter=5)
     assert "temp" in h[0] and "data" in h[-1] and abs(h[0]["temp"] - h_ref[0]["temp"]) < 1e-5 * abs(h_ref[0]["temp"])
     err = (got.cpu() - ref).abs()
     assert err.median().item() < 1e-5 and err.max().item() < 5e-3, (err.median().item(), err.max().item())
-    plain, _ = MotionDenoise(net, device="cuda:0").optimize(noisy, iterations=2, steps_per_iter=5, record=False)
+    plain, _ = MotionDenoise(net, device="cuda:0").denoise(noisy, iterations=2, steps_per_iter=5, record=False)
     # the body-model terms changed the solution (slightly: the prior's 1e7 weight dominates every Adam step)
     assert (plain.cpu() - got.cpu()).abs().max().item() > 2e-5
     with pytest.raises(ValueError):
-        MotionDenoise(net, body_model=_LinearBlendBody("cuda:0"), device="cuda:0").optimize(noisy, fused=True)
+        MotionDenoise(net, body_model=_LinearBlendBody("cuda:0"), device="cuda:0").denoise(noisy, fused=True)
 
 
 def test_body_model_hook_cpu():
@@ -280,8 +280,8 @@ def test_very_short_sequences(T):
     rng = np.random.default_rng(7)
     noisy = torch.from_numpy(rng.normal(scale=0.3, size=(4, T, 69)).astype(np.float32)).cuda()
     md = MotionDenoise(net)
-    a, _ = md.optimize(noisy, iterations=2, steps_per_iter=3, fused=False)
-    b, _ = md.optimize(noisy, iterations=2, steps_per_iter=3, fused=True)
+    a, _ = md.denoise(noisy, iterations=2, steps_per_iter=3, fused=False)
+    b, _ = md.denoise(noisy, iterations=2, steps_per_iter=3, fused=True)
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
     assert (a - b).abs().max().item() < 2e-4, (a - b).abs().max().item()
 
@@ -331,13 +331,13 @@ def test_fused_partial_observation_schedule_matches_oracle(precision):
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     noisy = _noisy_sequences(3, 14, seed=8)
     md = MotionDenoise(net, device="cuda:0", schedule="partial_observation")
-    got, _ = md.optimize(noisy, iterations=2, steps_per_iter=4, fused=True)
+    got, _ = md.denoise(noisy, iterations=2, steps_per_iter=4, fused=True)
     ref = denoise_np.optimize(noisy.numpy(), sd, iterations=2, steps_per_iter=4, schedule="partial_observation")
     diff = np.abs(got.cpu().numpy() - ref)
     assert np.median(diff) < 1e-5 and (diff > 1e-3).mean() < 0.01, (np.median(diff), diff.max())
-    other, _ = MotionDenoise(net, device="cuda:0").optimize(noisy, iterations=2, steps_per_iter=4, fused=True)
+    other, _ = MotionDenoise(net, device="cuda:0").denoise(noisy, iterations=2, steps_per_iter=4, fused=True)
     assert (other - got).abs().max().item() > 1e-3          # the two schedules are different objectives
-    auto, _ = md.optimize(noisy, iterations=2, steps_per_iter=4, record=False)
+    auto, _ = md.denoise(noisy, iterations=2, steps_per_iter=4, record=False)
     d2 = (auto - got).abs().flatten()
     assert d2.median().item() < 1e-5 and (d2 > 1e-3).float().mean().item() < 0.01
 
@@ -365,3 +365,36 @@ def test_load_motion_npz_pads_hand_joints(tmp_path):
     np.savez(tmp_path / "bad.npz", pose_body=body[:, :60])
     with pytest.raises(ValueError):
         load_motion_npz(tmp_path / "bad.npz", device="cpu")
+
+
+def test_reference_argument_order_is_drop_in():
+    """experiments/motion_denoise.py:21,58,151-152 verbatim: `MotionDenoise(net, body_model=body_model, batch_size=len(noisy_poses),
+    out_path=out_path)` then `v2v_err = motion_denoiser.optimize(noisy_poses, gt_poses)` -- second positional argument of
+    `optimize` is the ground truth, the result is the v2v error in cm as a numpy scalar.  CPU: the oracle
+    network and a small differentiable body stand-in; the batched form lives behind `denoise`."""
+    import inspect
+    from posendf_amd.motion_denoise import MotionDenoise
+    assert list(inspect.signature(MotionDenoise.__init__).parameters)[:8] == [
+        "self", "posendf", "body_model", "out_path", "debug", "device", "batch_size", "gender"]
+    assert list(inspect.signature(MotionDenoise.optimize).parameters)[:5] == [
+        "self", "noisy_poses", "gt_poses", "iterations", "steps_per_iter"]
+    net = _OraclePrior("lrelu", golden_weights("live"))
+    body = _LinearBlendBody("cpu")
+    gt_poses = _noisy_sequences(1, 8, seed=21)[0] * 0.3
+    noisy_poses = gt_poses + 0.05 * torch.randn(8, 69, generator=torch.Generator().manual_seed(3))
+    # the reference's own call shapes: positional out_path / debug / device, keyword body_model / batch_size
+    motion_denoiser = MotionDenoise(net, body, "/tmp/unused_out_path", False, "cpu", len(noisy_poses), "male")
+    v2v_err = motion_denoiser.optimize(noisy_poses, gt_poses, 2, 3)
+    assert isinstance(v2v_err, np.ndarray) and v2v_err.shape == () and np.isfinite(v2v_err) and v2v_err > 0
+    out = motion_denoiser.last_poses
+    assert out.shape == (8, 69)
+    want = torch.mean(torch.sqrt(torch.sum((body(out)[0] - body(gt_poses)[0]) ** 2, dim=2))) * 100.0       # :117-118
+    assert abs(float(v2v_err) - float(want)) < 1e-6 * float(want)
+    # the same poses as the batched entry point produces
+    ref, _ = MotionDenoise(net, body_model=body, device="cpu").denoise(noisy_poses, iterations=2, steps_per_iter=3, record=False)
+    assert torch.equal(ref, out)
+    # without ground truth the error is measured against the noisy input's meshes (:110)
+    v_in = MotionDenoise(net, body_model=body, batch_size=8, out_path="x", device="cpu").optimize(noisy_poses, None, 1, 2)
+    assert np.isfinite(v_in) and v_in > 0
+    with pytest.raises(ValueError):
+        MotionDenoise(net, device="cpu").optimize(noisy_poses)

@@ -77,7 +77,7 @@ def _denoise_worker(rank, world, port, S, T, outdir):
     md = MotionDenoise(_OraclePrior("lrelu", golden_weights("live")), device="cpu")
     theta = _noisy_sequences(S, T, seed=4)
     lo, hi = shard_bounds(S, rank, world)
-    out = denoise_sharded(lambda th: md.optimize(th, iterations=2, steps_per_iter=2, record=False)[0], theta[lo:hi], S)
+    out = denoise_sharded(lambda th: md.denoise(th, iterations=2, steps_per_iter=2, record=False)[0], theta[lo:hi], S)
     np.save(os.path.join(outdir, f"th_{rank}.npy"), out.numpy())
     dist.destroy_process_group()
 
@@ -90,7 +90,7 @@ def test_two_rank_gloo_denoise_shards_whole_sequences(tmp_path):
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_denoise_worker, args=(world, port, S, T, str(tmp_path)), nprocs=world, join=True)
     md = MotionDenoise(_OraclePrior("lrelu", golden_weights("live")), device="cpu")
-    ref, _ = md.optimize(_noisy_sequences(S, T, seed=4), iterations=2, steps_per_iter=2, record=False)
+    ref, _ = md.denoise(_noisy_sequences(S, T, seed=4), iterations=2, steps_per_iter=2, record=False)
     for r in range(world):
         got = np.load(tmp_path / f"th_{r}.npy")
         assert got.shape == (S, T, 69)

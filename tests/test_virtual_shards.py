@@ -111,11 +111,11 @@ def test_config4_512_sequences_as_eight_virtual_shards(rccl_single_rank, precisi
 
     def optimize_fn(th):
         calls.append(tuple(th.shape))
-        return md.optimize(th, iterations=iters, steps_per_iter=per, fused=True)[0]
+        return md.denoise(th, iterations=iters, steps_per_iter=per, fused=True)[0]
 
     out_sh = run_virtual_shards(optimize_fn, theta, SHARDS)
     assert calls == [(S // SHARDS, T, 69)] * SHARDS
-    out_one = md.optimize(theta, iterations=iters, steps_per_iter=per, fused=True)[0]     # all 153,600 frames per launch
+    out_one = md.denoise(theta, iterations=iters, steps_per_iter=per, fused=True)[0]     # all 153,600 frames per launch
     assert torch.equal(out_sh, out_one) and torch.isfinite(out_sh).all()
     # one sequence of the LAST shard against the numpy oracle of the loop (Adam's first steps are +-lr: compare the bulk)
     s = S - 5
@@ -147,11 +147,11 @@ def test_config4_reference_objective_as_eight_virtual_shards(rccl_single_rank):
 
     def optimize_fn(th):
         calls.append(tuple(th.shape))
-        return md.optimize(th, iterations=iters, steps_per_iter=per, fused=True)[0]
+        return md.denoise(th, iterations=iters, steps_per_iter=per, fused=True)[0]
 
     out_sh = run_virtual_shards(optimize_fn, theta, SHARDS)
     assert calls == [(S // SHARDS, T, 69)] * SHARDS and torch.isfinite(out_sh).all()
-    out_one = md.optimize(theta, iterations=iters, steps_per_iter=per, fused=True)[0]
+    out_one = md.denoise(theta, iterations=iters, steps_per_iter=per, fused=True)[0]
     d = (out_sh - out_one).abs().flatten()
     moved = (out_one - theta).abs().max().item()
     assert moved > 1e-3 and d.median().item() < 1e-6 and (d > 1e-3).float().mean().item() < 0.01 and d.max().item() < 0.5 * moved

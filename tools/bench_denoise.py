@@ -33,16 +33,16 @@ def main():
     theta = (torch.cumsum(0.02 * torch.randn(S, T, 69, generator=g), dim=1) + 0.3 * torch.randn(S, 1, 69, generator=g)
              + 0.1 * torch.randn(S, T, 69, generator=g))
     md = MotionDenoise(net, device="cuda:0")
-    md.optimize(theta, iterations=1, steps_per_iter=3, record=False)          # warm-up
+    md.denoise(theta, iterations=1, steps_per_iter=3, record=False)          # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out, _ = md.optimize(theta, iterations=2, steps_per_iter=args.steps // 2, record=False)
+    out, _ = md.denoise(theta, iterations=2, steps_per_iter=args.steps // 2, record=False)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    md.optimize(theta, iterations=1, steps_per_iter=3, fused=True)
+    md.denoise(theta, iterations=1, steps_per_iter=3, fused=True)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    out_f, _ = md.optimize(theta, iterations=2, steps_per_iter=args.steps // 2, fused=True)
+    out_f, _ = md.denoise(theta, iterations=2, steps_per_iter=args.steps // 2, fused=True)
     torch.cuda.synchronize()
     df = time.perf_counter() - t2
     # engine share: forward+grad launches alone on the same number of frames

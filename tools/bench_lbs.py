@@ -64,17 +64,17 @@ def main():
     net = PoseNDF(cfg)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_weights(0, 2.0, 0.1).items()})
     md = MotionDenoise(net, body_model=bm, device="cuda:0")
-    md.optimize(theta, iterations=1, steps_per_iter=2, fused=True)
+    md.denoise(theta, iterations=1, steps_per_iter=2, fused=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res, _ = md.optimize(theta, iterations=2, steps_per_iter=5, fused=True)
+    res, _ = md.denoise(theta, iterations=2, steps_per_iter=5, fused=True)
     torch.cuda.synchronize()
     ms_step = (time.perf_counter() - t0) / 10 * 1e3
     md0 = MotionDenoise(net, device="cuda:0")
-    md0.optimize(theta, iterations=1, steps_per_iter=2, fused=True)
+    md0.denoise(theta, iterations=1, steps_per_iter=2, fused=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    md0.optimize(theta, iterations=2, steps_per_iter=5, fused=True)
+    md0.denoise(theta, iterations=2, steps_per_iter=5, fused=True)
     torch.cuda.synchronize()
     ms_step0 = (time.perf_counter() - t0) / 10 * 1e3
     tf = S * T * FLOP_PER_FRAME / (ms_terms * 1e-3) / 1e12
