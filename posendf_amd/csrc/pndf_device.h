@@ -227,20 +227,99 @@ __device__ __forceinline__ float relu_factor(float step, float slope) { return f
 // nn.Softplus(beta, threshold=20) (net_modules.py:39-40): x if beta x > 20 else log1p(exp(beta x)) / beta;
 // derivative as PyTorch's softplus_backward: e / (e + 1) with e = exp(beta x), 1 above the threshold.
 // On the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each) instead of libm's expf / log1pf /
-// IEEE division (~70 instructions per value: they made the softplus kernel 57 % slower than the relu one):
-//   e = 2^(min(beta x, 20) log2 e);  u = 1 + e;  log1p(e) = ln(u) + (e - (u - 1)) / u;  derivative e / u.
-//   ~15 instructions, a few ulp.
-__device__ __forceinline__ float act_softplus(float z, float beta, float& deriv) {
-    const float bz = z * beta;
+// IEEE division (~70 instructions per value: they made the softplus kernel 57 % slower than the relu one).
+//
+// PNDF_SP_FORM 1 (round 4, default): 10 plain instructions per value instead of 16, written on PAIRS of values so that they
+// issue as packed fp32 (v_pk_mul / v_pk_fma / v_pk_add: two values per issue slot) -- the split softplus kernel is bound by
+// VALU issue, the three quarter-rate transcendentals per value are the floor:
+//   x = min(z beta log2 e, 20 log2 e);  e = 2^x;  u = 1 + e;  ru = 1 / u;
+//   softplus = max(z, (ln 2 / beta) log2 u + ((e - (u - 1)) ru) / beta);   derivative = e ru
+// * the clamp replaces both selects of form 0: above the threshold u = e exactly (e > 2^24), so the clamped value is
+//   (20 + 2e-9) / beta < z and max() returns z as PyTorch does, while e ru = 1 to an ulp; below it softplus(z) > z, and max()
+//   returns the computed value (at beta z within rounding of 20 the two agree to an ulp);
+// * (e - (u - 1)) ru puts the rounding of 1 + e back to first order: a saturated-low unit keeps softplus = e / beta, not 0.
+// PNDF_SP_FORM 0: rounds 1-3 (kept for same-box A/B builds).
+#ifndef PNDF_SP_FORM
+#define PNDF_SP_FORM 1
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct SpK {            // uniform constants of the activation
+    float beta, b2, c, invb;      // beta, beta log2(e), ln 2 / beta, 1 / beta
+};
+__device__ __forceinline__ SpK sp_consts(float beta) {
+    const float invb = __builtin_amdgcn_rcpf(beta);
+    return SpK{beta, beta * 1.44269504088896341f, 0.693147180559945309f * invb, invb};
+}
+constexpr float SP_CLAMP_LOG2 = 28.8539008177792681f;      // 20 log2(e): the threshold of nn.Softplus in the exponent's unit
+// one v_min / v_max: fminf() / fmaxf() make hipcc quiet both operands first (a second instruction per value)
+__device__ __forceinline__ float vmin1(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax1(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ float act_softplus(float z, const SpK& k, float& deriv) {
+#if PNDF_SP_FORM == 0
+    const float bz = z * k.beta;
     const float e = __builtin_amdgcn_exp2f(fminf(bz, 20.0f) * 1.44269504088896341f);
     const bool lin = bz > 20.0f;
     const float u = 1.0f + e;
     const float ru = __builtin_amdgcn_rcpf(u);
-    // log1p(e) = ln(u) + ln((1 + e) / u) = ln(u) + (e - (u - 1)) / u + O(2^-48): the rounding of 1 + e is put back to
-    // first order, with the reciprocal the derivative needs anyway (three quarter-rate transcendentals per value)
     const float l = fmaf(e - (u - 1.0f), ru, __builtin_amdgcn_logf(u) * 0.693147180559945309f);
     deriv = lin ? 1.0f : e * ru;
-    return lin ? z : l * __builtin_amdgcn_rcpf(beta);      // beta is uniform: hipcc hoists this reciprocal
+    return lin ? z : l * k.invb;
+#else
+    const float e = __builtin_amdgcn_exp2f(vmin1(z * k.b2, SP_CLAMP_LOG2));
+    const float u = 1.0f + e;
+    const float ru = __builtin_amdgcn_rcpf(u);
+    const float t = (e - (u - 1.0f)) * ru;
+    deriv = e * ru;
+    return vmax1(z, fmaf(t, k.invb, __builtin_amdgcn_logf(u) * k.c));
+#endif
+}
+
+// two values at once: the plain instructions as packed fp32
+__device__ __forceinline__ f32x2 act_softplus2(f32x2 z, const SpK& k, f32x2& deriv) {
+#if PNDF_SP_FORM == 0
+    f32x2 y;
+    float d0, d1;
+    y[0] = act_softplus(z[0], k, d0);
+    y[1] = act_softplus(z[1], k, d1);
+    deriv = f32x2{d0, d1};
+    return y;
+#else
+    const f32x2 x = z * k.b2;
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(vmin1(x[0], SP_CLAMP_LOG2));
+    e[1] = __builtin_amdgcn_exp2f(vmin1(x[1], SP_CLAMP_LOG2));
+    const f32x2 u = e + 1.0f;
+    f32x2 ru, lg;
+    ru[0] = __builtin_amdgcn_rcpf(u[0]);
+    ru[1] = __builtin_amdgcn_rcpf(u[1]);
+    lg[0] = __builtin_amdgcn_logf(u[0]);
+    lg[1] = __builtin_amdgcn_logf(u[1]);
+    const f32x2 t = (e - (u - 1.0f)) * ru;
+    const f32x2 sp = t * k.invb + lg * k.c;          // (contracted to one packed fma)
+    deriv = e * ru;
+    return f32x2{vmax1(z[0], sp[0]), vmax1(z[1], sp[1])};
+#endif
+}
+// a whole C/D tile register set (4 values per lane)
+__device__ __forceinline__ void act_softplus4(f32x4& z, const SpK& k, f32x4& deriv) {
+    f32x2 d0, d1;
+    const f32x2 y0 = act_softplus2(f32x2{z[0], z[1]}, k, d0), y1 = act_softplus2(f32x2{z[2], z[3]}, k, d1);
+    z = f32x4{y0[0], y0[1], y1[0], y1[1]};
+    deriv = f32x4{d0[0], d0[1], d1[0], d1[1]};
 }
 
 // Activation parameters + where derivatives are parked between the forward and the backward pass.
@@ -257,7 +336,7 @@ struct SpRef {
 };
 struct ActP {
     float slope;        // relu family
-    float beta;         // softplus
+    SpK k;              // softplus
     SpRef sp;           // softplus: this thread's column of the scratch, else {null, 0}
     char* stage;        // softplus backward: this wave's LDS staging window for derivative tiles (its own F rows,
     int lane;           //   free between the forward trunk and the end of the backward trunk); lane id
@@ -339,14 +418,24 @@ __device__ __forceinline__ f32x4 enc_tile(Ring& ring) {
 }
 
 // per-component denominators of F.normalize(pose, dim=1): max(||q[:, c]||_2 over joints, eps)
-__device__ __forceinline__ void joint_axis_norms(const float* my_q, float (&ss)[4]) {
+// POISON (softplus instantiations): also returns 0 * (every component of the pose), i.e. +0 for a finite pose and NaN for
+// one that holds a NaN or an infinity -- as F.normalize makes of it (inf / inf).  nn.Softplus carries a NaN through
+// (softplus(NaN) = NaN); the hardware v_min / v_max of the activation return their other operand, so the kernels add this
+// to the pose's distance and gradient seed instead (0 + x is exact for every finite x).
+template <bool POISON = false>
+__device__ __forceinline__ float joint_axis_norms(const float* my_q, float (&ss)[4]) {
     ss[0] = ss[1] = ss[2] = ss[3] = 0.f;
+    float poison = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const f32x4 v = *(const f32x4*)(my_q + 4 * j);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ss[c] = fmaf(v[c], v[c], ss[c]);
+        for (int c = 0; c < 4; ++c) {
+            ss[c] = fmaf(v[c], v[c], ss[c]);
+            if constexpr (POISON) poison = fmaf(v[c], 0.0f, poison);
+        }
     }
+    return poison;
 }
 
 // activation of one encoder tile; returns 4 derivative bits (relu family) or stores the derivative (softplus)
@@ -355,12 +444,7 @@ __device__ __forceinline__ float enc_act(f32x4& z, const ActP& ap, int spslot) {
     float bitsum = 0.f;
     if constexpr (SP) {
         f32x4 dv;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float dr;
-            z[r] = act_softplus(z[r], ap.beta, dr);
-            dv[r] = dr;
-        }
+        act_softplus4(z, ap.k, dv);
         *ap.sp.slot(spslot) = dv;
     } else {
 #pragma unroll
@@ -490,10 +574,10 @@ __device__ __forceinline__ void enc_fwd_step(const float* my_q, float* my_f, con
 }
 
 template <bool SP>
-__device__ __forceinline__ void encoder_forward(const float* my_q, float* my_f, const float* encb,
-                                                uint32_t (&eb)[6], Ring& ring, const ActP& ap, int g) {
+__device__ __forceinline__ float encoder_forward(const float* my_q, float* my_f, const float* encb,
+                                                 uint32_t (&eb)[6], Ring& ring, const ActP& ap, int g) {
     float ss[4], inv[4];
-    joint_axis_norms(my_q, ss);
+    const float poison = joint_axis_norms<SP>(my_q, ss);
 #pragma unroll
     for (int c = 0; c < 4; ++c) inv[c] = 1.0f / fmaxf(sqrtf(ss[c]), 1e-12f);
     f32x4 F[NJ];
@@ -515,6 +599,7 @@ __device__ __forceinline__ void encoder_forward(const float* my_q, float* my_f, 
         eb[w] = v;
         asm volatile("" : "+v"(eb[w]));      // pin the packing here (see act_tiles)
     }
+    return poison;
 }
 
 // Joint J, backward: GF[J] (rows 4..9 = d d / d feature, from the trunk plus the children) ->
@@ -614,9 +699,10 @@ __device__ __forceinline__ void ring_skip_encoder_section(Ring& ring) {
         ring_dma(ring);
     }
 }
-__device__ __forceinline__ void noenc_forward(const float* my_q, float* my_f, int g) {
+template <bool SP = false>
+__device__ __forceinline__ float noenc_forward(const float* my_q, float* my_f, int g) {
     float ss[4], inv[4];
-    joint_axis_norms(my_q, ss);
+    const float poison = joint_axis_norms<SP>(my_q, ss);
 #pragma unroll
     for (int c = 0; c < 4; ++c) inv[c] = 1.0f / fmaxf(sqrtf(ss[c]), 1e-12f);
     for (int j = g; j < 32; j += 4) {          // rows 84..127 of x0 are zero
@@ -629,6 +715,7 @@ __device__ __forceinline__ void noenc_forward(const float* my_q, float* my_f, in
         *(f32x4*)(my_f + 4 * j) = v;
     }
     wave_lds_fence();      // written by one lane group each, read by all (x0)
+    return poison;
 }
 
 // q <- q - d * grad exactly as the reference evaluates it (experiments/sample_poses.py:74: the product is rounded to

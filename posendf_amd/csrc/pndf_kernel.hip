@@ -90,12 +90,7 @@ struct PhaseBody {
                             f32x4* slot = ap.sp.slot(spslot + c * CT + ci);
                             if (!BWD) {
                                 f32x4 dv;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    float dr;
-                                    ch[ci][r] = act_softplus(ch[ci][r], ap.beta, dr);
-                                    dv[r] = dr;
-                                }
+                                act_softplus4(ch[ci], ap.k, dv);
                                 *slot = dv;
                             } else {
                                 if (ci == 0) wait_staged_derivatives<(KA * CT / 4 < 12) ? KA * CT / 4 : 12>();
@@ -185,12 +180,7 @@ __device__ __forceinline__ void act_tiles(f32x4 (&x)[NT], uint32_t (&m)[(NT * 4 
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             f32x4 dv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float dr;
-                x[t][r] = act_softplus(x[t][r], ap.beta, dr);
-                dv[r] = dr;
-            }
+            act_softplus4(x[t], ap.k, dv);
             *ap.sp.slot(spslot + t) = dv;
         }
     } else {
@@ -250,7 +240,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     const int wp = wave * 16 + p;     // pose within the workgroup
     ActP ap;
     ap.slope = args.slope;
-    ap.beta = args.beta;
+    ap.k = sp_consts(args.beta);
     ap.sp = SpRef{SP ? (const char*)(args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS) : nullptr, (uint32_t)tid * 16u};
     ap.stage = (char*)(smem + LDS_F) + wave * (16 * FSTRIDE * 4);
     ap.lane = lane;
@@ -315,6 +305,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
             asm volatile("" : "+v"(ap.sp.off));
         }
         uint32_t eb[6];
+        float poison = 0.f;      // softplus kernels: NaN for a pose that holds a NaN / infinity (joint_axis_norms), else +0
         uint32_t m2[4], m4[4], m6[1];
         f32x4 x6[4];
         f32x4 x4[32];
@@ -323,10 +314,10 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
             {
                 // ---------------- normalise + encoder forward (posendf.py:71, net_modules.py:162-169)
                 if (args.noenc) {
-                    noenc_forward(my_q, my_f, g);
+                    poison = noenc_forward<SP>(my_q, my_f, g);
                     ring_skip_encoder_section(ring);
                 } else {
-                    encoder_forward<SP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ap, g);
+                    poison = encoder_forward<SP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ap, g);
                 }
                 if (DBG && dbg && step == 0) {
                     for (int i = 0; i < NFEAT; ++i) dbg[(size_t)(DBG_FEAT + i) * WG_THREADS + tid] = my_f[i];
@@ -374,9 +365,10 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
         const float z7 = part + lds_bias[BIAS_OFF[6]];
         float gz7;
         if constexpr (SP) {
-            dval = act_softplus(z7, ap.beta, gz7);      // output Softplus, net_modules.py:39-41,69
+            dval = act_softplus(z7, ap.k, gz7) + poison;      // output Softplus, net_modules.py:39-41,69; NaN / inf poses: joint_axis_norms
+            gz7 += poison;
         } else {
-            dval = fmaxf(z7, 0.f);                       // output ReLU for relu AND lrelu, net_modules.py:30-37
+            dval = (z7 != z7) ? z7 : fmaxf(z7, 0.f);   // (relu(NaN) = NaN as in PyTorch; v_max alone returns 0)                       // output ReLU for relu AND lrelu, net_modules.py:30-37
             gz7 = (z7 > 0.f) ? 1.f : 0.f;
         }
         if (DBG && dbg && step == 0) dbg[(size_t)DBG_D * WG_THREADS + tid] = dval;

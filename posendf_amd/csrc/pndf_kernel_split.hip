@@ -88,7 +88,10 @@ __device__ __forceinline__ float lrelu_bit(float z, float slope, uint32_t& m) {
 // The fp32 accumulators of a layer then hold s_l sigma_in x the true value; one multiply per value in the epilogue
 // (`to_true * oscale`, per lane) turns that into the next operand, and forward accumulators start from b s_l sigma_in.
 struct SAct {
-    float slope, beta;
+    float slope;
+    float beta, b2, c, invb;      // softplus constants (SpK, pndf_device.h) as plain members: a nested struct behind the
+                                  // epilogue's reference ended up as a stack object, re-read from scratch inside the loops
+    __device__ __forceinline__ SpK k() const { return SpK{beta, b2, c, invb}; }
     SpRef sp;
     int spslot;
     float to_true;    // per lane: 1 / (s_l sigma_in): accumulator -> true pre-activation / gradient
@@ -331,8 +334,14 @@ struct SplitPhase {
     // Forward softplus: a value is ~16 instructions, three of them quarter-rate transcendentals (16 cycles each) -- as
     // one block behind an MFMA it stalls the pipe for ~120 cycles, so it is cut into SUB = 8 stages of at most one
     // transcendental or three plain instructions.
-    static constexpr int SUB = (SP && !BWD) ? 8 : 1;
-    static constexpr int NV = 4 * CT, NS = NV * SUB + 2 + 2 * CT, EPI_SLOTS = 4 * NT * (BG < 8 ? BG : 8);
+    // PNDF_SP_FORM 1 (round 4): the values go through the stages in PAIRS -- eleven stages per pair (5.5 per value instead of
+    // eight), the plain instructions as packed fp32 (act_softplus2, pndf_device.h), still at most one transcendental per stage.
+    // A pair is split into its hi / lo halves in its own last stage (the activated values never wait in registers for a
+    // separate split pass: eight registers less in a loop that has none to spare).
+    static constexpr bool SPF = SP && !BWD, SPP = SPF && PNDF_SP_FORM != 0;
+    static constexpr int SUB = SPP ? 11 : SPF ? 8 : 1;                        // stages per unit
+    static constexpr int NV = 4 * CT, NU = SPP ? NV / 2 : NV;                 // units: pairs of values, or values
+    static constexpr int NS = NU * SUB + 2 + (SPP ? 0 : 2 * CT), EPI_SLOTS = 4 * NT * (BG < 8 ? BG : 8);
     static_assert(BG >= 2, "the epilogue is dealt out over at least two groups of part B");
     struct Epi {
         f32x4 (&ch)[3][CT];
@@ -346,13 +355,21 @@ struct SplitPhase {
         uint32_t bits;
         unsigned hw[2 * CT], lw[2 * CT];
         float cf, k1, k0;
-        float sz, sbz, se, su, st2, sru, slg, sd;      // forward softplus: the value in flight (act_softplus, staged)
+        float sz, sbz, se, su, st2, sru, slg, sd;      // forward softplus, form 0: the value in flight (act_softplus, staged)
+        f32x2 pz, px, pe, pu, pt, pru, plg, pd;        // forward softplus, form 1: the PAIR in flight (act_softplus2, staged)
+        float kb2, kc, kinvb, ktt, kos;                // its constants, read ONCE per chunk as plain scalar loads of `act` and pinned:
+                                                       // splatted straight from the struct's fields into packed operands they
+                                                       // become overlapping vector loads that keep the whole SAct on the stack
         float smax;                                    // forward softplus: largest derivative of this lane's chunk values
 
         template <int S>
         __device__ __forceinline__ void step() {
             if constexpr (S == 0) {
                 cf = act.to_true * act.oscale;
+                if constexpr (SPP) {
+                    kb2 = act.b2; kc = act.c; kinvb = act.invb; ktt = act.to_true; kos = act.oscale;
+                    asm volatile("" : "+v"(kb2), "+v"(kc), "+v"(kinvb), "+v"(ktt), "+v"(kos));
+                }
                 if constexpr (SP && BWD) {
                     if (!(PNDF_SP_DIAG & 1)) wait_staged_derivatives<STAGE_YOUNGER>();
                 } else if constexpr (!BWD) {
@@ -367,7 +384,43 @@ struct SplitPhase {
                     k1 = (1.0f - act.slope) * cf;
                     k0 = act.slope * cf;
                 }
-            } else if constexpr (S <= NV * SUB) {
+            } else if constexpr (S <= NU * SUB && SPP) {
+                // forward softplus, pairs: values k0 = 2 u, k0 + 1 of the chunk (the same tile: four values per tile)
+                constexpr int u = (S - 1) / SUB, sub = (S - 1) % SUB, ci = (2 * u) / 4, r0 = (2 * u) % 4;
+                if constexpr (sub == 0) {
+                    pz = f32x2{ch[0][ci][r0], ch[0][ci][r0 + 1]} * ktt + f32x2{bt[ci][r0], bt[ci][r0 + 1]};
+                    px = pz * kb2;
+                } else if constexpr (sub == 1) {
+                    px[0] = vmin1(px[0], SP_CLAMP_LOG2);
+                    px[1] = vmin1(px[1], SP_CLAMP_LOG2);
+                    pe[0] = __builtin_amdgcn_exp2f(px[0]);
+                } else if constexpr (sub == 2) {
+                    pe[1] = __builtin_amdgcn_exp2f(px[1]);
+                } else if constexpr (sub == 3) {
+                    pu = pe + 1.0f;
+                    pt = pe - (pu - 1.0f);
+                } else if constexpr (sub == 4) {
+                    pru[0] = __builtin_amdgcn_rcpf(pu[0]);
+                } else if constexpr (sub == 5) {
+                    pru[1] = __builtin_amdgcn_rcpf(pu[1]);
+                } else if constexpr (sub == 6) {
+                    plg[0] = __builtin_amdgcn_logf(pu[0]);
+                } else if constexpr (sub == 7) {
+                    plg[1] = __builtin_amdgcn_logf(pu[1]);
+                } else if constexpr (sub == 8) {
+                    pt = pt * pru;
+                    plg = pt * kinvb + plg * kc;                      // the softplus value below the threshold
+                    pd = pe * pru;
+                } else if constexpr (sub == 9) {
+                    pz = f32x2{vmax1(pz[0], plg[0]), vmax1(pz[1], plg[1])} * kos;      // the scaled operand values
+                    smax = vmax3(smax, pd[0], pd[1]);
+                    bt[ci][r0] = pd[0];                              // the bias values are dead: their slot carries the derivatives
+                    bt[ci][r0 + 1] = pd[1];
+                    if constexpr (r0 == 2) *act.sp.slot(act.spslot + c * CT + ci) = bt[ci];
+                } else {
+                    split2<SINGLE>(pz[0], pz[1], hw[u], lw[u]);      // pair u = values (2 u, 2 u + 1) = dword u of the B operands
+                }
+            } else if constexpr (S <= NU * SUB) {
                 // forward relu family: from the HIGHEST value down, so that value k ends at bit k (lrelu_bit)
                 constexpr int v = (S - 1) / SUB, sub = (S - 1) % SUB;
                 constexpr int k = (!SP && !BWD) ? NV - 1 - v : v, ci = k / 4, r = k % 4;
@@ -393,7 +446,7 @@ struct SplitPhase {
                     } else if constexpr (sub == 6) {
                         const bool lin = sbz > 20.0f;
                         sd = lin ? 1.0f : sd;
-                        sz = lin ? sz : slg * __builtin_amdgcn_rcpf(act.beta);      // beta is uniform: hoisted
+                        sz = lin ? sz : slg * act.invb;
                     } else {
                         y[ci][r] = sz * act.oscale;
                         smax = fmaxf(smax, sd);
@@ -409,13 +462,20 @@ struct SplitPhase {
                     // derivative factor with the accumulator -> operand scale folded in (exact powers of two apart)
                     y[ci][r] = a * fmaf((float)((bits >> k) & 1u), k1, k0);
                 }
-            } else if constexpr (S == NV * SUB + 1) {
+            } else if constexpr (S == NU * SUB + 1) {
                 if constexpr (!SP && !BWD) {
                     asm volatile("" : "+v"(bits));      // pin the chain here (see pndf_kernel.hip act_tiles)
                     store_chunk_bits<CT>(mask, c, bits);
                 }
+                if constexpr (SPP) {
+#pragma unroll
+                    for (int b = 0; b < CB; ++b) {
+                        out[b].h = __builtin_bit_cast(f16x8, u32x4{hw[4 * b], hw[4 * b + 1], hw[4 * b + 2], hw[4 * b + 3]});
+                        out[b].l = __builtin_bit_cast(f16x8, u32x4{lw[4 * b], lw[4 * b + 1], lw[4 * b + 2], lw[4 * b + 3]});
+                    }
+                }
             } else {
-                constexpr int j = S - NV * SUB - 2, t = j / 2, h = j % 2;
+                constexpr int j = S - NU * SUB - 2, t = j / 2, h = j % 2;
                 split2<SINGLE>(y[t][2 * h], y[t][2 * h + 1], hw[j], lw[j]);
                 if constexpr (S == NS - 1) {
 #pragma unroll
@@ -696,13 +756,10 @@ __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             f32x4 dv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float dr;
-                x[t][r] = act_softplus(x[t][r] * act.to_true, act.beta, dr);
-                dv[r] = dr;
-                dm[r] = fmaxf(dm[r], dr);
-            }
+            x[t] = x[t] * act.to_true;
+            act_softplus4(x[t], act.k(), dv);
+            dm[0] = vmax3(dm[0], dv[0], dv[1]);
+            dm[1] = vmax3(dm[1], dv[2], dv[3]);
             *act.sp.slot(act.spslot + t) = dv;
         }
         dmax = pose_max(fmaxf(fmaxf(dm[0], dm[1]), fmaxf(dm[2], dm[3])));
@@ -776,7 +833,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
     const int wp = wave * 16 + p;
     ActP ap;
     ap.slope = args.slope;
-    ap.beta = args.beta;
+    ap.k = sp_consts(args.beta);
     ap.sp = SpRef{SP ? (const char*)(args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS) : nullptr, (uint32_t)tid * 16u};
     // uniform constants of the packer: 1 / weight scale of lin0..lin5 (powers of two) and the norms behind the a-priori
     // bounds of the chunked layers (pndf_layout.h NORM_OFF)
@@ -790,7 +847,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
     // layer l, operand of scale sigma_in coming in (per lane), operand of scale sigma_out going out (see SAct)
     auto layer = [&](int spslot, int l, float sigma_in, float sigma_out) {
         const float to_true = inv_w[l] * pow2_rcp(sigma_in);
-        return SAct{args.slope, args.beta, ap.sp, spslot, to_true, sigma_out, pow2_rcp(to_true),
+        return SAct{args.slope, ap.k.beta, ap.k.b2, ap.k.c, ap.k.invb, ap.sp, spslot, to_true, sigma_out, pow2_rcp(to_true),
                     (char*)(smem + LDS_F) + wave * (16 * FSTRIDE * 4), lane};
     };
     float* const lds_bias = (float*)(smem + LDS_BIAS);
@@ -852,6 +909,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
             asm volatile("" : "+v"(ap.sp.off));
         }
         uint32_t eb[6];
+        float poison = 0.f;      // softplus kernels: NaN for a pose that holds a NaN / infinity (joint_axis_norms), else +0
         uint32_t m2[4], m4[4], m6[1];
         f32x4 x6[4];
         Blk b4[16];
@@ -864,10 +922,10 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
             Blk b2[16];
             {
                 if (args.noenc) {
-                    noenc_forward(my_q, my_f, g);
+                    poison = noenc_forward<SP>(my_q, my_f, g);
                     ring_skip_encoder_section(ring);
                 } else {
-                    encoder_forward<SP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ap, g);
+                    poison = encoder_forward<SP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ap, g);
                 }
                 // x0: the pose's 128 feature rows, bound measured, scaled per pose (see SAct)
                 f32x4 f0[8];
@@ -940,9 +998,10 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
         const float z7 = part + lds_bias[BIAS_OFF[6]];
         float gz7;
         if constexpr (SP) {
-            dval = act_softplus(z7, ap.beta, gz7);      // output Softplus, net_modules.py:39-41,69
+            dval = act_softplus(z7, ap.k, gz7) + poison;      // output Softplus, net_modules.py:39-41,69; NaN / inf poses: joint_axis_norms
+            gz7 += poison;
         } else {
-            dval = fmaxf(z7, 0.f);                       // output ReLU for relu AND lrelu, net_modules.py:30-37
+            dval = (z7 != z7) ? z7 : fmaxf(z7, 0.f);   // (relu(NaN) = NaN as in PyTorch; v_max alone returns 0)                       // output ReLU for relu AND lrelu, net_modules.py:30-37
             gz7 = (z7 > 0.f) ? 1.f : 0.f;
         }
         if (args.mode == MODE_FORWARD) break;

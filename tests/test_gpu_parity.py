@@ -351,12 +351,15 @@ def test_side_stream_and_graph_capture(torch_cuda, act, precision):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-def test_nonfinite_pose_stays_in_its_row(torch_cuda, precision):
+@pytest.mark.parametrize("act", ["lrelu", "softplus"])
+def test_nonfinite_pose_stays_in_its_row(torch_cuda, precision, act):
     """Poses are independent rows (model/posendf.py:64 reshapes to [B,21,4]): a NaN pose poisons only its own
-    distance and gradient, as in the reference, and its 63 workgroup neighbours are bit-identical."""
+    distance and gradient, as in the reference, and its 63 workgroup neighbours are bit-identical.  Softplus too (round 4:
+    the hardware min / max of its evaluation drop a NaN operand; the kernels carry it past them, pndf_device.h
+    joint_axis_norms), for a NaN and for an infinity (F.normalize turns inf into inf / inf)."""
     torch = torch_cuda
     from posendf_amd import synth
-    net = make_net(torch, "lrelu", "live", precision=precision)
+    net = make_net(torch, act, "live", precision=precision)
     q = torch.from_numpy(synth.make_poses(128, seed=11)).cuda()
     clean_q, clean_d = net.project(q, steps=3)
     bad = q.clone()
@@ -367,6 +370,16 @@ def test_nonfinite_pose_stays_in_its_row(torch_cuda, precision):
     keep[37] = False
     assert torch.equal(got_q[keep], clean_q[keep]) and torch.equal(got_d[keep], clean_d[keep])
     assert not torch.isfinite(got_q[37]).all()
+    for poison in (float("nan"), float("inf")):
+        bad = q.clone()
+        bad[90, 11, 0] = poison
+        bad.requires_grad_(True)
+        d = net(bad, train=False)["dist_pred"]
+        (g,) = torch.autograd.grad(d.sum(), bad)
+        assert torch.isnan(d[90]).all() and torch.isnan(g[90]).any(), (act, poison, d[90], g[90].isnan().sum())
+        ok = torch.ones(128, dtype=torch.bool, device="cuda")
+        ok[90] = False
+        assert torch.isfinite(d[ok]).all() and torch.isfinite(g[ok]).all()
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)

@@ -230,3 +230,60 @@ def test_other_kinematic_tree_takes_the_generic_per_frame_kernels(lbs_precision)
         _, J0 = lbs_np.lbs(th0[s_], m)
         g64, _ = lbs_np.body_terms(th[s_], J0, m, 2)
         assert np.abs(g[s_] - g64).max() < TOL * np.abs(g64).max()
+
+
+def test_constructor_and_argument_hardening(tmp_path):
+    """what the constructor and the raw-pointer entry points must not accept silently."""
+    from posendf_amd import BodyModel
+    from posendf_amd.engine import PndfError
+    m = lbs_np.synthetic_model(V=137, seed=9, extra=(5, 60, 136))
+    parents_before = np.array(m["parents"], copy=True)
+    m_i32 = dict(m, parents=np.ascontiguousarray(m["parents"], dtype=np.int32))
+    with pytest.raises(PndfError):                                      # validated before anything is created
+        BodyModel(m, device="cuda:0", precision="bf16")
+    with pytest.raises(PndfError):                                      # a vertex named twice
+        BodyModel(m, device="cuda:0", extra_joint_vertex=(5, 5, 136))
+    bm = BodyModel(m_i32, device="cuda:0")
+    assert np.array_equal(m_i32["parents"], parents_before)             # the caller's table keeps its root entry
+    th = _theta(2, 9, seed=3) * 0.4
+    # betas shorter than num_betas are zero padded (the host read used to run past the array); the model's own betas are the default
+    betas = np.array([0.7, -0.4, 0.2], np.float32)
+    b_short = BodyModel(m, device="cuda:0", betas=betas)
+    full = np.zeros(10, np.float32)
+    full[:3] = betas
+    assert np.array_equal(b_short.betas.cpu().numpy(), full)
+    V64, J64 = lbs_np.lbs(th.reshape(-1, 69), dict(m, betas=full))
+    out = b_short(pose_body=torch.from_numpy(th.reshape(-1, 69)))
+    assert _rel(out.vertices.cpu().numpy(), V64) < 1e-5 and _rel(out.Jtr.cpu().numpy(), J64) < 1e-5
+    b_own = BodyModel(dict(m, betas=full), device="cuda:0")              # params['betas'] is what rest_shape() of the oracle uses
+    assert torch.equal(b_own(pose_body=torch.from_numpy(th.reshape(-1, 69))).vertices, out.vertices)
+    # from_arrays / from_npz(faces=...)
+    b_arr = BodyModel.from_arrays(m["v_template"], m["shapedirs"], m["posedirs"], m["J_regressor"], m["parents"], m["lbs_weights"],
+                                  extra_joint_vertex=(5, 60, 136), device="cuda:0")
+    assert torch.equal(b_arr.joints_of(torch.from_numpy(th)), bm.joints_of(torch.from_numpy(th)))
+    faces = np.arange(12, dtype=np.int64).reshape(4, 3)
+    np.savez(tmp_path / "model.npz", **{k: v for k, v in m.items()}, f=faces + 1)
+    assert np.array_equal(BodyModel.from_npz(tmp_path / "model.npz", device="cuda:0").faces_tensor.cpu().numpy(), faces + 1)
+    assert np.array_equal(BodyModel.from_npz(tmp_path / "model.npz", device="cuda:0", faces=faces).faces_tensor.cpu().numpy(), faces)
+    # forward hands back the caller's own [N,69] tensor (smplx does: the reference feeds body_pose into the next step)
+    pose = torch.from_numpy(th.reshape(-1, 69)).cuda().requires_grad_(True)
+    assert bm(pose_body=pose).body_pose is pose
+    zeros = torch.zeros(1, 10, device="cuda")
+    for _ in range(3):                                                  # the reference passes the same zero betas every step
+        bm(pose_body=pose, betas=zeros)
+    with pytest.raises(PndfError):
+        bm(pose_body=pose, betas=torch.ones(1, 10, device="cuda"))
+    # terms_grad: inputs are coerced, a wrong output buffer or shape is refused
+    th_t = torch.from_numpy(th).cuda()
+    j0 = bm.joints_of(th_t + 0.02)
+    want = bm.terms_grad(th_t, j0, 2)
+    strided = torch.empty(2, 9, 138, device="cuda")[:, :, ::2]
+    strided.copy_(th_t)
+    assert not strided.is_contiguous() and torch.equal(bm.terms_grad(strided, j0.double(), 2), want)
+    assert torch.equal(bm.terms_grad(th_t.cpu(), j0.cpu(), 2), want)
+    with pytest.raises(PndfError):
+        bm.terms_grad(th_t, j0, 2, out=torch.empty(2, 9, 69, device="cuda", dtype=torch.float64))
+    with pytest.raises(PndfError):
+        bm.terms_grad(th_t, j0[:-1], 2)
+    with pytest.raises(PndfError):
+        bm.terms_grad(th_t.reshape(-1, 69), j0, 2)

@@ -166,3 +166,18 @@ def test_pack_refuses_bad_models():
                          arrs[4].ctypes.data, p.ctypes.data, w.ctypes.data, e.ctypes.data, len(e), blob.ctypes.data, None, None)
     assert lib.pndf_lbs_pack_host(*args(np.ascontiguousarray(par, dtype=np.int32), np.ascontiguousarray([1], dtype=np.int32))) == -4
     assert lib.pndf_lbs_pack_host(*args(np.ascontiguousarray(m["parents"], dtype=np.int32), ex)) == -1      # vertex 25 >= V
+    # a vertex named twice: refused (the vertex kernels serve one picked joint per vertex)
+    good = np.ascontiguousarray(m["parents"], dtype=np.int32)
+    assert lib.pndf_lbs_pack_host(*args(good, np.ascontiguousarray([1, 2], dtype=np.int32))) == 0
+    assert lib.pndf_lbs_pack_host(*args(good, np.ascontiguousarray([2, 2], dtype=np.int32))) == -1
+
+
+def test_synthetic_models_never_pick_a_vertex_twice():
+    """the default SMPL table folded into a small cloud (`% V`) used to produce duplicates silently"""
+    from posendf_amd import synth
+    for V in (21, 30, 137, 500, 3000, synth.SMPL_V):
+        ex = synth.make_body_model(V=V, seed=1)["extra_joint_vertex"]
+        assert len(ex) == 21 and len(set(ex.tolist())) == 21 and ex.min() >= 0 and ex.max() < V
+    assert np.array_equal(synth.make_body_model(seed=1)["extra_joint_vertex"], np.asarray(synth.SMPL_EXTRA_JOINT_VERTICES))
+    with pytest.raises(ValueError):
+        synth.make_body_model(V=20, seed=1)
