@@ -114,15 +114,34 @@ class GpuTelemetry:
         self.period = period_s
         self.samples = []
         self.src = None
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
-        amd = [c for c in cards if os.path.exists(os.path.join(c, "freq1_input"))
-               and (os.path.exists(os.path.join(c, "power1_average")) or os.path.exists(os.path.join(c, "power1_input")))]
-        if amd:
-            h = amd[min(index, len(amd) - 1)]
-            self.src = (os.path.join(h, "freq1_input"),
-                        os.path.join(h, "power1_average" if os.path.exists(os.path.join(h, "power1_average")) else "power1_input"))
+        self.how = "unavailable"
         self._stop = None
         self._thread = None
+        cands = []
+        for h in sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*")):
+            f = os.path.join(h, "freq1_input")
+            pw = next((os.path.join(h, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(h, n))), None)
+            if os.path.exists(f) and pw:
+                pci = os.path.basename(os.path.realpath(os.path.join(h, "..", "..")))     # .../<domain:bus:dev.fn>/hwmon/hwmonN
+                cands.append((pci.lower(), f, pw))
+        if not cands:
+            return
+        # a node shows the hwmon files of ALL its GPUs, the process sees one: match the HIP device by its PCI address
+        want = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:
+            pass
+        hit = [c for c in cands if c[0] == want]
+        if hit:
+            self.src = [hit[0][1:]]
+            self.how = f"amdgpu hwmon of {want} ({os.path.basename(hit[0][2])}, freq1_input), median over the timed loop"
+        else:      # no PCI match (container without the address): sample all, report the busiest one
+            self.src = [c[1:] for c in cands]
+            self.how = (f"amdgpu hwmon ({os.path.basename(cands[0][2])}, freq1_input): busiest of {len(cands)} devices visible in "
+                        "sysfs, median over the timed loop")
 
     @staticmethod
     def _read(path):
@@ -140,9 +159,11 @@ class GpuTelemetry:
 
         def loop():
             while not self._stop.is_set():
-                f, p = self._read(self.src[0]), self._read(self.src[1])
-                if f is not None and p is not None:
-                    self.samples.append((f / 1e6, p / 1e6))      # Hz -> MHz, uW -> W
+                row = []
+                for fpath, ppath in self.src:
+                    f, p = self._read(fpath), self._read(ppath)
+                    row.append((f / 1e6, p / 1e6) if (f is not None and p is not None) else None)      # Hz -> MHz, uW -> W
+                self.samples.append(row)
                 self._stop.wait(self.period)
         self._thread = threading.Thread(target=loop, daemon=True)
         self._thread.start()
@@ -154,10 +175,15 @@ class GpuTelemetry:
 
     def summary(self):
         import statistics
-        if self.samples:
-            return {"sclk_mhz": statistics.median(s[0] for s in self.samples),
-                    "package_w": statistics.median(s[1] for s in self.samples), "telemetry_samples": len(self.samples),
-                    "telemetry_source": "amdgpu hwmon (freq1_input, power1_average), median over the timed loop"}
+        best = None
+        for k in range(len(self.src or [])):
+            col = [r[k] for r in self.samples if r[k] is not None]
+            if col:
+                cand = (statistics.median(c[1] for c in col), statistics.median(c[0] for c in col), len(col))
+                if best is None or cand[0] > best[0]:
+                    best = cand
+        if best:
+            return {"sclk_mhz": best[1], "package_w": best[0], "telemetry_samples": best[2], "telemetry_source": self.how}
         return {"sclk_mhz": None, "package_w": None, "telemetry_samples": 0, "telemetry_source": "unavailable"}
 
 
@@ -361,7 +387,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     tele.stop()
-    telemetry = tele.summary() if tele.samples or smi is None else smi
+    telemetry = tele.summary() if (tele.samples or smi is None) else smi
     kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) if args.steps else float("nan")
     gather_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) if (args.steps and use_dist) else 0.0
     per_rank = None

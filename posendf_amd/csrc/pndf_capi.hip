@@ -136,8 +136,12 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
     hipError_t e = hipMalloc((void**)&h->d_stream, (size_t)(STEP_TILES + STREAM_PAD_SLOTS * SLOT_TILES) * TILE_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias, BIAS_FLOATS * sizeof(float));
     if (e == hipSuccess && cfg->act == PNDF_ACT_SOFTPLUS) {
-        e = hipMalloc((void**)&h->d_scratch,
-                      (size_t)h->resident_wgs * pndf_kernel_softplus_scratch_floats_per_wg() * sizeof(float));
+        const size_t sbytes = (size_t)h->resident_wgs * pndf_kernel_softplus_scratch_floats_per_wg() * sizeof(float);
+        // PNDF_SP_SCRATCH=uncached|finegrained: memory-type experiments on the derivative scratch (profiles/r04/sp_forward_diag.txt)
+        const char* mt = getenv("PNDF_SP_SCRATCH");
+        if (mt && mt[0] == 'u') e = hipExtMallocWithFlags((void**)&h->d_scratch, sbytes, hipDeviceMallocUncached);
+        else if (mt && mt[0] == 'f') e = hipExtMallocWithFlags((void**)&h->d_scratch, sbytes, hipDeviceMallocFinegrained);
+        else e = hipMalloc((void**)&h->d_scratch, sbytes);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->sp_done, hipEventDisableTiming);
     }
     if (e == hipSuccess)

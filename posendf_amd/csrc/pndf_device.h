@@ -133,7 +133,13 @@ __device__ __forceinline__ void ring_dma(Ring& r) {
 
 __device__ __forceinline__ void ring_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // at most two slot fetches (4 pieces each) of this wave may still be in flight
-__device__ __forceinline__ void ring_wait_next_slot() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+#ifndef PNDF_SP_DIAG
+#define PNDF_SP_DIAG 0
+#endif
+__device__ __forceinline__ void ring_wait_next_slot() {
+    if (PNDF_SP_DIAG & 32) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // (timing diagnostic only: see pndf_kernel_split.hip)
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
 
 // slots 0..3 into buffers 0..3; the caller waits vmcnt(0) + barrier.  The first slot boundary makes buffer 0 current
 // and buffer 4 "previous", so the first mid-slot fetch (slot 4) fills buffer 4.
@@ -262,14 +268,39 @@ __device__ __forceinline__ float vmax1(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// The same v_max whose result may be the A / B operand of the NEXT instruction, an MFMA: a VGPR written by a VALU
+// instruction needs wait states before an MFMA reads it as an operand, hipcc pads them for its own instructions but not for
+// the inside of an asm statement (cdna_hip_programming.md 5.7 item 2) -- without the pad the encoder's MFMAs read the
+// PREVIOUS contents of the register (found by bisecting the sites of form 1 on the hardware, round 4: every site whose
+// result passes through another VALU instruction first was right, the encoder -- activation straight into the next
+// layer's MFMA -- was wrong).
+__device__ __forceinline__ float vmax1_mfma(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 
+// per-site overrides for bisection builds (default: PNDF_SP_FORM everywhere)
+#ifndef PNDF_SP_FORM_OUT
+#define PNDF_SP_FORM_OUT PNDF_SP_FORM
+#endif
+#ifndef PNDF_SP_FORM_ENC
+#define PNDF_SP_FORM_ENC PNDF_SP_FORM
+#endif
+#ifndef PNDF_SP_FORM_TILES
+#define PNDF_SP_FORM_TILES PNDF_SP_FORM
+#endif
+#ifndef PNDF_SP_FORM_CHUNK
+#define PNDF_SP_FORM_CHUNK PNDF_SP_FORM
+#endif
+template <int FORM = PNDF_SP_FORM>
 __device__ __forceinline__ float act_softplus(float z, const SpK& k, float& deriv) {
-#if PNDF_SP_FORM == 0
+  if constexpr (FORM == 0) {
     const float bz = z * k.beta;
     const float e = __builtin_amdgcn_exp2f(fminf(bz, 20.0f) * 1.44269504088896341f);
     const bool lin = bz > 20.0f;
@@ -278,26 +309,28 @@ __device__ __forceinline__ float act_softplus(float z, const SpK& k, float& deri
     const float l = fmaf(e - (u - 1.0f), ru, __builtin_amdgcn_logf(u) * 0.693147180559945309f);
     deriv = lin ? 1.0f : e * ru;
     return lin ? z : l * k.invb;
-#else
+  } else {
     const float e = __builtin_amdgcn_exp2f(vmin1(z * k.b2, SP_CLAMP_LOG2));
     const float u = 1.0f + e;
     const float ru = __builtin_amdgcn_rcpf(u);
     const float t = (e - (u - 1.0f)) * ru;
     deriv = e * ru;
     return vmax1(z, fmaf(t, k.invb, __builtin_amdgcn_logf(u) * k.c));
-#endif
+  }
 }
 
 // two values at once: the plain instructions as packed fp32
+// TO_MFMA: the activated values are MFMA operands as they are (the encoder, the fp32 kernel's trunk)
+template <int FORM = PNDF_SP_FORM, bool TO_MFMA = false>
 __device__ __forceinline__ f32x2 act_softplus2(f32x2 z, const SpK& k, f32x2& deriv) {
-#if PNDF_SP_FORM == 0
+  if constexpr (FORM == 0) {
     f32x2 y;
     float d0, d1;
-    y[0] = act_softplus(z[0], k, d0);
-    y[1] = act_softplus(z[1], k, d1);
+    y[0] = act_softplus<0>(z[0], k, d0);
+    y[1] = act_softplus<0>(z[1], k, d1);
     deriv = f32x2{d0, d1};
     return y;
-#else
+  } else {
     const f32x2 x = z * k.b2;
     f32x2 e;
     e[0] = __builtin_amdgcn_exp2f(vmin1(x[0], SP_CLAMP_LOG2));
@@ -309,15 +342,19 @@ __device__ __forceinline__ f32x2 act_softplus2(f32x2 z, const SpK& k, f32x2& der
     lg[0] = __builtin_amdgcn_logf(u[0]);
     lg[1] = __builtin_amdgcn_logf(u[1]);
     const f32x2 t = (e - (u - 1.0f)) * ru;
-    const f32x2 sp = t * k.invb + lg * k.c;          // (contracted to one packed fma)
+    // which of the two products is fused with the sum is pinned (the two-term and three-term split kernels must agree bit
+    // for bit: left to -ffp-contract each instantiation chose for itself)
+    const f32x2 sp = __builtin_elementwise_fma(t, f32x2{k.invb, k.invb}, lg * k.c);
     deriv = e * ru;
-    return f32x2{vmax1(z[0], sp[0]), vmax1(z[1], sp[1])};
-#endif
+    if constexpr (TO_MFMA) return f32x2{vmax1_mfma(z[0], sp[0]), vmax1_mfma(z[1], sp[1])};
+    else return f32x2{vmax1(z[0], sp[0]), vmax1(z[1], sp[1])};
+  }
 }
 // a whole C/D tile register set (4 values per lane)
+template <int FORM = PNDF_SP_FORM, bool TO_MFMA = false>
 __device__ __forceinline__ void act_softplus4(f32x4& z, const SpK& k, f32x4& deriv) {
     f32x2 d0, d1;
-    const f32x2 y0 = act_softplus2(f32x2{z[0], z[1]}, k, d0), y1 = act_softplus2(f32x2{z[2], z[3]}, k, d1);
+    const f32x2 y0 = act_softplus2<FORM, TO_MFMA>(f32x2{z[0], z[1]}, k, d0), y1 = act_softplus2<FORM, TO_MFMA>(f32x2{z[2], z[3]}, k, d1);
     z = f32x4{y0[0], y0[1], y1[0], y1[1]};
     deriv = f32x4{d0[0], d0[1], d1[0], d1[1]};
 }
@@ -329,10 +366,24 @@ __device__ __forceinline__ void act_softplus4(f32x4& z, const SpK& k, f32x4& der
 // + a 32-bit per-lane byte offset: `global_load/store v_off, .., s[base:base+1]`.  As per-lane 64-bit pointers (round 1)
 // the ~200 slot addresses were computed ahead, hoisted and spilled -- and every spill reload is a VMEM load whose
 // vmcnt(0) drains the ring's DMA.
+#ifndef PNDF_SP_NT
+#define PNDF_SP_NT 0
+#endif
 struct SpRef {
     const char* base;   // uniform: this workgroup's block of the scratch
     uint32_t off;       // per lane: tid * 16
     __device__ __forceinline__ f32x4* slot(int s) const { return (f32x4*)(const_cast<char*>(base) + (uint32_t)(off + (uint32_t)s * (WG_THREADS * 16u))); }
+    // the parked derivatives are written once and read once, 843 KB per workgroup and step: PNDF_SP_NT marks these accesses
+    // non-temporal (1 = the chunk layers' stores, 2 = every store, 4 = the loads) so that they do not push the weight stream out of L2
+    template <int KIND>
+    __device__ __forceinline__ void put(int s, const f32x4& v) const {
+        if constexpr ((PNDF_SP_NT & KIND) != 0) __builtin_nontemporal_store(v, slot(s));
+        else *slot(s) = v;
+    }
+    __device__ __forceinline__ f32x4 get(int s) const {
+        if constexpr ((PNDF_SP_NT & 4) != 0) return __builtin_nontemporal_load(slot(s));
+        else return *slot(s);
+    }
 };
 struct ActP {
     float slope;        // relu family
@@ -350,7 +401,10 @@ __device__ __forceinline__ void stage_derivative_tile(const SpRef& sp, int slot,
     // wave-uniform by construction (the wave's window); readfirstlane keeps it in an SGPR whatever hipcc infers
     const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(PNDF_LDS char*)stage_tile);
     const uint32_t off = sp.off + (uint32_t)slot * (WG_THREADS * 16u);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(sp.base), "s"(dst) : "memory", "m0");
+    if constexpr ((PNDF_SP_NT & 4) != 0)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(off), "s"(sp.base), "s"(dst) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(sp.base), "s"(dst) : "memory", "m0");
 }
 template <int YOUNGER>
 __device__ __forceinline__ void wait_staged_derivatives() {
@@ -444,8 +498,8 @@ __device__ __forceinline__ float enc_act(f32x4& z, const ActP& ap, int spslot) {
     float bitsum = 0.f;
     if constexpr (SP) {
         f32x4 dv;
-        act_softplus4(z, ap.k, dv);
-        *ap.sp.slot(spslot) = dv;
+        act_softplus4<PNDF_SP_FORM_ENC, true>(z, ap.k, dv);
+        ap.sp.put<2>(spslot, dv);
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -679,7 +733,7 @@ __device__ __forceinline__ void encoder_backward(float* my_f, float* my_gn, cons
     f32x4 D[SP ? 2 * NJ : 1];
     if constexpr (SP) {
 #pragma unroll
-        for (int i = 0; i < 2 * NJ; ++i) D[i] = *ap.sp.slot(SP_SLOT_ENC + i);
+        for (int i = 0; i < 2 * NJ; ++i) D[i] = ap.sp.get(SP_SLOT_ENC + i);
     }
     f32x4 t[4];
     enc_tiles<0, enc_bwd_pairable(NJ - 1) ? 4 : 2>(t, ring);

@@ -87,11 +87,10 @@ struct PhaseBody {
                     if constexpr (SP) {
 #pragma unroll
                         for (int ci = 0; ci < CT; ++ci) {
-                            f32x4* slot = ap.sp.slot(spslot + c * CT + ci);
                             if (!BWD) {
                                 f32x4 dv;
-                                act_softplus4(ch[ci], ap.k, dv);
-                                *slot = dv;
+                                act_softplus4<PNDF_SP_FORM_CHUNK, true>(ch[ci], ap.k, dv);
+                                ap.sp.put<1>(spslot + c * CT + ci, dv);
                             } else {
                                 if (ci == 0) wait_staged_derivatives<(KA * CT / 4 < 12) ? KA * CT / 4 : 12>();
                                 ch[ci] = ch[ci] * *(const f32x4*)(ap.stage + ci * 1024 + ap.lane * 16);
@@ -180,8 +179,8 @@ __device__ __forceinline__ void act_tiles(f32x4 (&x)[NT], uint32_t (&m)[(NT * 4 
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             f32x4 dv;
-            act_softplus4(x[t], ap.k, dv);
-            *ap.sp.slot(spslot + t) = dv;
+            act_softplus4<PNDF_SP_FORM_TILES, true>(x[t], ap.k, dv);
+            ap.sp.put<2>(spslot + t, dv);
         }
     } else {
         constexpr int NW = (NT * 4 + 31) / 32;
@@ -218,7 +217,7 @@ __device__ __forceinline__ void dact_tiles(f32x4 (&gx)[NT], const uint32_t (&m)[
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if constexpr (SP) {
-            gx[t] = gx[t] * *sp.slot(spslot + t);
+            gx[t] = gx[t] * sp.get(spslot + t);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -365,7 +364,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
         const float z7 = part + lds_bias[BIAS_OFF[6]];
         float gz7;
         if constexpr (SP) {
-            dval = act_softplus(z7, ap.k, gz7) + poison;      // output Softplus, net_modules.py:39-41,69; NaN / inf poses: joint_axis_norms
+            dval = act_softplus<PNDF_SP_FORM_OUT>(z7, ap.k, gz7) + poison;      // output Softplus, net_modules.py:39-41,69; NaN / inf poses: joint_axis_norms
             gz7 += poison;
         } else {
             dval = (z7 != z7) ? z7 : fmaxf(z7, 0.f);   // (relu(NaN) = NaN as in PyTorch; v_max alone returns 0)                       // output ReLU for relu AND lrelu, net_modules.py:30-37

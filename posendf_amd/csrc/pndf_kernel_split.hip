@@ -12,9 +12,17 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-#ifndef PNDF_SP_DIAG
-#define PNDF_SP_DIAG 0      // timing diagnostics of the softplus backward staging (WRONG results): 1 = no wait for the staged tiles,
-#endif                      // 2 = no staging DMA either (profiles/r03/sp_stage_diag.txt)
+#ifndef PNDF_SP_PARK
+#define PNDF_SP_PARK 1      // forward chunk layers: 1 = every derivative tile is stored as it is produced (default); N = tiles parked in
+                            // LDS and stored N at a time (an experiment that did not pay: 101.6 against 100.3 ms, profiles/r04/sp_forward_diag.txt)
+#endif
+#ifndef PNDF_SP_DIAG_DOC   // (the macro itself is defined in pndf_device.h, included above: bit 32 lives in the ring)
+#define PNDF_SP_DIAG_DOC 0  // timing diagnostics of the softplus kernels (WRONG results): 1 = no wait for the staged tiles of the backward
+#endif                      // pass, 2 = no staging DMA either (profiles/r03/sp_stage_diag.txt); round 4, forward chunk epilogue: 4 = the
+                            // derivative tiles are not stored, 8 = the three transcendentals of a value are plain multiplies
+                            // 16 = they all go to ONE slot per layer (an L2-resident line), 32 = the ring's counted wait tolerates two more
+                            // operations in flight (pndf_device.h; UNSAFE), 64 = only every other tile is stored, 128 = two 8-byte stores per lane
+                            // instead of one 16-byte store (profiles/r04/sp_forward_diag.txt)
 
 namespace {
 
@@ -338,7 +346,7 @@ struct SplitPhase {
     // eight), the plain instructions as packed fp32 (act_softplus2, pndf_device.h), still at most one transcendental per stage.
     // A pair is split into its hi / lo halves in its own last stage (the activated values never wait in registers for a
     // separate split pass: eight registers less in a loop that has none to spare).
-    static constexpr bool SPF = SP && !BWD, SPP = SPF && PNDF_SP_FORM != 0;
+    static constexpr bool SPF = SP && !BWD, SPP = SPF && PNDF_SP_FORM_CHUNK != 0;
     static constexpr int SUB = SPP ? 11 : SPF ? 8 : 1;                        // stages per unit
     static constexpr int NV = 4 * CT, NU = SPP ? NV / 2 : NV;                 // units: pairs of values, or values
     static constexpr int NS = NU * SUB + 2 + (SPP ? 0 : 2 * CT), EPI_SLOTS = 4 * NT * (BG < 8 ? BG : 8);
@@ -388,35 +396,59 @@ struct SplitPhase {
                 // forward softplus, pairs: values k0 = 2 u, k0 + 1 of the chunk (the same tile: four values per tile)
                 constexpr int u = (S - 1) / SUB, sub = (S - 1) % SUB, ci = (2 * u) / 4, r0 = (2 * u) % 4;
                 if constexpr (sub == 0) {
-                    pz = f32x2{ch[0][ci][r0], ch[0][ci][r0 + 1]} * ktt + f32x2{bt[ci][r0], bt[ci][r0 + 1]};
+                    pz = __builtin_elementwise_fma(f32x2{ch[0][ci][r0], ch[0][ci][r0 + 1]}, f32x2{ktt, ktt}, f32x2{bt[ci][r0], bt[ci][r0 + 1]});
                     px = pz * kb2;
                 } else if constexpr (sub == 1) {
                     px[0] = vmin1(px[0], SP_CLAMP_LOG2);
                     px[1] = vmin1(px[1], SP_CLAMP_LOG2);
-                    pe[0] = __builtin_amdgcn_exp2f(px[0]);
+                    pe[0] = (PNDF_SP_DIAG & 8) ? px[0] * 0.03f : __builtin_amdgcn_exp2f(px[0]);
                 } else if constexpr (sub == 2) {
-                    pe[1] = __builtin_amdgcn_exp2f(px[1]);
+                    pe[1] = (PNDF_SP_DIAG & 8) ? px[1] * 0.03f : __builtin_amdgcn_exp2f(px[1]);
                 } else if constexpr (sub == 3) {
                     pu = pe + 1.0f;
                     pt = pe - (pu - 1.0f);
                 } else if constexpr (sub == 4) {
-                    pru[0] = __builtin_amdgcn_rcpf(pu[0]);
+                    pru[0] = (PNDF_SP_DIAG & 8) ? pu[0] * 0.5f : __builtin_amdgcn_rcpf(pu[0]);
                 } else if constexpr (sub == 5) {
-                    pru[1] = __builtin_amdgcn_rcpf(pu[1]);
+                    pru[1] = (PNDF_SP_DIAG & 8) ? pu[1] * 0.5f : __builtin_amdgcn_rcpf(pu[1]);
                 } else if constexpr (sub == 6) {
-                    plg[0] = __builtin_amdgcn_logf(pu[0]);
+                    plg[0] = (PNDF_SP_DIAG & 8) ? pu[0] * 0.25f : __builtin_amdgcn_logf(pu[0]);
                 } else if constexpr (sub == 7) {
-                    plg[1] = __builtin_amdgcn_logf(pu[1]);
+                    plg[1] = (PNDF_SP_DIAG & 8) ? pu[1] * 0.25f : __builtin_amdgcn_logf(pu[1]);
                 } else if constexpr (sub == 8) {
                     pt = pt * pru;
-                    plg = pt * kinvb + plg * kc;                      // the softplus value below the threshold
+                    plg = __builtin_elementwise_fma(pt, f32x2{kinvb, kinvb}, plg * kc);      // the value below the threshold (fma pinned: see act_softplus2)
                     pd = pe * pru;
                 } else if constexpr (sub == 9) {
                     pz = f32x2{vmax1(pz[0], plg[0]), vmax1(pz[1], plg[1])} * kos;      // the scaled operand values
                     smax = vmax3(smax, pd[0], pd[1]);
                     bt[ci][r0] = pd[0];                              // the bias values are dead: their slot carries the derivatives
                     bt[ci][r0 + 1] = pd[1];
-                    if constexpr (r0 == 2) *act.sp.slot(act.spslot + c * CT + ci) = bt[ci];
+                    if constexpr (r0 == 2 && !(PNDF_SP_DIAG & 4) && !((PNDF_SP_DIAG & 64) && ci % 2 == 1)) {
+                        if constexpr ((PNDF_SP_DIAG & 128) != 0) {      // (diagnostic: the same bytes as two 8-byte stores per lane)
+                            f32x2* p2 = (f32x2*)act.sp.slot(act.spslot + c * CT + ci);
+                            p2[0] = f32x2{bt[ci][0], bt[ci][1]};
+                            p2[1] = f32x2{bt[ci][2], bt[ci][3]};
+                        } else if constexpr (PNDF_SP_PARK > 1) {
+                            // (experiment, off by default) the derivative tile is PARKED in LDS -- this wave's feature rows, free between
+                            // the packing of x0 and the end of the backward trunk -- and PNDF_SP_PARK tiles leave for the scratch
+                            // together.  Built on the guess that every store stalls the ring's counted waits once; it does not:
+                            // what the stores cost is the ENERGY of their traffic, batching changes nothing.
+                            constexpr int PK = PNDF_SP_PARK;
+                            static_assert((PK & (PK - 1)) == 0 && PK % CT == 0 && PK * 1024 <= 16 * FSTRIDE * 4, "park window");
+                            const int tile = c * CT + ci;
+                            *(f32x4*)(act.stage + (tile & (PK - 1)) * 1024 + act.lane * 16) = bt[ci];
+                            if constexpr (ci == CT - 1) {
+                                if ((tile & (PK - 1)) == PK - 1) {
+#pragma unroll
+                                    for (int k = 0; k < PK; ++k)
+                                        act.sp.template put<1>(act.spslot + tile - (PK - 1) + k, *(const f32x4*)(act.stage + k * 1024 + act.lane * 16));
+                                }
+                            }
+                        } else {
+                            act.sp.template put<1>((PNDF_SP_DIAG & 16) ? act.spslot : act.spslot + c * CT + ci, bt[ci]);
+                        }
+                    }
                 } else {
                     split2<SINGLE>(pz[0], pz[1], hw[u], lw[u]);      // pair u = values (2 u, 2 u + 1) = dword u of the B operands
                 }
@@ -451,7 +483,7 @@ struct SplitPhase {
                         y[ci][r] = sz * act.oscale;
                         smax = fmaxf(smax, sd);
                         bt[ci][r] = sd;                              // the bias value is dead: its slot carries the derivative
-                        if constexpr (r == 3) *act.sp.slot(act.spslot + c * CT + ci) = bt[ci];
+                        if constexpr (r == 3) act.sp.template put<1>(act.spslot + c * CT + ci, bt[ci]);
                     }
                 } else if constexpr (SP && BWD) {
                     if constexpr (r == 0) bt[ci] = *(const f32x4*)(act.stage + ci * 1024 + act.lane * 16);
@@ -757,10 +789,10 @@ __device__ __forceinline__ void act_split_tiles(f32x4 (&x)[NT], Blk (&out)[NT / 
         for (int t = 0; t < NT; ++t) {
             f32x4 dv;
             x[t] = x[t] * act.to_true;
-            act_softplus4(x[t], act.k(), dv);
+            act_softplus4<PNDF_SP_FORM_TILES>(x[t], act.k(), dv);
             dm[0] = vmax3(dm[0], dv[0], dv[1]);
             dm[1] = vmax3(dm[1], dv[2], dv[3]);
-            *act.sp.slot(act.spslot + t) = dv;
+            act.sp.template put<2>(act.spslot + t, dv);
         }
         dmax = pose_max(fmaxf(fmaxf(dm[0], dm[1]), fmaxf(dm[2], dm[3])));
         bound = pose_max(tiles_absmax<NT>(x));
@@ -808,7 +840,7 @@ __device__ __forceinline__ void dact_split_tiles(f32x4 (&gx)[NT], Blk (&out)[NT 
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if constexpr (SP) {
-            gx[t] = (gx[t] * cf) * *sp.slot(act.spslot + t);
+            gx[t] = (gx[t] * cf) * sp.get(act.spslot + t);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -998,7 +1030,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
         const float z7 = part + lds_bias[BIAS_OFF[6]];
         float gz7;
         if constexpr (SP) {
-            dval = act_softplus(z7, ap.k, gz7) + poison;      // output Softplus, net_modules.py:39-41,69; NaN / inf poses: joint_axis_norms
+            dval = act_softplus<PNDF_SP_FORM_OUT>(z7, ap.k, gz7) + poison;      // output Softplus, net_modules.py:39-41,69; NaN / inf poses: joint_axis_norms
             gz7 += poison;
         } else {
             dval = (z7 != z7) ? z7 : fmaxf(z7, 0.f);   // (relu(NaN) = NaN as in PyTorch; v_max alone returns 0)                       // output ReLU for relu AND lrelu, net_modules.py:30-37
