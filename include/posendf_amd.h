@@ -119,6 +119,22 @@ int pndf_debug_project_timing(pndf_handle h, const float* q_in, float* q_out, in
                               unsigned long long* cycles, void* stream);
 int pndf_debug_timing_regions(void);
 
+/* ---- host twins (SURVEY.md 8b `pndf_*_cpu`): the same three operations on HOST pointers, for a caller whose
+ * `train.device` is "cpu" (model/posendf.py:35,64 runs wherever the config says).  A separate handle type with no device
+ * behind it: plain C++ on the host cores, fp32, PyTorch's activation conventions; blocks of 32 poses are dealt to threads
+ * (PNDF_CPU_THREADS, default: all hardware threads).  Same configurations as pndf_create (all three activations, the
+ * encoder-less model, narrower hidden layers; `precision` is ignored), same status codes; no stream argument: the calls
+ * return when the result is in memory.  Never used as a fallback: the device entry points above fail when there is no
+ * gfx950 device. */
+typedef struct pndf_cpu_engine* pndf_cpu_handle;
+int pndf_cpu_create(pndf_cpu_handle* out, const pndf_config* cfg);
+int pndf_cpu_destroy(pndf_cpu_handle h);
+int pndf_cpu_load_weights(pndf_cpu_handle h, const float* const* tensors, const int64_t* numel, int n_tensors);   /* as pndf_load_weights */
+int pndf_forward_cpu(pndf_cpu_handle h, const float* q, float* d, int64_t B);                                       /* posendf.py:62-76 */
+int pndf_forward_grad_cpu(pndf_cpu_handle h, const float* q, const float* grad_out, float* d, float* dq, int64_t B); /* posendf.py:18-27 */
+int pndf_project_cpu(pndf_cpu_handle h, const float* q_in, float* q_out, float* d_last, int64_t B, int steps);      /* sample_poses.py:67-74 */
+const char* pndf_cpu_last_error(pndf_cpu_handle h);   /* h may be NULL: last error of a failed pndf_cpu_create */
+
 /* Host-only weight packer (what pndf_load_weights uploads); needs no device.  Output sizes in floats come
  * from pndf_packed_sizes.  Used by the CPU tests that check the MFMA tile order against a lane-level model. */
 void pndf_packed_sizes(int64_t* stream_floats, int64_t* bias_floats);

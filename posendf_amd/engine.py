@@ -107,6 +107,18 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.pndf_quat_topk.argtypes = [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p,
                                    c_void_p, c_void_p]
     lib.pndf_quat_topk.restype = c_int
+    CH = c_void_p
+    lib.pndf_cpu_create.argtypes = [POINTER(CH), POINTER(PndfConfig)]
+    lib.pndf_cpu_destroy.argtypes = [CH]
+    lib.pndf_cpu_load_weights.argtypes = [CH, POINTER(c_void_p), POINTER(c_int64), c_int]
+    lib.pndf_forward_cpu.argtypes = [CH, c_void_p, c_void_p, c_int64]
+    lib.pndf_forward_grad_cpu.argtypes = [CH, c_void_p, c_void_p, c_void_p, c_void_p, c_int64]
+    lib.pndf_project_cpu.argtypes = [CH, c_void_p, c_void_p, c_void_p, c_int64, c_int]
+    lib.pndf_cpu_last_error.argtypes = [CH]
+    lib.pndf_cpu_last_error.restype = c_char_p
+    for name in ("pndf_cpu_create", "pndf_cpu_destroy", "pndf_cpu_load_weights", "pndf_forward_cpu", "pndf_forward_grad_cpu",
+                 "pndf_project_cpu"):
+        getattr(lib, name).restype = c_int
     lib.pndf_last_error.argtypes = [H]
     lib.pndf_last_error.restype = c_char_p
     lib.pndf_version.restype = c_char_p
@@ -124,7 +136,9 @@ EXPORTS = ("pndf_default_config", "pndf_create", "pndf_destroy", "pndf_load_weig
            "pndf_packed_sizes", "pndf_pack_host", "pndf_pack_host_split", "pndf_aa2quat", "pndf_denoise_update", "pndf_denoise_update_body", "pndf_denoise_update_w", "pndf_lbs_terms_grad_w", "pndf_quat_topk",
            "pndf_lbs_create", "pndf_lbs_destroy", "pndf_lbs_set_precision", "pndf_lbs_precision", "pndf_lbs_num_joints", "pndf_lbs_num_vertices", "pndf_lbs_workspace_floats",
            "pndf_lbs_forward", "pndf_lbs_terms_grad", "pndf_lbs_backward", "pndf_lbs_packed_floats", "pndf_lbs_pack_host", "pndf_lbs_packed_split_bytes", "pndf_lbs_pack_split_host",
-           "pndf_lbs_last_error", "pndf_last_error", "pndf_version", "pndf_kernel_name")
+           "pndf_lbs_last_error", "pndf_last_error", "pndf_version", "pndf_kernel_name",
+           "pndf_cpu_create", "pndf_cpu_destroy", "pndf_cpu_load_weights", "pndf_forward_cpu", "pndf_forward_grad_cpu", "pndf_project_cpu",
+           "pndf_cpu_last_error")
 
 
 def state_dict_order(encoder: bool = True):
@@ -222,6 +236,67 @@ class Engine:
     def close(self):
         if getattr(self, "handle", None):
             self.lib.pndf_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CpuEngine:
+    """The host twins `pndf_*_cpu` behind the interface of `Engine` (raw HOST pointers; `stream` is accepted and ignored):
+    what `PoseNDF` runs on when its config says `train.device: cpu`, as the reference's class does (model/posendf.py:35,64).
+    Plain C++ on the host cores -- not the oracle, and never a fallback of the device engine."""
+
+    def __init__(self, act: str = "lrelu", beta: float = 100.0, lib=None, encoder: bool = True, hidden=None):
+        self.lib = lib or load_library()
+        if act not in ACT_CODES:
+            raise PndfError(f"unknown activation {act!r}")
+        cfg = PndfConfig()
+        self.lib.pndf_default_config(ctypes.byref(cfg), ACT_CODES[act], float(beta))
+        if not encoder:
+            cfg.dims[0] = 84
+        if hidden is not None:
+            hidden = [int(w) for w in hidden]
+            if len(hidden) != 6:
+                raise PndfError(f"DFNet with {len(hidden)} hidden layers: 6 as in configs/amass.yaml")
+            for i, w in enumerate(hidden):
+                cfg.dims[i + 1] = w
+        self.precision = "fp32"
+        self.handle = c_void_p()
+        rc = self.lib.pndf_cpu_create(ctypes.byref(self.handle), ctypes.byref(cfg))
+        if rc != 0:
+            msg = self.lib.pndf_cpu_last_error(None).decode()
+            self.handle = None
+            raise PndfError(f"pndf_cpu_create failed ({rc}): {msg}")
+        self.device = "cpu"
+        self.act = act
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PndfError(f"{what} failed ({rc}): {self.lib.pndf_cpu_last_error(self.handle).decode()}")
+
+    def load_weights(self, sd_np):
+        arrs, ptrs, numel = _tensor_table(sd_np)
+        self._check(self.lib.pndf_cpu_load_weights(self.handle, ptrs, numel, len(arrs)), "pndf_cpu_load_weights")
+
+    def kernel_name(self) -> str:
+        return "pndf_cpu (host twin)"
+
+    def forward(self, q_ptr, d_ptr, B, stream=0):
+        self._check(self.lib.pndf_forward_cpu(self.handle, q_ptr, d_ptr, B), "pndf_forward_cpu")
+
+    def forward_grad(self, q_ptr, gout_ptr, d_ptr, dq_ptr, B, stream=0):
+        self._check(self.lib.pndf_forward_grad_cpu(self.handle, q_ptr, gout_ptr, d_ptr, dq_ptr, B), "pndf_forward_grad_cpu")
+
+    def project(self, q_in_ptr, q_out_ptr, d_ptr, B, steps, stream=0):
+        self._check(self.lib.pndf_project_cpu(self.handle, q_in_ptr, q_out_ptr, d_ptr, B, int(steps)), "pndf_project_cpu")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.pndf_cpu_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

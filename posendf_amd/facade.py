@@ -6,8 +6,10 @@ values, same parameter tree / state-dict keys.  With train=False the distance an
 come from the fused HIP kernel through the C ABI (include/posendf_amd.h); `project()` runs the whole
 projection loop of experiments/sample_poses.py:67-74 in one persistent launch.
 
-There is no CPU or eager-PyTorch fallback on the inference path: without the built library or without a
-gfx950 device, train=False raises.
+There is no fallback on the inference path: a pose on a `cuda` device runs on the HIP engine or raises (no built
+library, no gfx950 device).  A model whose config says `train.device: cpu` -- the reference's class works there too,
+posendf.py:35,64 -- runs train=False on the library's host twins (`pndf_*_cpu`, plain C++ on the host cores),
+selected by the pose's device alone, never by a failure of the device path.
 """
 from __future__ import annotations
 
@@ -18,7 +20,7 @@ import torch
 import torch.nn as nn
 from torch.autograd.function import once_differentiable
 
-from .engine import Engine, PndfError, state_dict_order
+from .engine import CpuEngine, Engine, PndfError, state_dict_order
 from .modules import DFNet, StructureEncoder
 
 
@@ -27,6 +29,11 @@ def gradient(inputs, outputs):
     ones = torch.ones_like(outputs, requires_grad=False, device=outputs.device)
     return torch.autograd.grad(outputs=outputs, inputs=inputs, grad_outputs=ones, create_graph=True,
                                retain_graph=True, only_inputs=True)[0]
+
+
+def _stream_of(device):
+    """the caller's current HIP stream as an integer handle (0 for a host tensor: the host twins take none)"""
+    return torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
 
 
 class _Distance(torch.autograd.Function):
@@ -41,7 +48,7 @@ class _Distance(torch.autograd.Function):
         B = q.shape[0]
         d = torch.empty(B, device=q.device, dtype=torch.float32)
         eng = owner._engine_for(q.device)
-        stream = torch.cuda.current_stream(q.device).cuda_stream
+        stream = _stream_of(q.device)
         if ctx.needs_input_grad[0]:     # one launch yields d and d d/d pose
             dq = torch.empty_like(q)
             eng.forward_grad(q.data_ptr(), None, d.data_ptr(), dq.data_ptr(), B, stream)
@@ -122,11 +129,14 @@ class PoseNDF(nn.Module):
         return super().load_state_dict(*args, **kwargs)
 
     def _engine_for(self, device):
-        if device.type != "cuda":
-            raise PndfError("PoseNDF inference runs on the HIP engine only; no CPU path exists")
-        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if device.type not in ("cuda", "cpu"):
+            raise PndfError(f"PoseNDF inference runs on the HIP engine (cuda) or the host twins (cpu), not on {device}")
+        host = device.type == "cpu"
+        idx = "cpu" if host else (device.index if device.index is not None else torch.cuda.current_device())
         fp = self._fingerprint()
         entry = self._engines.get(idx)
+        if entry is None and host:
+            entry = self._engines[idx] = [CpuEngine(self._act, self._beta, encoder=self.enc is not None, hidden=self._hidden), None]
         if entry is None:
             # the plain-f16 comparison kernel is relu-family only; fp32 and f16x3 implement all three activations
             prec = "fp32" if (self._act == "softplus" and self._precision == "f16") else self._precision
@@ -181,6 +191,5 @@ class PoseNDF(nn.Module):
         out = torch.empty_like(q)
         d = torch.empty(q.shape[0], device=q.device, dtype=torch.float32)
         eng = self._engine_for(q.device)
-        eng.project(q.data_ptr(), out.data_ptr(), d.data_ptr(), q.shape[0], int(steps),
-                    torch.cuda.current_stream(q.device).cuda_stream)
+        eng.project(q.data_ptr(), out.data_ptr(), d.data_ptr(), q.shape[0], int(steps), _stream_of(q.device))
         return (out, d.view(-1, 1)) if return_dist else out

@@ -123,7 +123,8 @@ def test_split_packer_scales_each_layer_and_refuses_the_unscalable(lib):
 
 def test_facade_surface_cpu():
     """Reference-compatible surface without touching the engine: state-dict keys, train=True objective
-    (pinned against the reference in tests/golden), loud failure of train=False on CPU."""
+    (pinned against the reference in tests/golden); train=False of a `train.device: cpu` model runs on the library's host
+    twins (tests/test_cpu_twin.py holds them to the golden vectors), any other device type is refused."""
     import torch
     from conftest import golden_weights, load_golden
     from posendf_amd import PoseNDF, amass_config, synth
@@ -141,8 +142,11 @@ def test_facade_surface_cpu():
     assert abs(ld["eikonal"].item() - g["train_eikonal"]) < 1e-5
     loss.backward()                                                 # weight gradients flow (train_posendf.py:98)
     assert net.dfnet.lin0.weight.grad is not None
+    d = net(torch.from_numpy(g["q"]), train=False)["dist_pred"]
+    assert d.shape == (len(g["q"]), 1) and d.device.type == "cpu"
+    assert net._engine_for(torch.device("cpu")).kernel_name() == "pndf_cpu (host twin)"
     with pytest.raises(PndfError):
-        net(torch.from_numpy(g["q"]), train=False)
+        net._engine_for(torch.device("meta"))
 
 
 def test_reference_checkpoint_interchange(tmp_path):
