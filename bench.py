@@ -715,6 +715,19 @@ def main():
             out["gpu_torch_baseline"] = gt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.act, sd, args.proj_steps, args.cpu_budget)
+            # the library's own host twins (pndf_*_cpu, plain C++; what a `train.device: cpu` config runs) on the same sample:
+            # product code beside the reference's CPU path, informational -- never `value`, never the baseline
+            cfg_h = amass_config(args.act, "cpu")
+            host = PoseNDF(cfg_h)
+            host.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            qh = torch.from_numpy(synth.make_poses(4096, seed=1234))
+            host.project(qh, steps=2)
+            t0 = time.perf_counter()
+            host.project(qh, steps=10)
+            dt = (time.perf_counter() - t0) * args.proj_steps / 10
+            out["host_twin"] = {"what": "pndf_project_cpu (posendf_amd/csrc/pndf_cpu.cpp, fp32, std::threads), B=4096 x 10 steps "
+                                        f"scaled to {args.proj_steps}", "value": 4096 / dt, "unit": "projected poses/s",
+                                "threads": os.environ.get("PNDF_CPU_THREADS", "all hardware threads")}
         json_line = json.dumps(out)
     if use_dist:
         dist.barrier()
