@@ -13,6 +13,7 @@ selected by the pose's device alone, never by a failure of the device path.
 """
 from __future__ import annotations
 
+import logging
 import os
 import warnings
 
@@ -143,6 +144,11 @@ class PoseNDF(nn.Module):
             entry = [Engine(self._act, self._beta, idx, precision="f16x3" if prec == "auto" else prec,
                             encoder=self.enc is not None, hidden=self._hidden), None]
             self._engines[idx] = entry
+            if prec == "auto":      # a drop-in of an fp32 model picks an arithmetic on the caller's behalf: say so, once per engine
+                logging.getLogger("posendf_amd").info(
+                    "PoseNDF on cuda:%s: precision 'auto' runs the split-precision kernels (f16x3: fp32 operands as fp16 hi + lo, "
+                    "three fp16 MFMAs per product block, fp32 accumulate; same parity gates as the exact kernel); "
+                    "opt['engine'] = {'precision': 'fp32'} or PNDF_PRECISION=fp32 selects the exact fp32 MFMA kernel", idx)
         if entry[1] != fp:          # first use, load_state_dict, optimiser step, .to(): re-pack the weights
             sd = self.state_dict()
             weights = {k: sd[k].detach().float().cpu().numpy() for k in state_dict_order(self.enc is not None)}

@@ -4,7 +4,7 @@
 Builds the library with `-fsanitize=address -fno-gpu-sanitize` (host code instrumented, device code untouched) into
 gpurun_ab/lib_asan.so and drives every entry point that needs no device -- the weight packers (`pndf_pack_host`,
 `pndf_pack_host_split`: full architecture, encoder-less, narrower hidden layers), the body-model packers
-(`pndf_lbs_pack_host`, `pndf_lbs_pack_split_host`: SMPL size and a ragged small model) and their refusal paths -- with
+(`pndf_lbs_pack_host`, `pndf_lbs_pack_split_host`: SMPL size and a ragged small model), their refusal paths, and the host twins `pndf_*_cpu` -- with
 EXACTLY sized numpy buffers, in a child process that preloads the ASan runtime.  Any out-of-bounds host access of the
 packers ends the child with an AddressSanitizer report.  Needs no GPU.
 
@@ -75,7 +75,36 @@ for V, extra, nb in ((6890, synth.SMPL_EXTRA_JOINT_VERTICES, 10), (137, (5, 60, 
         assert lib.pndf_lbs_pack_host(V, nb, vt.ctypes.data, sd_.ctypes.data if nb else None, betas.ctypes.data if nb else None,
                                       pd.ctypes.data, jr.ctypes.data, par.ctypes.data, w.ctypes.data, dup.ctypes.data, len(extra),
                                       blob.ctypes.data, None, None) != 0
-print("asan host check: clean (%%d packer calls)" %% calls)
+# the host twins (pndf_*_cpu): every configuration, ragged batches, exactly sized pose / distance / gradient buffers
+class Cfg(ctypes.Structure):
+    _fields_ = [("act", c_int32), ("beta", ctypes.c_float), ("num_joints", c_int32), ("n_dims", c_int32), ("dims", c_int32 * 16),
+                ("parent", c_int32 * 32), ("precision", c_int32)]
+lib.pndf_default_config.argtypes = [POINTER(Cfg), c_int32, ctypes.c_float]; lib.pndf_default_config.restype = None
+lib.pndf_cpu_create.argtypes = [POINTER(c_void_p), POINTER(Cfg)]
+lib.pndf_cpu_load_weights.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_int64), c_int]
+lib.pndf_forward_cpu.argtypes = [c_void_p, c_void_p, c_void_p, c_int64]
+lib.pndf_forward_grad_cpu.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64]
+lib.pndf_project_cpu.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int]
+lib.pndf_cpu_destroy.argtypes = [c_void_p]
+twin = 0
+for act, dims in ((1, synth.DFNET_DIMS), (2, synth.DFNET_DIMS_NOENC), (0, (126, 192, 384, 700, 300, 200, 48, 1))):
+    cfg = Cfg(); lib.pndf_default_config(ctypes.byref(cfg), act, 100.0)
+    for i, w in enumerate(dims): cfg.dims[i] = w
+    h = c_void_p(); assert lib.pndf_cpu_create(ctypes.byref(h), ctypes.byref(cfg)) == 0
+    sd = synth.make_weights(1, 2.0, 0.1, dims=dims)
+    arrs = [np.ascontiguousarray(sd[k]) for k in synth.state_dict_shapes(dims)]
+    ptrs = (c_void_p * len(arrs))(*[a.ctypes.data for a in arrs]); numel = (c_int64 * len(arrs))(*[a.size for a in arrs])
+    assert lib.pndf_cpu_load_weights(h, ptrs, numel, len(arrs)) == 0
+    for B in (1, 31, 32, 33, 70):
+        q = np.ascontiguousarray(synth.make_poses(B, seed=B)); d = np.empty(B, np.float32); dq = np.empty((B, 84), np.float32)
+        go = np.linspace(-1, 2, B).astype(np.float32); qo = np.empty_like(q)
+        assert lib.pndf_forward_cpu(h, q.ctypes.data, d.ctypes.data, B) == 0
+        assert lib.pndf_forward_grad_cpu(h, q.ctypes.data, go.ctypes.data, d.ctypes.data, dq.ctypes.data, B) == 0
+        assert lib.pndf_project_cpu(h, q.ctypes.data, qo.ctypes.data, d.ctypes.data, B, 2) == 0
+        assert np.isfinite(qo).all() and np.isfinite(dq).all()
+        twin += 3
+    lib.pndf_cpu_destroy(h)
+print("asan host check: clean (%%d packer calls, %%d host-twin calls)" %% (calls, twin))
 """
 
 
