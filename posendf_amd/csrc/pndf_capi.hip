@@ -401,7 +401,11 @@ static int pack_host_split(const float* const* tensors, const int64_t* numel, in
     float* dst = stream + (size_t)ENC_TILES_PADDED * TILE_FLOATS;
     bool any_lo = false;
     for (int ph = 0; ph < 6; ++ph) {
-        const Phase& P = PHASES[ph];
+        Phase P = PHASES[ph];
+        if (PNDF_BIG_CT != 2 && P.NC == 32) {      // (experiment: the two big phases in chunks of PNDF_BIG_CT tiles, pndf_layout.h)
+            P.NC = P.NC * P.CT / PNDF_BIG_CT;
+            P.CT = PNDF_BIG_CT;
+        }
         const Mat A{lin[2 * P.a_lin], nd.out(P.a_lin), nd.in(P.a_lin), P.transposed};
         const Mat B{lin[2 * P.b_lin], nd.out(P.b_lin), nd.in(P.b_lin), P.transposed};
         auto partA = [&](int c) {

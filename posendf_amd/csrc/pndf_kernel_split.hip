@@ -994,7 +994,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
 #pragma unroll
                 for (int t = 0; t < 32; ++t) x4[t] = x4[t] * bs;
             }
-            const float dm = PhaseSel<TERMS, SP, 16, 2, 32, 32, false, TIMING && TERMS == 3 && PNDF_GROUP_STAMPS>::type::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], 2, sg_in, sg_ch), g, &rc);
+            const float dm = PhaseSel<TERMS, SP, 16, PNDF_BIG_CT, 64 / PNDF_BIG_CT, 32, false, TIMING && TERMS == 3 && PNDF_GROUP_STAMPS>::type::run(b2, x4, ring, lds_bias + BIAS_OFF[2], lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], 2, sg_in, sg_ch), g, &rc);
             if constexpr (SP) dmax3 = pose_max(dm);
             tick<TIMING>(rc, 3);
             act_split_tiles<32, SG, SP>(x4, b4, m4, layer(SP_SLOT_X4, 3, sg_ch, 0.f), 0.f, bnd, sg_in, dmax4);
@@ -1078,7 +1078,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
                     f32x4 g2[32];
 #pragma unroll
                     for (int t = 0; t < 32; ++t) g2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    PhaseSel<TERMS, SP, 16, 2, 32, 32, true>::type::run(gb4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], 3, bwd_sigma, sg_ch), g);
+                    PhaseSel<TERMS, SP, 16, PNDF_BIG_CT, 64 / PNDF_BIG_CT, 32, true>::type::run(gb4, g2, ring, nullptr, lds_mask + MASK_BASE[1] * WG_THREADS, layer(SP_SLOT_CHUNK[1], 3, bwd_sigma, sg_ch), g);
                     dact_split_tiles<32, SG, SP>(g2, gb2, m2, layer(SP_SLOT_X2, 2, sg_ch, 0.f), dmax2, bwd_bound, bwd_sigma);
                     tick<TIMING>(rc, 8);
                 }

@@ -90,6 +90,11 @@ constexpr int phase_b_pairs(const Phase& p) { return p.NB * (p.CT / 2); }
 static_assert(2 * (phase_a_pairs(PHASES[1]) + phase_b_pairs(PHASES[1])) == phase_chunk_tiles(PHASES[1]), "same tile count");
 static_assert(2 * (phase_a_pairs(PHASES[2]) + phase_b_pairs(PHASES[2])) == phase_chunk_tiles(PHASES[2]), "same tile count");
 
+// Experiment switch (split-precision stream and kernels only): chunk size of the two big phases (lin2,lin3) / (lin3^T,lin2^T).
+// 2 = product; 4 = part B's accumulators get chains of six MFMAs per chunk instead of three (DESIGN.md Appendix C 7.1 b).
+#ifndef PNDF_BIG_CT
+#define PNDF_BIG_CT 2
+#endif
 enum Precision { PREC_FP32 = 0, PREC_F16X3 = 1, PREC_F16 = 2 };
 
 // bias block (floats) copied to LDS: b0..b5, then w6 (64), then b6

@@ -20,7 +20,9 @@ SWEEP_WEIGHTS = ((0, 2.0, 0.1), (0, 2.5, 0.05), (1, 1.0, 0.2), (2, 3.0, 0.05), (
 # HELD-OUT weight sets that never took part in calibrating a gate: PNDF_SWEEP_HELDOUT=1 (round 2's six) or =2 (six more, first
 # run in round 3 after the outlier gate was tightened) swaps them into tests/test_gpu_sweep.py; results under profiles/.
 _HELDOUT = {"1": ((5, 0.7, 0.3), (6, 1.5, 0.1), (7, 2.0, 0.0), (8, 3.5, 0.02), (9, 4.0, 0.1), (10, 2.2, -0.05)),
-            "2": ((11, 0.6, 0.25), (12, 1.2, 0.15), (13, 1.8, 0.0), (14, 2.8, 0.03), (15, 3.2, 0.08), (16, 2.4, -0.03))}
+            "2": ((11, 0.6, 0.25), (12, 1.2, 0.15), (13, 1.8, 0.0), (14, 2.8, 0.03), (15, 3.2, 0.08), (16, 2.4, -0.03)),
+            # =3: six more, first run in round 4 after the softplus activation was rewritten (packed fp32, clamp instead of selects)
+            "3": ((21, 0.8, 0.2), (22, 1.4, 0.1), (23, 2.1, 0.0), (24, 3.0, 0.04), (25, 3.6, 0.06), (26, 1.7, -0.02))}
 SWEEP_WEIGHTS = _HELDOUT.get(os.environ.get("PNDF_SWEEP_HELDOUT", ""), SWEEP_WEIGHTS)
 
 
@@ -142,7 +144,43 @@ def _fp32_noise(q, sd, act, draws=8, extra_d=(), extra_g=(), seed=1):
     return np.max(sig_d, axis=0), np.max(sig_g, axis=0), d64, g64
 
 
-def pose_gate(err, sigma, what="", factor=8.0, floor=8e-6, exempt=None, tol=1e-4):
+def escalated_noise(q, sd, act, idx, truth, draws=32, seed=11, steps=0, kind="g"):
+    """Second, better estimate of the fp32 variability of the REFERENCE arithmetic, for the few poses `idx` that exceeded the
+    cheap envelope (round 4; found by a fresh held-out sweep, profiles/r04/sweep_heldout.txt).  The cheap envelopes perturb
+    the INPUT by one fp32 rounding (8 single-step draws, 3 trajectory draws): that under-samples (i) heavy-tailed trajectories
+    -- one softplus pose of a gain-3.6 network: 1.5e-5 over 3 draws, 1.24e-4 over 100 -- and (ii) the freedom of the
+    evaluation ORDER: a correct fp32 evaluation may round every product differently (BLAS blocking, MFMA accumulation
+    order), which one-rounding perturbations of the WEIGHTS model -- one lrelu pose whose pre-activation sits 7e-5 from a
+    kink: 2.5e-6 under 48 input perturbations, 3.3e-5 under 32 weight perturbations, the exact-fp32 kernel 3.2e-5.
+    Here: `draws` fp32 oracle evaluations of the poses `idx` with inputs AND weights perturbed by one rounding each;
+    returns the per-pose maximum error against `truth` (the fp64 result of the full batch: the metric keeps the full
+    batch's floors).  steps = 0: single step (kind "d" or "g"); steps > 0: the projected poses after `steps` steps."""
+    from oracle import posendf_np as onp
+    idx = np.asarray(idx)
+    q = np.asarray(q, np.float32)
+    truth = np.asarray(truth, np.float64)
+    t_rows = truth.reshape(truth.shape[0], -1)
+    if kind == "d":
+        floor = 0.05 * max(np.abs(t_rows).max(), 1e-30)
+    else:
+        floor = max(1e-3 * float(np.median(np.abs(t_rows).max(axis=1))), 1e-30)
+    den = np.maximum(np.abs(t_rows[idx]).max(axis=1), floor)
+    rng = np.random.default_rng(seed)
+    worst = np.zeros(len(idx))
+    for _ in range(draws):
+        qk = (q[idx] * (1 + rng.uniform(-2.0 ** -23, 2.0 ** -23, q[idx].shape))).astype(np.float32)
+        sdk = {k: (v * (1 + rng.uniform(-2.0 ** -23, 2.0 ** -23, v.shape))).astype(np.float32) for k, v in sd.items()}
+        if steps > 0:
+            out, _ = onp.project(qk, sdk, steps=steps, act=act)
+        else:
+            d32, g32 = onp.forward_grad(qk, sdk, act, dtype=np.float32)
+            out = d32 if kind == "d" else g32
+        num = np.abs(np.asarray(out, np.float64).reshape(len(idx), -1) - t_rows[idx]).max(axis=1)
+        worst = np.maximum(worst, num / den)
+    return worst
+
+
+def pose_gate(err, sigma, what="", factor=8.0, floor=8e-6, exempt=None, tol=1e-4, escalate=None):
     """Every pose individually: error <= factor x the pose's fp32 sensitivity (fp32_noise) + floor.  Calibrated on
     tools/gpu_sweep.py (6 weight sets x 3 activations x 2 pose distributions x 1,024 poses, both kernels): the largest
     error / (sigma + 1e-6) observed is 6.3, the 99th percentile 2.7.  `exempt`: poses that are allowed to exceed it
@@ -152,6 +190,15 @@ def pose_gate(err, sigma, what="", factor=8.0, floor=8e-6, exempt=None, tol=1e-4
     bad = err > factor * sigma + floor
     if exempt is not None:
         bad &= ~np.asarray(exempt)
+    if bad.any() and escalate is not None and bad.sum() <= max(4, len(err) // 100):
+        # few poses over the cheap envelope: measure the reference arithmetic's variability there properly (escalated_noise)
+        # and hold them to TWICE the worst of those evaluations -- a tighter factor for a better estimate
+        idx = np.flatnonzero(bad)
+        s2 = np.asarray(escalate(idx), dtype=np.float64)
+        still = err[idx] > 2.0 * s2 + floor
+        print(f"[pose_gate {what}] escalated {idx.tolist()}: error {err[idx].tolist()} cheap sigma {sigma[idx].tolist()} "
+              f"-> worst of the escalated reference evaluations {s2.tolist()}: {'FAIL' if still.any() else 'explained'}")
+        bad[idx] = still
     assert not bad.any(), (what, int(bad.sum()), np.flatnonzero(bad)[:8].tolist(), err[bad][:8].tolist(),
                            sigma[bad][:8].tolist())
     assert np.median(err) <= max(tol / 10, factor * float(np.median(sigma))), (what, float(np.median(err)))
@@ -163,7 +210,7 @@ def pose_gate(err, sigma, what="", factor=8.0, floor=8e-6, exempt=None, tol=1e-4
     return worst
 
 
-def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0, margin=None, kink_tol=1e-5, cap=10.0, sigma=None):
+def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0, margin=None, kink_tol=1e-5, cap=10.0, sigma=None, escalate=None):
     """Gate for quantities that are DISCONTINUOUS in the input (d d/d q and everything derived from it):
     a pre-activation within rounding of a ReLU/LeakyReLU kink flips its derivative (1 vs slope), so any two
     fp32 evaluations -- including the reference's own fp32 run against its fp64 run -- disagree by O(1) on a
@@ -202,6 +249,15 @@ def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0, margin=None,
     by_kink = np.zeros(n, bool) if margin is None else (np.asarray(margin) < kink_tol)
     by_sigma = np.zeros(n, bool) if sigma is None else (mine_rows <= 8.0 * np.asarray(sigma, dtype=np.float64) + 8e-6)
     unexplained = out & ~by_ref & ~by_kink & ~by_sigma
+    if unexplained.any() and escalate is not None and unexplained.sum() <= max(4, n // 100):
+        idx = np.flatnonzero(unexplained)       # (see pose_gate: escalated_noise, factor 2 on the better estimate)
+        s2 = np.asarray(escalate(idx), dtype=np.float64)
+        still = mine_rows[idx] > 2.0 * s2 + 8e-6
+        print(f"[gate {what}] escalated {idx.tolist()}: error {mine_rows[idx].tolist()} -> worst of the escalated reference "
+              f"evaluations {s2.tolist()}: {'FAIL' if still.any() else 'explained'}")
+        unexplained[idx] = still
+        by_sigma = by_sigma.copy()
+        by_sigma[idx[~still]] = True
     assert not unexplained.any(), (what, "outliers that neither the reference's fp32 error nor a kink explains",
                                    np.flatnonzero(unexplained)[:8].tolist(), mine_rows[unexplained][:8].tolist(),
                                    ref_rows[unexplained][:8].tolist())

@@ -42,8 +42,9 @@ def test_sweep(weights, act, signed, precision):
     d = net(q, train=False)["dist_pred"]
     (dq,) = torch.autograd.grad(d, q, grad_outputs=torch.ones_like(d))
     e_d, e_g = d_rows(d.detach().cpu().numpy(), d64), rel_err_rows(dq.cpu().numpy(), g64)
-    pose_gate(e_d, sig_d, "d")
-    pose_gate(e_g, sig_g, "dq", exempt=ex)
+    from conftest import escalated_noise
+    pose_gate(e_d, sig_d, "d", escalate=lambda i: escalated_noise(qn, sd, act, i, d64, kind="d"))
+    pose_gate(e_g, sig_g, "dq", exempt=ex, escalate=lambda i: escalated_noise(qn, sd, act, i, g64, kind="g"))
     # the kink exemption is not a quota: exempt poses that do exceed the bound must be genuine derivative flips, i.e. rare
     if ex is not None:
         flipped = ex & (e_g > 8 * sig_g + 8e-6)
@@ -56,4 +57,5 @@ def test_sweep(weights, act, signed, precision):
     qp, _ = net.project(q.detach()[idx].contiguous(), steps=5)
     from conftest import outlier_gate
     from conftest import traj_envelope
-    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), 1e-4, "project5", **traj_envelope(qn[idx], sd, act, 5, q64))
+    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), 1e-4, "project5", **traj_envelope(qn[idx], sd, act, 5, q64),
+                 escalate=lambda i: escalated_noise(qn[idx], sd, act, i, q64, steps=5))
