@@ -12,17 +12,14 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-#ifndef PNDF_SP_PARK
-#define PNDF_SP_PARK 1      // forward chunk layers: 1 = every derivative tile is stored as it is produced (default); N = tiles parked in
-                            // LDS and stored N at a time (an experiment that did not pay: 101.6 against 100.3 ms, profiles/r04/sp_forward_diag.txt)
-#endif
 #ifndef PNDF_SP_DIAG_DOC   // (the macro itself is defined in pndf_device.h, included above: bit 32 lives in the ring)
 #define PNDF_SP_DIAG_DOC 0  // timing diagnostics of the softplus kernels (WRONG results): 1 = no wait for the staged tiles of the backward
 #endif                      // pass, 2 = no staging DMA either (profiles/r03/sp_stage_diag.txt); round 4, forward chunk epilogue: 4 = the
                             // derivative tiles are not stored, 8 = the three transcendentals of a value are plain multiplies
                             // 16 = they all go to ONE slot per layer (an L2-resident line), 32 = the ring's counted wait tolerates two more
                             // operations in flight (pndf_device.h; UNSAFE), 64 = only every other tile is stored, 128 = two 8-byte stores per lane
-                            // instead of one 16-byte store (profiles/r04/sp_forward_diag.txt)
+                            // instead of one 16-byte store (profiles/r04/sp_forward_diag.txt; the LDS-parking experiment of that file -- tiles
+                            // stored eight at a time, +1.3 % -- was removed again: git history, commit "softplus: asm v_max padded ...")
 
 namespace {
 
@@ -429,22 +426,6 @@ struct SplitPhase {
                             f32x2* p2 = (f32x2*)act.sp.slot(act.spslot + c * CT + ci);
                             p2[0] = f32x2{bt[ci][0], bt[ci][1]};
                             p2[1] = f32x2{bt[ci][2], bt[ci][3]};
-                        } else if constexpr (PNDF_SP_PARK > 1) {
-                            // (experiment, off by default) the derivative tile is PARKED in LDS -- this wave's feature rows, free between
-                            // the packing of x0 and the end of the backward trunk -- and PNDF_SP_PARK tiles leave for the scratch
-                            // together.  Built on the guess that every store stalls the ring's counted waits once; it does not:
-                            // what the stores cost is the ENERGY of their traffic, batching changes nothing.
-                            constexpr int PK = PNDF_SP_PARK;
-                            static_assert((PK & (PK - 1)) == 0 && PK % CT == 0 && PK * 1024 <= 16 * FSTRIDE * 4, "park window");
-                            const int tile = c * CT + ci;
-                            *(f32x4*)(act.stage + (tile & (PK - 1)) * 1024 + act.lane * 16) = bt[ci];
-                            if constexpr (ci == CT - 1) {
-                                if ((tile & (PK - 1)) == PK - 1) {
-#pragma unroll
-                                    for (int k = 0; k < PK; ++k)
-                                        act.sp.template put<1>(act.spslot + tile - (PK - 1) + k, *(const f32x4*)(act.stage + k * 1024 + act.lane * 16));
-                                }
-                            }
                         } else {
                             act.sp.template put<1>((PNDF_SP_DIAG & 16) ? act.spslot : act.spslot + c * CT + ci, bt[ci]);
                         }
