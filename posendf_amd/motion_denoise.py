@@ -141,6 +141,9 @@ class MotionDenoise:
         S, T = pose.shape[:2]
         N = S * T
         dev = pose.device
+        if dev.type != "cuda":
+            raise ValueError("fused=True is the HIP driver (engine launch + pndf_denoise_update per Adam step): poses on "
+                             f"{dev}; the autograd driver (fused=False) runs anywhere the PoseNDF model does")
         if bm is not None and torch.device(dev.type, dev.index or 0) != bm.device:
             raise ValueError(f"poses on {dev} but the body model lives on {bm.device}: the fused step hands raw pointers to both")
         eng = self.pose_prior._engine_for(dev)

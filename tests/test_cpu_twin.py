@@ -147,3 +147,19 @@ def test_reference_projection_loop_runs_unchanged_on_cpu():
         noisy_poses = noisy_poses.reshape(-1, 21, 4)
     env = traj_envelope(g["q"], sd, "lrelu", 10, g["q10_f64"])
     outlier_gate(rel_err_rows(noisy_poses.detach().numpy(), g["q10_f64"]), rel_err_rows(g["q10_f32"], g["q10_f64"]), TOL, "loop host", **env)
+
+
+def test_motion_denoise_loop_on_a_cpu_config():
+    """experiments/motion_denoise.py's loop (autograd driver) around a `train.device: cpu` model: the pose prior runs on the host
+    twins; same poses as the loop around the PyTorch restatement of the reference; the fused HIP driver refuses host poses."""
+    from test_motion_denoise import _OraclePrior, _noisy_sequences
+    from posendf_amd.motion_denoise import MotionDenoise
+    sd = golden_weights("live")
+    noisy = _noisy_sequences(2, 8, seed=5)
+    got, h = MotionDenoise(make_net("lrelu", sd), device="cpu").denoise(noisy, iterations=2, steps_per_iter=4)
+    ref, h_ref = MotionDenoise(_OraclePrior("lrelu", sd), device="cpu").denoise(noisy, iterations=2, steps_per_iter=4)
+    assert abs(h[0]["pose_pr"] - h_ref[0]["pose_pr"]) < 1e-5 * abs(h_ref[0]["pose_pr"])
+    err = (got - ref).abs()
+    assert err.median().item() < 1e-5 and err.max().item() < 5e-3, (err.median().item(), err.max().item())
+    with pytest.raises(ValueError):
+        MotionDenoise(make_net("lrelu", sd), device="cpu").denoise(noisy, fused=True)
