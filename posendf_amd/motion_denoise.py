@@ -12,7 +12,7 @@ and its first-order autograd contract.  The reference's temporal / data terms ne
 pluggable: pass `body_model(pose_body[T,69]) -> (vertices[T,V,3], joints[T,J,3])`, or leave it None to use
 pose-space surrogates (per-joint axis-angle differences), which keep the objective's structure.
 
-`optimize(fused=True)` runs the same loop without PyTorch in it: per Adam step one engine launch (distances and
+`denoise(fused=True)` runs the same loop without PyTorch in it: per Adam step one engine launch (distances and
 d d / d q for all S x T frames) and one HIP kernel (`pndf_denoise_update`, posendf_amd/csrc/pndf_denoise.hip) that
 does the per-sequence mean, the weights, the axis-angle Jacobian, the pose-space terms, Adam and the next step's
 quaternions -- 3 launches per step instead of ~60.  With `body_model is None` it optimises the surrogate terms; with a
