@@ -219,6 +219,77 @@ __device__ __forceinline__ void lbs_pose_body(const PndfLbsArgs& a) {
 extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_kernel(PndfLbsArgs a) { lbs_pose_body<ModelTree>(a); }
 extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_smpl_kernel(PndfLbsArgs a) { lbs_pose_body<SmplTree>(a); }
 
+// ------------------------------------------------------------------ joints only (no vertices asked for)
+// smplx's joints are the 24 posed chain joints + the vertices its VertexJointSelector picks (21 for SMPL).  When the caller
+// wants only them (`joints_of()`: the Jtr of the noisy poses, motion_denoise.py:60,63), skinning all 6,890 vertices -- 431
+// groups through the vertex kernel, 6.6 ms for 153,600 frames -- to read 21 of them is waste: one thread per frame does the
+// kinematic chain and then skins the picked vertices alone, from a small table made at create time (per picked vertex:
+// shaped template [3] | skinning weights [24] | pose blend shapes [207][3]; uniform addresses: scalar loads).  fp32 on the VALU.
+constexpr int PICK_FLOATS = 3 + NJ + 3 * 9 * (NJ - 1);
+template <class Tree>
+__device__ __forceinline__ void lbs_joints_only_body(const PndfLbsArgs& a, const float* __restrict__ picked) {
+    // v_posed of the picked vertices between the two passes: [x * 3 + c][thread] (one column per thread: conflict-free)
+    __shared__ float vps[PNDF_LBS_MAX_EXTRA * 3][64];
+    const long long n = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (n >= (long long)a.S * a.T) return;
+    const float* th = a.theta + n * 69;
+    // ONE set of 24 matrices: first the joints' own rotations (what the pose blend shapes need), then -- in place, parents
+    // before children -- the global ones (what skinning needs); both sets at once do not fit a lone wave's registers
+    float M[NJ][9], Gt[NJ][3];
+    rodrigues(0.f, 0.f, 0.f, M[0]);
+    for_joints<Tree, 1>([&](int j) __attribute__((always_inline)) { rodrigues(th[3 * j - 3], th[3 * j - 2], th[3 * j - 1], M[j]); });
+    for (int x = 0; x < a.NE; ++x) {              // v_posed = v_shaped + posedirs^T (R - I)
+        const float* P = picked + (size_t)x * PICK_FLOATS;
+        float vp[3] = {P[0], P[1], P[2]};
+        for_joints<Tree, 1>([&](int j) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {
+                const float pf = M[j][e] - ((e % 4 == 0) ? 1.0f : 0.0f);
+                const float* pd = P + 3 + NJ + 3 * (9 * (j - 1) + e);
+                vp[0] = fmaf(pd[0], pf, vp[0]);
+                vp[1] = fmaf(pd[1], pf, vp[1]);
+                vp[2] = fmaf(pd[2], pf, vp[2]);
+            }
+        });
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vps[3 * x + c][threadIdx.x] = vp[c];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Gt[0][i] = a.model.rel[0][i];
+    for_joints<Tree, 1>([&](int j) __attribute__((always_inline)) {      // smplx batch_rigid_transform, as frame_transforms
+        const int p = Tree::parent(a.model, j);
+        float G[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) G[3 * r + b] = M[p][3 * r] * M[j][b] + M[p][3 * r + 1] * M[j][3 + b] + M[p][3 * r + 2] * M[j][6 + b];
+            Gt[j][r] = M[p][3 * r] * a.model.rel[j][0] + M[p][3 * r + 1] * a.model.rel[j][1] + M[p][3 * r + 2] * a.model.rel[j][2] + Gt[p][r];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) M[j][i] = G[i];
+    });
+    const int njt = NJ + a.NE;
+    for_joints<Tree, 0>([&](int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) a.joints[(n * njt + j) * 3 + e] = Gt[j][e];
+    });
+    for (int x = 0; x < a.NE; ++x) {              // sum_j W[v, j] (G_R[j] (v_posed - J_j) + G_t[j])
+        const float* P = picked + (size_t)x * PICK_FLOATS;
+        const float vp[3] = {vps[3 * x][threadIdx.x], vps[3 * x + 1][threadIdx.x], vps[3 * x + 2][threadIdx.x]};
+        float v[3] = {0.f, 0.f, 0.f};
+        for_joints<Tree, 0>([&](int j) __attribute__((always_inline)) {
+            const float w = P[3 + j];
+            const float u0 = vp[0] - a.model.J[j][0], u1 = vp[1] - a.model.J[j][1], u2 = vp[2] - a.model.J[j][2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = fmaf(w, M[j][3 * c] * u0 + M[j][3 * c + 1] * u1 + M[j][3 * c + 2] * u2 + Gt[j][c], v[c]);
+        });
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.joints[(n * njt + NJ + x) * 3 + c] = v[c];
+    }
+}
+extern "C" __global__ void __launch_bounds__(64) pndf_lbs_joints_only_kernel(PndfLbsArgs a, const float* picked) { lbs_joints_only_body<ModelTree>(a, picked); }
+extern "C" __global__ void __launch_bounds__(64) pndf_lbs_joints_only_smpl_kernel(PndfLbsArgs a, const float* picked) { lbs_joints_only_body<SmplTree>(a, picked); }
+
 __device__ __forceinline__ void lbs_rotate(f32x4 (&off)[3], f32x4 (&Tm)[12], const f32x4 (&off_n)[3], const f32x4 (&Tm_n)[12]) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) off[i] = off_n[i];
@@ -1214,6 +1285,7 @@ struct pndf_lbs_model {
     int V = 0, NG = 0, NE = 0;
     float* d_blob = nullptr;
     void* d_sblob = nullptr;          // the model for the split-precision kernels (pndf_lbs_split.h)
+    float* d_picked = nullptr;        // [NE][PICK_FLOATS]: the vertex-picked joints' own rows of the model (joints-only forward)
     int precision = PNDF_LBS_F16X3;   // forward and fused-terms passes; the general reverse pass is always fp32
     float p_scale = 1.f, w_scale = 1.f, a_scale = 1.f;      // powers of two: model and joint-transform operands
     float w_rowsum = 1.f;             // max_v sum_j |W[v, j]|                        (bounds |T_R^T g|)
@@ -1421,6 +1493,28 @@ extern "C" int pndf_lbs_create(pndf_lbs_handle* out, int32_t V, int32_t NB, cons
     h->sm_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     memcpy(h->consts.J, J, sizeof(J));
     memcpy(h->consts.rel, rel, sizeof(rel));
+    if (n_extra > 0) {
+        std::vector<float> pk((size_t)n_extra * PICK_FLOATS);
+        const int npf = 9 * (NJ - 1);
+        for (int x = 0; x < n_extra; ++x) {
+            const int v = extra_joint_vertex[x];
+            float* P = pk.data() + (size_t)x * PICK_FLOATS;
+            for (int c = 0; c < 3; ++c) {
+                double acc = v_template[(size_t)v * 3 + c];
+                for (int l = 0; l < NB; ++l) acc += (double)shapedirs[((size_t)v * 3 + c) * NB + l] * betas[l];
+                P[c] = (float)acc;
+            }
+            for (int j = 0; j < NJ; ++j) P[3 + j] = lbs_weights[(size_t)v * NJ + j];
+            for (int k = 0; k < npf; ++k)
+                for (int c = 0; c < 3; ++c) P[3 + NJ + 3 * k + c] = posedirs[(size_t)k * V * 3 + (size_t)v * 3 + c];
+        }
+        if (hipMalloc((void**)&h->d_picked, pk.size() * sizeof(float)) != hipSuccess ||
+            hipMemcpy(h->d_picked, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            if (h->d_picked) (void)hipFree(h->d_picked);
+            delete h;
+            return lbs_fail(nullptr, PNDF_ERR_HIP, "pndf_lbs_create: picked-joint table");
+        }
+    }
     h->smpl_tree = true;
     for (int j = 0; j < NJ; ++j) {
         h->consts.parent[j] = parents[j];
@@ -1457,6 +1551,7 @@ extern "C" int pndf_lbs_create(pndf_lbs_handle* out, int32_t V, int32_t NB, cons
         const std::string m = std::string("pndf_lbs_create: ") + hipGetErrorString(e);
         if (h->d_blob) (void)hipFree(h->d_blob);
         if (h->d_sblob) (void)hipFree(h->d_sblob);
+        if (h->d_picked) (void)hipFree(h->d_picked);
         delete h;
         return lbs_fail(nullptr, PNDF_ERR_HIP, m);
     }
@@ -1469,6 +1564,7 @@ extern "C" int pndf_lbs_destroy(pndf_lbs_handle h) {
     DeviceGuard guard(h->device);
     if (h->d_blob) (void)hipFree(h->d_blob);
     if (h->d_sblob) (void)hipFree(h->d_sblob);
+    if (h->d_picked) (void)hipFree(h->d_picked);
     delete h;
     return PNDF_OK;
 }
@@ -1546,6 +1642,13 @@ static int lbs_launch(pndf_lbs_model* h, int mode, PndfLbsArgs& a, void* workspa
     if (!guard.ok) return lbs_fail(h, PNDF_ERR_HIP, "hipSetDevice failed");
     const long long N = (long long)a.S * a.T;
     const dim3 fgrid((unsigned)((N + 63) / 64)), fblock(64);
+    if (mode == 0 && !a.verts && a.joints) {      // joints only: the chain + the picked vertices alone (lbs_joints_only_body)
+        if (h->smpl_tree) hipLaunchKernelGGL(pndf_lbs_joints_only_smpl_kernel, fgrid, fblock, 0, (hipStream_t)stream, a, (const float*)h->d_picked);
+        else hipLaunchKernelGGL(pndf_lbs_joints_only_kernel, fgrid, fblock, 0, (hipStream_t)stream, a, (const float*)h->d_picked);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return lbs_fail(h, PNDF_ERR_HIP, std::string("launch: ") + hipGetErrorString(e));
+        return PNDF_OK;
+    }
     const dim3 vgrid((unsigned)(((long long)a.S * a.cps + 3) / 4), (unsigned)(mode == 0 ? 1 : a.vsplit)), vblock(256);
     const int lds = 3 * BLOB * (int)sizeof(float);
     if (mode == 0) a.vsplit = split ? (h->NG < 8 ? h->NG : 8) : 1;      // (forward: the vertex ranges are independent outputs)
