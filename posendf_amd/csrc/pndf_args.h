@@ -97,6 +97,7 @@ struct PndfLbsArgs {
     float* gA;                 // [vsplit, S*T, 12, 32] d L / d joint transform entries
     float* halo_pf;            // [vsplit, S*cps, 208] the same for the frame a chunk shares with the next chunk
     float* halo_A;             // [vsplit, S*cps, 12, 32]
+    float* red;                // [207 + 12 * 24][S*T] the partial results summed over vertex ranges and halos, value-major
     float* verts;              // forward output [S*T, V, 3] or null
     float* joints;             // forward output [S*T, 24 + NE, 3] or null
     float* g_theta;            // [S*T, 69]

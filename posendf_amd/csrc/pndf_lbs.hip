@@ -534,6 +534,52 @@ extern "C" __global__ void __launch_bounds__(256, 1) pndf_lbs_vertex_forward_ker
 extern "C" __global__ void __launch_bounds__(256, 1) pndf_lbs_vertex_terms_kernel(PndfLbsArgs a) { lbs_vertex_body<1>(a); }
 extern "C" __global__ void __launch_bounds__(256, 1) pndf_lbs_vertex_reverse_kernel(PndfLbsArgs a) { lbs_vertex_body<2>(a); }
 
+// ------------------------------------------------------------------ partial results -> one value-major array
+// The vertex kernels leave d L / d pose_feature and d L / d A per vertex range (and once more for the frame a chunk shares
+// with the next one), frame-major.  The per-frame reverse kernels run one THREAD per frame; reading those rows directly,
+// every load of a wave touched 64 cache lines (stride 208 / 384 floats between lanes): 0.51 ms for 19,200 frames, a fifth
+// of the whole fused pass, all of it latency.  This kernel sums the ranges and halos in their fixed order (the same order
+// as before: bit-identical sums) and TRANSPOSES through LDS: read with lanes along the values of a frame, written with lanes
+// along the frames, so that the reverse kernels' loads are one line per wave.
+constexpr int RED_PF = 9 * (NJ - 1);               // 207 pose-feature rows, then 12 x 24 transform-entry rows
+constexpr int RED_ROWS = RED_PF + 12 * NJ;
+extern "C" __global__ void __launch_bounds__(256) pndf_lbs_reduce_partials_kernel(PndfLbsArgs a) {
+    __shared__ float tile[64][65];
+    const long long N = (long long)a.S * a.T;
+    const long long f0 = (long long)blockIdx.x * 64;
+    const int r0 = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int nch = a.S * a.cps;
+    const int r = r0 + tx;
+    const bool pf = r < RED_PF;
+    const int q = r - RED_PF;
+    const int off = pf ? r : (q / NJ) * 32 + (q % NJ);
+    const int stride = pf ? PF : A_FLOATS;
+    const float* base = pf ? a.gpf : a.gA;
+    const float* hbase = pf ? a.halo_pf : a.halo_A;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int fl = ty + 4 * it;
+        const long long n = f0 + fl;
+        float acc = 0.f;
+        if (n < N && r < RED_ROWS) {
+            for (int v = 0; v < a.vsplit; ++v) acc += base[((size_t)v * N + n) * stride + off];
+            const int s = (int)(n / a.T), t = (int)(n - (long long)s * a.T);
+            if (hbase && t > 0 && t % 15 == 0 && t / 15 < a.cps) {
+                const long long hidx = (long long)s * a.cps + t / 15 - 1;
+                for (int v = 0; v < a.vsplit; ++v) acc += hbase[((size_t)v * nch + hidx) * stride + off];
+            }
+        }
+        tile[tx][fl] = acc;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int rl = ty + 4 * it;
+        const long long n = f0 + tx;
+        if (n < N && r0 + rl < RED_ROWS) a.red[(size_t)(r0 + rl) * N + n] = tile[rl][tx];
+    }
+}
+
 // ------------------------------------------------------------------ per-frame reverse
 template <class Tree>
 __device__ __forceinline__ void lbs_pose_backward_body(const PndfLbsArgs& a) {
@@ -547,20 +593,9 @@ __device__ __forceinline__ void lbs_pose_backward_body(const PndfLbsArgs& a) {
     // the frame a chunk of pairs shares with the next chunk got a second partial result there
     const bool halo = a.halo_pf && t > 0 && t % 15 == 0 && t / 15 < a.cps;
     const long long hidx = (long long)s * a.cps + t / 15 - 1;
-    auto sum_pf = [&](int k) __attribute__((always_inline)) {
-        float acc = 0.f;
-        for (int v = 0; v < a.vsplit; ++v) acc += a.gpf[((size_t)v * N + n) * PF + k];
-        if (halo)
-            for (int v = 0; v < a.vsplit; ++v) acc += a.halo_pf[((size_t)v * nch + hidx) * PF + k];
-        return acc;
-    };
-    auto sum_A = [&](int e, int j) __attribute__((always_inline)) {
-        float acc = 0.f;
-        for (int v = 0; v < a.vsplit; ++v) acc += a.gA[((size_t)v * N + n) * A_FLOATS + e * 32 + j];
-        if (halo)
-            for (int v = 0; v < a.vsplit; ++v) acc += a.halo_A[((size_t)v * nch + hidx) * A_FLOATS + e * 32 + j];
-        return acc;
-    };
+    // (summed over vertex ranges and halos by pndf_lbs_reduce_partials_kernel: value-major, one line per wave and load)
+    auto sum_pf = [&](int k) __attribute__((always_inline)) { return a.red[(size_t)k * N + n]; };
+    auto sum_A = [&](int e, int j) __attribute__((always_inline)) { return a.red[(size_t)(RED_PF + e * NJ + j) * N + n]; };
     float gGR[NJ][9], gGt[NJ][3], gR[NJ][9];
     for_joints<Tree, 0>([&](int j) __attribute__((always_inline)) {
         float gAt[3];
@@ -643,31 +678,9 @@ extern "C" __global__ void __launch_bounds__(64) pndf_lbs_pose_backward_smpl_ker
     // partial results of joint i, summed over the vertex ranges (and the chunk that shares this frame) in a fixed order
     auto gather = [&](int i, float (&sA)[12], float (&sP)[9]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int e = 0; e < 12; ++e) sA[e] = 0.f;
+        for (int e = 0; e < 12; ++e) sA[e] = a.red[(size_t)(RED_PF + e * NJ + i) * N + n];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) sP[e] = 0.f;
-        for (int v = 0; v < a.vsplit; ++v) {
-            const float* qA = a.gA + ((size_t)v * N + n) * A_FLOATS + i;
-            const float* qP = a.gpf + ((size_t)v * N + n) * PF + 9 * (i - 1);
-#pragma unroll
-            for (int e = 0; e < 12; ++e) sA[e] += qA[e * 32];
-            if (i >= 1) {
-#pragma unroll
-                for (int e = 0; e < 9; ++e) sP[e] += qP[e];
-            }
-        }
-        if (halo) {
-            for (int v = 0; v < a.vsplit; ++v) {
-                const float* qA = a.halo_A + ((size_t)v * nch + hidx) * A_FLOATS + i;
-                const float* qP = a.halo_pf + ((size_t)v * nch + hidx) * PF + 9 * (i - 1);
-#pragma unroll
-                for (int e = 0; e < 12; ++e) sA[e] += qA[e * 32];
-                if (i >= 1) {
-#pragma unroll
-                    for (int e = 0; e < 9; ++e) sP[e] += qP[e];
-                }
-            }
-        }
+        for (int e = 0; e < 9; ++e) sP[e] = (i >= 1) ? a.red[(size_t)(9 * (i - 1) + e) * N + n] : 0.f;
     };
     float pGR[NJ][9], pGt[NJ][3];      // pending: what a joint's children handed up (static indices: only the live ones cost registers)
     static_for<NJ>([&](auto ic) __attribute__((always_inline)) {
@@ -1614,10 +1627,11 @@ static int64_t lbs_workspace(const pndf_lbs_model* h, int64_t S, int64_t T, Pndf
     float* gA = take((int64_t)vsplit * N * A_FLOATS);
     float* hpf = take((int64_t)vsplit * nch * PF);
     float* hA = take((int64_t)vsplit * nch * A_FLOATS);
+    float* red = take(N * RED_ROWS);
     float* pfs = take(N * (PNDF_LBS_PFS_HALFS / 2));       // split-precision B operands (halfs)
     float* Aps = take(N * (PNDF_LBS_APS_HALFS / 2));
     if (a) {
-        a->pfp = pfp; a->Ap = Ap; a->Gt = Gt; a->gpf = gpf; a->gA = gA;
+        a->pfp = pfp; a->Ap = Ap; a->Gt = Gt; a->gpf = gpf; a->gA = gA; a->red = red;
         a->halo_pf = (mode == 1) ? hpf : nullptr; a->halo_A = (mode == 1) ? hA : nullptr;
         a->cps = cps; a->vsplit = vsplit;
     }
@@ -1674,6 +1688,7 @@ static int lbs_launch(pndf_lbs_model* h, int mode, PndfLbsArgs& a, void* workspa
                 hipLaunchKernelGGL(pndf_lbs_vertex_split_forward_kernel, sgrid, vblock, lds_s, (hipStream_t)stream, sa);
         } else {
             hipLaunchKernelGGL(pndf_lbs_vertex_split_terms_kernel, sgrid, vblock, lds_s, (hipStream_t)stream, sa);
+            hipLaunchKernelGGL(pndf_lbs_reduce_partials_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((RED_ROWS + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a);
             if (h->smpl_tree) {
                 hipLaunchKernelGGL(pndf_lbs_pose_backward_smpl_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
                 hipLaunchKernelGGL(pndf_lbs_rodrigues_vjp_kernel, dim3((unsigned)((N * (NJ - 1) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
@@ -1691,6 +1706,7 @@ static int lbs_launch(pndf_lbs_model* h, int mode, PndfLbsArgs& a, void* workspa
     } else {
         if (mode == 1) hipLaunchKernelGGL(pndf_lbs_vertex_terms_kernel, vgrid, vblock, lds, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(pndf_lbs_vertex_reverse_kernel, vgrid, vblock, lds, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(pndf_lbs_reduce_partials_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((RED_ROWS + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a);
         if (h->smpl_tree) {
             hipLaunchKernelGGL(pndf_lbs_pose_backward_smpl_kernel, fgrid, fblock, 0, (hipStream_t)stream, a);
             hipLaunchKernelGGL(pndf_lbs_rodrigues_vjp_kernel, dim3((unsigned)((N * (NJ - 1) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
