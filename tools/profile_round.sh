@@ -6,14 +6,20 @@ OUT=${1:-gpurun_out/round}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 cd "$ROOT"
-python bench.py --steps 5 --warmup 1 > "$OUT/bench_head.json" 2> "$OUT/bench_head.err"
-echo "bench rc=$?"
 for cfg in "f16x3 lrelu" "f16x3 softplus" "fp32 lrelu"; do
     set -- $cfg
     bash tools/gpu_profile.sh "$OUT/prof_$1_$2" "$1" "$2" > "$OUT/prof_$1_$2.log" 2>&1
     echo "profile $1 $2 rc=$?"
 done
 cd "$ROOT"
+# the HBM bytes of THIS build into profiles/traffic.json before the bench line reads it (else the line says traffic_stale)
+W="(B=65536 x 100 steps)"
+bash tools/collect_profiles.sh "$OUT/prof_f16x3_lrelu" "$OUT/collected/f16x3" pndf_fused_split_relu_kernel "bench.py --precision f16x3 --act lrelu $W" > /dev/null
+bash tools/collect_profiles.sh "$OUT/prof_f16x3_softplus" "$OUT/collected/f16x3_softplus" pndf_fused_split_softplus_kernel "bench.py --precision f16x3 --act softplus $W" > /dev/null
+bash tools/collect_profiles.sh "$OUT/prof_fp32_lrelu" "$OUT/collected/fp32" pndf_fused_relu_kernel "bench.py --precision fp32 --act lrelu $W" > /dev/null
+cp profiles/traffic.json "$OUT/traffic.json"
+python bench.py --steps 5 --warmup 1 > "$OUT/bench_head.json" 2> "$OUT/bench_head.err"
+echo "bench rc=$?"
 python tools/gpu_region_timing.py 3 f16x3 lrelu > "$OUT/regions_f16x3_lrelu.txt" 2>&1
 python tools/gpu_region_timing.py 3 f16x3 softplus > "$OUT/regions_f16x3_softplus.txt" 2>&1
 python tools/gpu_region_timing.py 3 fp32 lrelu > "$OUT/regions_fp32_lrelu.txt" 2>&1
@@ -26,7 +32,7 @@ smi() { rocm-smi --showpower --showclocks 2>/dev/null | grep -E "sclk|Package Po
         set -- $cfg
         python bench.py --steps 150 --warmup 1 --no-cpu-baseline --no-fp32-ref --no-gpu-torch-baseline --no-parity-sample --no-motion-denoise --precision $1 --act $2 > /dev/null 2>&1 &
         pid=$!
-        sleep 14
+        sleep 9
         echo "== $1 $2 project loop running"
         for i in 1 2 3 4 5 6 7 8; do smi; sleep 0.6; done
         wait $pid
