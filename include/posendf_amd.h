@@ -40,7 +40,8 @@ typedef enum {
     PNDF_ERR_HIP = -3,            /* a HIP runtime call failed (text in pndf_last_error) */
     PNDF_ERR_UNSUPPORTED = -4,    /* activation / architecture the kernels do not implement */
     PNDF_ERR_NO_WEIGHTS = -5,     /* compute call before pndf_load_weights */
-    PNDF_ERR_NO_DEVICE = -6       /* no gfx950 device visible */
+    PNDF_ERR_NO_DEVICE = -6,      /* no gfx950 device visible */
+    PNDF_ERR_HOST = -7            /* host twins only: a worker thread or an allocation failed (text in pndf_cpu_last_error) */
 } pndf_status;
 
 typedef enum { PNDF_ACT_RELU = 0, PNDF_ACT_LRELU = 1, PNDF_ACT_SOFTPLUS = 2 } pndf_act;

@@ -18,6 +18,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -50,7 +52,7 @@ struct pndf_cpu_engine {
 
 namespace {
 
-std::string g_cpu_create_err;
+thread_local std::string g_cpu_create_err;      // (per thread, like pndf_lbs_last_error(nullptr))
 
 int cpu_fail(pndf_cpu_engine* h, int code, const std::string& msg) {
     (h ? h->err : g_cpu_create_err) = msg;
@@ -226,19 +228,34 @@ int threads_for(int64_t blocks) {
     return (int)std::min<int64_t>(n, blocks);
 }
 
+// (throws std::runtime_error when a worker or a thread start failed: the entry points turn it into PNDF_ERR_HOST)
 template <class F>
 void parallel_blocks(int64_t B, F&& body) {
     const int64_t blocks = (B + PB - 1) / PB;
     const int nt = threads_for(blocks);
+    std::atomic<bool> failed{false};
     auto worker = [&](int t) {
-        Scratch S;
-        for (int64_t blk = t; blk < blocks; blk += nt) body(blk * PB, (int)std::min<int64_t>(PB, B - blk * PB), S);
+        try {
+            Scratch S;
+            for (int64_t blk = t; blk < blocks && !failed.load(std::memory_order_relaxed); blk += nt)
+                body(blk * PB, (int)std::min<int64_t>(PB, B - blk * PB), S);
+        } catch (...) {      // (an allocation of the scratch: nothing else in a block throws)
+            failed.store(true);
+        }
     };
-    if (nt == 1) { worker(0); return; }
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; ++t) pool.emplace_back(worker, t);
-    worker(0);
-    for (auto& th : pool) th.join();
+    if (nt == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> pool;
+        try {
+            for (int t = 1; t < nt; ++t) pool.emplace_back(worker, t);
+        } catch (...) {
+            failed.store(true);      // the blocks of the threads that did not start stay undone: the call fails as a whole
+        }
+        if (!failed.load()) worker(0);
+        for (auto& th : pool) th.join();
+    }
+    if (failed.load()) throw std::runtime_error("a worker thread could not be started or ran out of memory");
 }
 
 int check(pndf_cpu_engine* h, const void* q, int64_t B) {
@@ -247,6 +264,19 @@ int check(pndf_cpu_engine* h, const void* q, int64_t B) {
     if (B < 0) return cpu_fail(h, PNDF_ERR_BAD_ARG, "negative batch");
     if (B > 0 && !q) return cpu_fail(h, PNDF_ERR_BAD_ARG, "null pose pointer");
     return PNDF_OK;
+}
+
+// No C++ exception may cross the C ABI: a failed thread start or allocation becomes a status code with its text.
+template <class F>
+int guarded(pndf_cpu_engine* h, F&& body) {
+    try {
+        body();
+        return PNDF_OK;
+    } catch (const std::exception& e) {
+        return cpu_fail(h, PNDF_ERR_HOST, std::string("host resource failure: ") + e.what());
+    } catch (...) {
+        return cpu_fail(h, PNDF_ERR_HOST, "host resource failure");
+    }
 }
 
 }  // namespace
@@ -264,12 +294,13 @@ extern "C" int pndf_cpu_create(pndf_cpu_handle* out, const pndf_config* cfg) {
         if (cfg->dims[l] < 1 || cfg->dims[l] > DIMS[l])      // the same architectures the device engine accepts
             return cpu_fail(nullptr, PNDF_ERR_UNSUPPORTED, "hidden widths up to configs/amass.yaml's");
     if (cfg->act == PNDF_ACT_SOFTPLUS && !(cfg->beta > 0.f)) return cpu_fail(nullptr, PNDF_ERR_BAD_ARG, "Softplus beta must be positive");
-    pndf_cpu_engine* h = new pndf_cpu_engine();
-    h->cfg = *cfg;
-    h->encoder = cfg->dims[0] == NFEAT;
-    for (int l = 0; l <= NLIN; ++l) h->dims[l] = cfg->dims[l];
-    *out = h;
-    return PNDF_OK;
+    return guarded(nullptr, [&] {
+        pndf_cpu_engine* h = new pndf_cpu_engine();
+        h->cfg = *cfg;
+        h->encoder = cfg->dims[0] == NFEAT;
+        for (int l = 0; l <= NLIN; ++l) h->dims[l] = cfg->dims[l];
+        *out = h;
+    });
 }
 
 extern "C" int pndf_cpu_destroy(pndf_cpu_handle h) {
@@ -283,25 +314,31 @@ extern "C" int pndf_cpu_load_weights(pndf_cpu_handle h, const float* const* tens
     if (!h || !tensors || !numel) return PNDF_ERR_BAD_ARG;
     const int want = (h->encoder ? 4 * NJ : 0) + 2 * NLIN;
     if (n_tensors != want) return cpu_fail(h, PNDF_ERR_BAD_SHAPE, "tensor count: " + std::to_string(n_tensors) + ", expected " + std::to_string(want));
-    int t = 0;
-    auto take = [&](Layer& L, int out, int in) -> bool {
-        if (!tensors[t] || !tensors[t + 1] || numel[t] != (int64_t)out * in || numel[t + 1] != out) return false;
-        L.in = in; L.out = out;
-        L.w.assign(tensors[t], tensors[t] + (size_t)out * in);
-        L.b.assign(tensors[t + 1], tensors[t + 1] + out);
-        L.wt.resize((size_t)in * out);
-        for (int o = 0; o < out; ++o)
-            for (int i = 0; i < in; ++i) L.wt[(size_t)i * out + o] = L.w[(size_t)o * in + i];
-        t += 2;
-        return true;
-    };
-    if (h->encoder)
-        for (int j = 0; j < NJ; ++j)
-            if (!take(h->enc[j][0], HID, enc_in(j)) || !take(h->enc[j][1], FEAT, HID))
-                return cpu_fail(h, PNDF_ERR_BAD_SHAPE, "encoder tensor " + std::to_string(t) + " has the wrong size");
-    for (int l = 0; l < NLIN; ++l)
-        if (!take(h->lin[l], h->dims[l + 1], h->dims[l]))
-            return cpu_fail(h, PNDF_ERR_BAD_SHAPE, "dfnet.lin" + std::to_string(l) + " has the wrong size");
+    h->have_weights = false;      // a failed load leaves no half-loaded engine behind
+    int rc = PNDF_OK;
+    const int grc = guarded(h, [&] {
+        int t = 0;
+        auto take = [&](Layer& L, int out, int in) -> bool {
+            if (!tensors[t] || !tensors[t + 1] || numel[t] != (int64_t)out * in || numel[t + 1] != out) return false;
+            L.in = in; L.out = out;
+            L.w.assign(tensors[t], tensors[t] + (size_t)out * in);
+            L.b.assign(tensors[t + 1], tensors[t + 1] + out);
+            L.wt.resize((size_t)in * out);
+            for (int o = 0; o < out; ++o)
+                for (int i = 0; i < in; ++i) L.wt[(size_t)i * out + o] = L.w[(size_t)o * in + i];
+            t += 2;
+            return true;
+        };
+        if (h->encoder)
+            for (int j = 0; j < NJ && rc == PNDF_OK; ++j)
+                if (!take(h->enc[j][0], HID, enc_in(j)) || !take(h->enc[j][1], FEAT, HID))
+                    rc = cpu_fail(h, PNDF_ERR_BAD_SHAPE, "encoder tensor " + std::to_string(t) + " has the wrong size");
+        for (int l = 0; l < NLIN && rc == PNDF_OK; ++l)
+            if (!take(h->lin[l], h->dims[l + 1], h->dims[l]))
+                rc = cpu_fail(h, PNDF_ERR_BAD_SHAPE, "dfnet.lin" + std::to_string(l) + " has the wrong size");
+    });
+    if (grc != PNDF_OK) return grc;
+    if (rc != PNDF_OK) return rc;
     h->have_weights = true;
     return PNDF_OK;
 }
@@ -309,24 +346,27 @@ extern "C" int pndf_cpu_load_weights(pndf_cpu_handle h, const float* const* tens
 extern "C" int pndf_forward_cpu(pndf_cpu_handle h, const float* q, float* d, int64_t B) {
     if (int rc = check(h, q, B)) return rc;
     if (B > 0 && !d) return cpu_fail(h, PNDF_ERR_BAD_ARG, "null output pointer");
-    parallel_blocks(B, [&](int64_t p0, int nb, Scratch& S) { forward_grad_block(*h, q + p0 * NQ, nb, nullptr, d + p0, nullptr, false, S); });
-    return PNDF_OK;
+    return guarded(h, [&] {
+        parallel_blocks(B, [&](int64_t p0, int nb, Scratch& S) { forward_grad_block(*h, q + p0 * NQ, nb, nullptr, d + p0, nullptr, false, S); });
+    });
 }
 
 extern "C" int pndf_forward_grad_cpu(pndf_cpu_handle h, const float* q, const float* grad_out, float* d, float* dq, int64_t B) {
     if (int rc = check(h, q, B)) return rc;
     if (B > 0 && !dq) return cpu_fail(h, PNDF_ERR_BAD_ARG, "null output pointer");
-    parallel_blocks(B, [&](int64_t p0, int nb, Scratch& S) {
-        float dd[PB];
-        forward_grad_block(*h, q + p0 * NQ, nb, grad_out ? grad_out + p0 : nullptr, dd, dq + p0 * NQ, true, S);
-        if (d) memcpy(d + p0, dd, sizeof(float) * nb);
+    return guarded(h, [&] {
+        parallel_blocks(B, [&](int64_t p0, int nb, Scratch& S) {
+            float dd[PB];
+            forward_grad_block(*h, q + p0 * NQ, nb, grad_out ? grad_out + p0 : nullptr, dd, dq + p0 * NQ, true, S);
+            if (d) memcpy(d + p0, dd, sizeof(float) * nb);
+        });
     });
-    return PNDF_OK;
 }
 
 extern "C" int pndf_project_cpu(pndf_cpu_handle h, const float* q_in, float* q_out, float* d_last, int64_t B, int steps) {
     if (int rc = check(h, q_in, B)) return rc;
     if (steps < 0 || (B > 0 && !q_out)) return cpu_fail(h, PNDF_ERR_BAD_ARG, "negative step count or null output pointer");
+    return guarded(h, [&] {
     parallel_blocks(B, [&](int64_t p0, int nb, Scratch& S) {
         float qb[PB * NQ], dqb[PB * NQ], dd[PB];
         memcpy(qb, q_in + p0 * NQ, sizeof(float) * nb * NQ);
@@ -342,5 +382,5 @@ extern "C" int pndf_project_cpu(pndf_cpu_handle h, const float* q_in, float* q_o
         memcpy(q_out + p0 * NQ, qb, sizeof(float) * nb * NQ);
         if (d_last) memcpy(d_last + p0, dd, sizeof(float) * nb);
     });
-    return PNDF_OK;
+    });
 }

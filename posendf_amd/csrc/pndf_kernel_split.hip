@@ -39,6 +39,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // (a, b) -> packed fp16 pairs: hi = rtz(a, b) (one v_cvt_pkrtz), lo = rne(a - hi_a, b - hi_b).  The remainders
 // are exact in fp32; rounding lo to NEAREST keeps the residual error unbiased (+-2^-23 relative) -- with a
 // truncated lo the error of a 1024-term contraction accumulates linearly instead of as a random walk.
+#ifndef PNDF_SPLIT_FOUR
+#define PNDF_SPLIT_FOUR 0
+#endif
 template <bool SINGLE>
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
     if constexpr (SINGLE) {        // plain fp16 operands: round to nearest, no lo part
@@ -52,6 +55,9 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     const unsigned hp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
     hi = hp;
     // remainders a - hi_a, b - hi_b (exact in fp32) in ONE mixed-precision FMA each: fma(f16 half of hp, -1.0, a)
+    // (fma in fp32, the result rounded to fp16 straight into one half of the register: the same bits as v_fma_mix_f32 +
+    // v_cvt_pk_f16_f32 for every input, tools/ubench/split_probe.hip -- three instructions per pair instead of four)
+#if PNDF_SPLIT_FOUR      // (A/B arm: the four-instruction form of rounds 2-4)
     float ra, rb;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hp), "v"(a));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hp), "v"(b));
@@ -59,6 +65,12 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     l[0] = (_Float16)ra;
     l[1] = (_Float16)rb;
     lo = __builtin_bit_cast(unsigned, l);
+#else
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hp), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hp), "v"(b));
+    lo = l;
+#endif
 }
 
 // LeakyReLU / ReLU forward on the split path: y = max(z, slope z) (exact for 0 <= slope < 1) and the derivative bit

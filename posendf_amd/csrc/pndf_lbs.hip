@@ -804,13 +804,12 @@ __device__ __forceinline__ f32x4 mf16(f16x8 a, f16x8 b, f32x4 c) { return __buil
 __device__ __forceinline__ void lbs_split2(float a, float b, unsigned& hi, unsigned& lo) {
     const unsigned hp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
     hi = hp;
-    float ra, rb;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hp), "v"(a));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hp), "v"(b));
-    f16x2 l;
-    l[0] = (_Float16)ra;
-    l[1] = (_Float16)rb;
-    lo = __builtin_bit_cast(unsigned, l);
+    // (fma in fp32, the result rounded to fp16 straight into one half of the register: the same bits as v_fma_mix_f32 +
+    // v_cvt_pk_f16_f32 for every input, tools/ubench/split_probe.hip -- three instructions per pair instead of four)
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hp), "v"(a));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hp), "v"(b));
+    lo = l;
 }
 __device__ __forceinline__ void lbs_split4(const f32x4& v, f16x4& hi, f16x4& lo) {
     unsigned h0, l0, h1, l1;
@@ -981,7 +980,7 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
         i32x4 fl;
         f32x4 vs[3], vp[3], V[3], d[3], n2, inv, u[3], gV[3];
     };
-    // model fetch: piece j (0 .. 11) of this wave -- KiB wave + 4 j of the 45 of blob `grp` -- into buffer `buf`; the twelfth
+    // model fetch: piece j (0 .. 11) of this wave -- KiB 11 wave + j of the 45 of blob `grp` -- into buffer `buf`; the twelfth
     // piece exists for wave 0 only (KiB 44): the other waves fetch it as well (same bytes) rather than branch
     constexpr int DMA_PIECES = (SBB / 1024 + 3) / 4;
     static_assert(SBB / 1024 == 45 && DMA_PIECES == 12, "pieces of the model fetch");
@@ -989,11 +988,18 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
     // the next LDS read, whatever buffer that reads; the explicit wait at the top of a group is what orders fetch and use)
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(lds_char*)smem_s);
     const uint32_t lane16 = (uint32_t)lane * 16u;
+    // A wave's eleven pieces are consecutive KiB (11 wave .. 11 wave + 10): four pieces share one source pointer and one M0,
+    // the instruction offset moves both addresses (as the distance engine's ring does, pndf_device.h) -- two scalar
+    // instructions per piece less than one pointer + one M0 per piece.  M0 is written by nothing else in these kernels.
     auto dma_piece = [&](int grp, int buf, int j) __attribute__((always_inline)) {
-        const int kib = (j < DMA_PIECES - 1) ? wave + 4 * j : SBB / 1024 - 1;
+        const int jb = (j < DMA_PIECES - 1) ? (j & ~3) : j;
+        const int kib = (j < DMA_PIECES - 1) ? wave * (DMA_PIECES - 1) + jb : SBB / 1024 - 1;
         const char* src = (const char*)sa.sblob + (size_t)grp * SBB + (size_t)kib * 1024;
         const uint32_t dst = lds_base + (uint32_t)(buf * SBB + kib * 1024);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane16), "s"(src), "s"(dst) : "memory", "m0");
+        if (j == jb) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane16), "s"(src), "s"(dst) : "memory", "m0");
+        else if (j - jb == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(lane16), "s"(src) : "memory");
+        else if (j - jb == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(lane16), "s"(src) : "memory");
+        else asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(lane16), "s"(src) : "memory");
     };
     // half h (0: hi tiles, 1: lo tiles) of the operand of forward step `st` (k-block st / 3, component st % 3; st == FSTEPS: W)
     auto fwd_ld = [&](const char* B, int st, int h, PTile& t) __attribute__((always_inline)) {
@@ -1214,7 +1220,9 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
                     if (pc == 2) Xe[e & 1] = cat(xh, xl);
                 }
             };
-            const f16x8 B0h = cat(gh[0], gh[1]), B0l = cat(gl[0], gl[1]), B1 = cat(gh[2], gl[2]);
+            const f16x8 B0h = cat(gh[0], gh[1]), B0l = cat(gl[0], gl[1]);
+            // component 2: the row tile's [hi | lo] registers as they were read serve both MFMAs (no copies in front of them)
+            const f16x8 B1 = cat(gh[2], gh[2]), B2 = cat(gl[2], zero4);
             // MFMA t (0 .. 4) of row tile kt of d L / d pose_feature; behind it, row reads of tile kt + RLA
             auto gpf_mfma = [&](int kt, int t) __attribute__((always_inline)) {
                 const RTile& tc = rt[kt % (RLA + 1)];
@@ -1223,8 +1231,8 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
                 else if (t == 0) gpf[kt] = mf16(cat(tc.c0h, tc.c1h), B0h, gpf[kt]);
                 else if (t == 1) gpf[kt] = mf16(cat(tc.c0h, tc.c1h), B0l, gpf[kt]);
                 else if (t == 2) gpf[kt] = mf16(cat(tc.c0l, tc.c1l), B0h, gpf[kt]);
-                else if (t == 3) gpf[kt] = mf16(cat(tc.c2h, tc.c2h), B1, gpf[kt]);       // hi hi + hi lo of component 2 in one k-block
-                else gpf[kt] = mf16(cat(tc.c2l, zero4), B1, gpf[kt]);
+                else if (t == 3) gpf[kt] = mf16(cat(tc.c2h, tc.c2l), B1, gpf[kt]);       // hi hi + lo hi of component 2 in one k-block
+                else gpf[kt] = mf16(cat(tc.c2h, tc.c2l), B2, gpf[kt]);                   // hi lo (the lo half meets zeros)
                 __builtin_amdgcn_sched_barrier(0);
                 // (the registers of tile kt + RLA are those of tile kt - 1: free since its last MFMA)
                 if (kt + RLA < KT) {

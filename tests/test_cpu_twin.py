@@ -125,6 +125,14 @@ def test_host_twin_configurations_and_refusals():
         eng.load_weights(synth.make_weights(0, 2.0, 0.1, dims=synth.DFNET_DIMS_NOENC))
     eng.load_weights(golden_weights("live"))
     eng.forward(buf.ctypes.data, out.ctypes.data, 0)
+    # a load that fails half way (one tensor of the wrong size) leaves no half-loaded engine behind
+    bad_sd = dict(golden_weights("live"))
+    bad_sd["dfnet.lin3.bias"] = bad_sd["dfnet.lin3.bias"][:-1]
+    with pytest.raises(PndfError):
+        eng.load_weights(bad_sd)
+    with pytest.raises(PndfError):
+        eng.forward(buf.ctypes.data, out.ctypes.data, 2)
+    eng.load_weights(golden_weights("live"))
     lib = load_library()
     assert lib.pndf_forward_cpu(eng.handle, None, out.ctypes.data, 2) == -1
     with pytest.raises(PndfError):
