@@ -790,7 +790,7 @@ namespace {
 constexpr int KB = PNDF_LBS_KB, SBB = PNDF_LBS_SB_BYTES, PLANE = PNDF_LBS_SB_PLANE;
 #ifndef PNDF_LBS_DIAG
 #define PNDF_LBS_DIAG 0     // timing diagnostics (WRONG results): 1 = no wait for the model fetch, 2 = no fetch, 4 = no barrier,
-#endif                      // 64 = no reverse MFMAs
+#endif                      // 8 = no operand splits in the reverse pass, 16 / 32 = no forward / reverse tile reads after the first, 64 = no reverse MFMAs
 #ifndef PNDF_LBS_FLA
 #define PNDF_LBS_FLA 2      // forward steps / reverse row tiles whose LDS reads are in flight ahead of the MFMAs that use them
 #endif
@@ -799,7 +799,6 @@ constexpr int KB = PNDF_LBS_KB, SBB = PNDF_LBS_SB_BYTES, PLANE = PNDF_LBS_SB_PLA
 #endif
 
 __device__ __forceinline__ f32x4 mf16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-
 // (a, b) -> packed fp16 pairs: hi = rtz(a, b), lo = rne(a - hi_a, b - hi_b); the remainders are exact in fp32
 __device__ __forceinline__ void lbs_split2(float a, float b, unsigned& hi, unsigned& lo) {
     const unsigned hp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
@@ -1075,12 +1074,15 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
             for (int r = r0; r < r0 + 2; ++r) q.gV[a3][r] = q.u[a3][r] - prev_frame(q.u[a3][r]);      // lane 0: no pair inside this chunk
         }
     };
-    struct RBase { lds_char *c0h, *c1h, *c2h, *c0l, *c1l, *c2l, *wh, *wl; };      // row-read bases of a group, one register each
+    struct RBase { lds_char *c0h, *c1h, *c2h, *c0l, *c1l, *c2l, *wh, *wl, *wm; };      // row-read bases of a group, one register each
     auto rev_base = [&](const char* B) __attribute__((always_inline)) {
         lds_char* q = (lds_char*)B + lane_rv;
         return RBase{lds_opaque(q + PNDF_LBS_SB_PH), lds_opaque(q + PNDF_LBS_SB_PH + PLANE), lds_opaque(q + PNDF_LBS_SB_PH + 2 * PLANE),
                      lds_opaque(q + PNDF_LBS_SB_PL), lds_opaque(q + PNDF_LBS_SB_PL + PLANE), lds_opaque(q + PNDF_LBS_SB_PL + 2 * PLANE),
-                     lds_opaque(q + PNDF_LBS_SB_WH), lds_opaque(q + PNDF_LBS_SB_WL)};
+                     lds_opaque(q + PNDF_LBS_SB_WH), lds_opaque(q + PNDF_LBS_SB_WL),
+                     // second joint tile (joints 16 .. 23 + eight rows of padding): tile rows 0 .. 7 read the hi plane's rows,
+                     // tile rows 8 .. 15 the LO plane's rows of the same eight joints
+                     lds_opaque((lds_char*)B + (p < 8 ? PNDF_LBS_SB_WH : PNDF_LBS_SB_WL) + 512 + 8 * pndf_lbs_sb_unit(p & 7, g))};
     };
     // row read `w` (0 .. 5) of row tile kt
     auto rev_ld = [&](const RBase& rb, int kt, int w, RTile& t) __attribute__((always_inline)) {
@@ -1103,6 +1105,15 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
     //            (five MFMAs) <- its row reads RLA tiles ahead; the thirteenth tile at the end
     constexpr int NG1 = (MODE == 0) ? 0 : 15, M1A = (MODE == 0) ? FMFMA : NP1;
     static_assert(NP1 + NG1 <= 3 * FSTEPS, "all readers of Tm sit behind pose-blend MFMAs, in front of the skinning MFMAs");
+    // (PNDF_LBS_DIAG & 256: s_memtime stamps at the region boundaries of a group, printed by one wave at the end)
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+    auto stamp = [&](int r) __attribute__((always_inline)) {
+        if (PNDF_LBS_DIAG & 256) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tacc[r] += now - tlast;
+            tlast = now;
+        }
+    };
     auto group = [&](auto has_next, auto has_fetch, int grp, f32x4 (&off)[3], f32x4 (&Tm)[12], f32x4 (&off_n)[3]) __attribute__((always_inline)) {
         constexpr bool HAS_NEXT = decltype(has_next)::value;
         constexpr bool FETCH = decltype(has_fetch)::value && !(PNDF_LBS_DIAG & 2);
@@ -1134,18 +1145,21 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
             __builtin_amdgcn_sched_barrier(0);
             fwd_mfma(m, tl, off_n, Tm);
             __builtin_amdgcn_sched_barrier(0);
-            fwd_reads(Bn, m, tl);
+            if (!(PNDF_LBS_DIAG & 16)) fwd_reads(Bn, m, tl);
             if constexpr (FETCH && m % 4 == 1 && m / 4 < DMA_PIECES) dma_piece(grp + 2, (k + 2) % 3, m / 4);
             if constexpr (m < NP1) valu_piece(m, q, B, off, Tm);
             else if constexpr (m < NP1 + NG1) g_piece(m - NP1);
         };
+        stamp(5);      // (loop overhead since the last group's end)
         if constexpr (HAS_NEXT) {
             if (!(PNDF_LBS_DIAG & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of blob grp + 1 have landed ...
             if (!(PNDF_LBS_DIAG & 4)) __syncthreads();            // ... everyone's have, and everyone has left buffer (k + 2) % 3
+            stamp(0);
 #pragma unroll
             for (int st = 0; st < FLA; ++st) { fwd_ld(Bn, st, 0, tl[st]); fwd_ld(Bn, st, 1, tl[st]); }
             static_for<M1A>([&](auto mc) __attribute__((always_inline)) { fwd_slot(mc); });
             __builtin_amdgcn_sched_barrier(0);
+            stamp(1);
         } else {
             static_for<NP1>([&](auto ic) __attribute__((always_inline)) { valu_piece(decltype(ic)::value, q, B, off, Tm); });
         }
@@ -1184,6 +1198,7 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
             if constexpr (HAS_NEXT) {
                 static_for<FMFMA - M1A>([&](auto mc) __attribute__((always_inline)) { fwd_slot(std::integral_constant<int, M1A + decltype(mc)::value>{}); });
                 __builtin_amdgcn_sched_barrier(0);
+                stamp(2);
             } else {
                 static_for<NG1>([&](auto ic) __attribute__((always_inline)) { g_piece(decltype(ic)::value); });
             }
@@ -1192,12 +1207,16 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
             const f16x4 zero4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
             const RBase rb = rev_base(B);
             RTile rt[RLA + 1];
-            f16x8 AWh[2], AWl[2];      // W^T: rows = joints; hi: the tile's 16 vertices twice (hi hi + hi lo in one k-block), lo: once
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt) {
-                const f16x4 wh = lds_row(rb.wh + jt * 512), wl = lds_row(rb.wl + jt * 512);
-                AWh[jt] = cat(wh, wh);
-                AWl[jt] = cat(wl, zero4);
+            // W^T: rows = joints.  Joints 0 .. 15: hi with the tile's 16 vertices twice (hi hi + hi lo in one k-block) and lo
+            // once.  Joints 16 .. 23 fill half a tile: its other eight rows carry the LO halves of the same joints (twice as
+            // well: lo hi + lo lo), so ONE MFMA does all of it -- rows 8 .. 15 of the accumulator are added to rows 0 .. 7
+            // when the kernel stores its results (36 instead of 48 MFMAs per group for d L / d A).
+            f16x8 AW[3];
+            {
+                const f16x4 wh = lds_row(rb.wh), wl = lds_row(rb.wl), wm = lds_row(rb.wm);
+                AW[0] = cat(wh, wh);
+                AW[1] = cat(wl, zero4);
+                AW[2] = cat(wm, wm);
             }
 #pragma unroll
             for (int kt = 0; kt < RLA; ++kt)
@@ -1235,7 +1254,7 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
                 else gpf[kt] = mf16(cat(tc.c2h, tc.c2l), B2, gpf[kt]);                   // hi lo (the lo half meets zeros)
                 __builtin_amdgcn_sched_barrier(0);
                 // (the registers of tile kt + RLA are those of tile kt - 1: free since its last MFMA)
-                if (kt + RLA < KT) {
+                if (kt + RLA < KT && !(PNDF_LBS_DIAG & 32)) {
                     rev_ld(rb, kt + RLA, t, rt[(kt + RLA) % (RLA + 1)]);
                     if (t == 4) rev_ld(rb, kt + RLA, 5, rt[(kt + RLA) % (RLA + 1)]);
                 }
@@ -1244,15 +1263,16 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
             for (int a3 = 0; a3 < 3; ++a3) gVs[a3] = gVs[a3] * sa.x_scale;
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) x_piece(0, pc);
+            stamp(3);
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
 #pragma unroll
-                for (int jm = 0; jm < 4; ++jm) {
+                for (int jm = 0; jm < 3; ++jm) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (PNDF_LBS_DIAG & 64) asm volatile("" : : "v"(AWh[jm / 2]), "v"(AWl[jm / 2]), "v"(Xe[i & 1]));
-                    else gA[i][jm / 2] = mf16((jm % 2) ? AWl[jm / 2] : AWh[jm / 2], Xe[i & 1], gA[i][jm / 2]);
+                    if (PNDF_LBS_DIAG & 64) asm volatile("" : : "v"(AW[jm]), "v"(Xe[i & 1]));
+                    else gA[i][jm / 2] = mf16(AW[jm], Xe[i & 1], gA[i][jm / 2]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (jm < 3 && i + 1 < 12) x_piece(i + 1, jm);
+                    if (i + 1 < 12 && !(PNDF_LBS_DIAG & 8)) x_piece(i + 1, jm);
                 }
 #pragma unroll
                 for (int t = 0; t < 5; ++t) gpf_mfma(i, t);
@@ -1260,6 +1280,7 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
 #pragma unroll
             for (int t = 0; t < 5; ++t) gpf_mfma(KT - 1, t);
             __builtin_amdgcn_sched_barrier(0);
+            stamp(4);
             static_assert(KT == 13, "row tiles of d L / d pose_feature: one per entry of d L / d A, one left over");
         }
         if constexpr (HAS_NEXT) {
@@ -1279,20 +1300,31 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
         __syncthreads();
         forward_all(smem_s, off, Tm);
     }
+    if (PNDF_LBS_DIAG & 256) tlast = __builtin_amdgcn_s_memtime();
     for (int grp = grp0; grp + 2 < grp1; ++grp) group(std::true_type{}, std::true_type{}, grp, off, Tm, off_n);
     if (grp0 + 1 < grp1) group(std::true_type{}, std::false_type{}, grp1 - 2, off, Tm, off_n);
     if (grp0 < grp1) group(std::false_type{}, std::false_type{}, grp1 - 1, off, Tm, off_n);
+    if ((PNDF_LBS_DIAG & 256) && MODE == 1 && blockIdx.x == 37 && threadIdx.x == 64)
+        printf("lbs regions (cycles of %d groups, wave 1 of workgroup 37): wait+barrier %llu  fwd 1a %llu  fwd 1b %llu  rev prologue %llu  rev %llu  between groups %llu\n",
+               grp1 - grp0, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5]);
     if constexpr (MODE != 0) {
+        float* o_A = nullptr;
         if (t_ok) {
             float* o_pf = owned ? a.gpf + ((size_t)vs * N + n) * PF : a.halo_pf + ((size_t)vs * nch + cid) * PF;
-            float* o_A = owned ? a.gA + ((size_t)vs * N + n) * A_FLOATS : a.halo_A + ((size_t)vs * nch + cid) * A_FLOATS;
+            o_A = owned ? a.gA + ((size_t)vs * N + n) * A_FLOATS : a.halo_A + ((size_t)vs * nch + cid) * A_FLOATS;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) *(f32x4*)(o_pf + 16 * kt + 4 * g) = gpf[kt] * sa.gpf_true;
 #pragma unroll
-            for (int e = 0; e < 12; ++e) {
-                *(f32x4*)(o_A + e * 32 + 4 * g) = gA[e][0] * sa.gA_true;
-                *(f32x4*)(o_A + e * 32 + 16 + 4 * g) = gA[e][1] * sa.gA_true;
-            }
+            for (int e = 0; e < 12; ++e) *(f32x4*)(o_A + e * 32 + 4 * g) = gA[e][0] * sa.gA_true;
+        }
+        // second joint tile: accumulator rows 8 .. 15 (lanes 32 .. 63) hold the lo halves' share of joints 16 .. 23 (every lane
+        // takes part in the exchange; rows 24 .. 31 of the output are the padding joints: zero, as W's padding rows made them)
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            f32x4 hi_part = gA[e][1], lo_part;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lo_part[r] = __shfl_down(hi_part[r], 32, 64);
+            if (t_ok) *(f32x4*)(o_A + e * 32 + 16 + 4 * g) = (g < 2) ? (hi_part + lo_part) * sa.gA_true : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 }
