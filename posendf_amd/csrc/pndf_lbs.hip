@@ -797,6 +797,9 @@ constexpr int KB = PNDF_LBS_KB, SBB = PNDF_LBS_SB_BYTES, PLANE = PNDF_LBS_SB_PLA
 #ifndef PNDF_LBS_RLA
 #define PNDF_LBS_RLA 1
 #endif
+#ifndef PNDF_LBS_PAIR_READS
+#define PNDF_LBS_PAIR_READS 0
+#endif
 
 __device__ __forceinline__ f32x4 mf16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 // (a, b) -> packed fp16 pairs: hi = rtz(a, b), lo = rne(a - hi_a, b - hi_b); the remainders are exact in fp32
@@ -806,8 +809,9 @@ __device__ __forceinline__ void lbs_split2(float a, float b, unsigned& hi, unsig
     // (fma in fp32, the result rounded to fp16 straight into one half of the register: the same bits as v_fma_mix_f32 +
     // v_cvt_pk_f16_f32 for every input, tools/ubench/split_probe.hip -- three instructions per pair instead of four)
     unsigned l;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hp), "v"(a));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hp), "v"(b));
+    // (one statement: between two, hipcc pads a wait state it cannot know to be unnecessary)
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(l) : "v"(hp), "v"(a), "v"(b));
     lo = l;
 }
 __device__ __forceinline__ void lbs_split4(const f32x4& v, f16x4& hi, f16x4& lo) {
@@ -990,11 +994,11 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
     // A wave's eleven pieces are consecutive KiB (11 wave .. 11 wave + 10): four pieces share one source pointer and one M0,
     // the instruction offset moves both addresses (as the distance engine's ring does, pndf_device.h) -- two scalar
     // instructions per piece less than one pointer + one M0 per piece.  M0 is written by nothing else in these kernels.
-    auto dma_piece = [&](int grp, int buf, int j) __attribute__((always_inline)) {
+    auto dma_piece = [&](int grp, uint32_t buf_off, int j) __attribute__((always_inline)) {      // buf_off: the buffer's byte offset
         const int jb = (j < DMA_PIECES - 1) ? (j & ~3) : j;
         const int kib = (j < DMA_PIECES - 1) ? wave * (DMA_PIECES - 1) + jb : SBB / 1024 - 1;
         const char* src = (const char*)sa.sblob + (size_t)grp * SBB + (size_t)kib * 1024;
-        const uint32_t dst = lds_base + (uint32_t)(buf * SBB + kib * 1024);
+        const uint32_t dst = lds_base + buf_off + (uint32_t)(kib * 1024);
         if (j == jb) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane16), "s"(src), "s"(dst) : "memory", "m0");
         else if (j - jb == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(lane16), "s"(src) : "memory");
         else if (j - jb == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(lane16), "s"(src) : "memory");
@@ -1074,12 +1078,34 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
             for (int r = r0; r < r0 + 2; ++r) q.gV[a3][r] = q.u[a3][r] - prev_frame(q.u[a3][r]);      // lane 0: no pair inside this chunk
         }
     };
-    struct RBase { lds_char *c0h, *c1h, *c2h, *c0l, *c1l, *c2l, *wh, *wl, *wm; };      // row-read bases of a group, one register each
+#if PNDF_LBS_PAIR_READS
+    // Row reads of the reverse pass: ONE lane-dependent base per group and constant offsets.  The two planes an MFMA operand is
+    // made of lie a multiple of 512 bytes apart (PLANE = 14 x 512, PL - PH = 42 x 512), so hipcc merges the pair into one
+    // ds_read2st64_b64 whose four result registers ARE the operand: 39 instead of 78 LDS instructions per group.
+    struct RBase { lds_char *q, *wm; };
+    auto rev_base = [&](const char* B) __attribute__((always_inline)) {
+        // wm: second joint tile (joints 16 .. 23 + eight rows of padding): tile rows 0 .. 7 read the hi plane's rows, tile rows
+        // 8 .. 15 the LO plane's rows of the same eight joints
+        return RBase{lds_opaque((lds_char*)B + lane_rv),
+                     lds_opaque((lds_char*)B + (p < 8 ? PNDF_LBS_SB_WH : PNDF_LBS_SB_WL) + 512 + 8 * pndf_lbs_sb_unit(p & 7, g))};
+    };
+    // pair `w` (0: components 0, 1 hi   1: components 0, 1 lo   2: component 2 hi, lo) of row tile kt
+    auto rev_ld = [&](const RBase& rb, int kt, int w, RTile& t) __attribute__((always_inline)) {
+        lds_char* q = rb.q + kt * 512;
+        if (w == 0) { t.c0h = lds_row(q + PNDF_LBS_SB_PH); t.c1h = lds_row(q + PNDF_LBS_SB_PH + PLANE); }
+        else if (w == 1) { t.c0l = lds_row(q + PNDF_LBS_SB_PL); t.c1l = lds_row(q + PNDF_LBS_SB_PL + PLANE); }
+        else { t.c2h = lds_row(q + PNDF_LBS_SB_PH + 2 * PLANE); t.c2l = lds_row(q + PNDF_LBS_SB_PL + 2 * PLANE); }
+    };
+#else
+    // Row reads of the reverse pass: one ds_read_b64 each, through one opaque base per plane (off ONE base hipcc merges the two
+    // planes of an MFMA operand -- a multiple of 512 bytes apart -- into a ds_read2st64_b64: 39 instead of 78 LDS instructions
+    // per group, and 2 % SLOWER, same box: profiles/r04/lbs/ablation_r04.txt)
+    struct RBase { lds_char *c0h, *c1h, *c2h, *c0l, *c1l, *c2l, *q, *wm; };
     auto rev_base = [&](const char* B) __attribute__((always_inline)) {
         lds_char* q = (lds_char*)B + lane_rv;
         return RBase{lds_opaque(q + PNDF_LBS_SB_PH), lds_opaque(q + PNDF_LBS_SB_PH + PLANE), lds_opaque(q + PNDF_LBS_SB_PH + 2 * PLANE),
                      lds_opaque(q + PNDF_LBS_SB_PL), lds_opaque(q + PNDF_LBS_SB_PL + PLANE), lds_opaque(q + PNDF_LBS_SB_PL + 2 * PLANE),
-                     lds_opaque(q + PNDF_LBS_SB_WH), lds_opaque(q + PNDF_LBS_SB_WL),
+                     lds_opaque(q),
                      // second joint tile (joints 16 .. 23 + eight rows of padding): tile rows 0 .. 7 read the hi plane's rows,
                      // tile rows 8 .. 15 the LO plane's rows of the same eight joints
                      lds_opaque((lds_char*)B + (p < 8 ? PNDF_LBS_SB_WH : PNDF_LBS_SB_WL) + 512 + 8 * pndf_lbs_sb_unit(p & 7, g))};
@@ -1093,6 +1119,7 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
         else if (w == 4) t.c2h = lds_row(rb.c2h + kt * 512);
         else t.c2l = lds_row(rb.c2l + kt * 512);
     };
+#endif
 
     // One group.  HAS_NEXT: the forward pass of group grp + 1 runs through the VALU section of group grp -- the pose-blend
     // MFMAs accumulate into off_n while `off` is still read, the skinning MFMAs come last and write Tm IN PLACE: by then every
@@ -1105,6 +1132,9 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
     //            (five MFMAs) <- its row reads RLA tiles ahead; the thirteenth tile at the end
     constexpr int NG1 = (MODE == 0) ? 0 : 15, M1A = (MODE == 0) ? FMFMA : NP1;
     static_assert(NP1 + NG1 <= 3 * FSTEPS, "all readers of Tm sit behind pose-blend MFMAs, in front of the skinning MFMAs");
+    // byte offsets of the three model buffers by role -- this group's blob, the next one's, the fetch target -- rotated at
+    // the end of every group (a group index modulo 3 costs a dozen scalar instructions per group)
+    uint32_t rot0 = 0u, rot1 = (uint32_t)SBB, rot2 = 2u * (uint32_t)SBB;
     // (PNDF_LBS_DIAG & 256: s_memtime stamps at the region boundaries of a group, printed by one wave at the end)
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
     auto stamp = [&](int r) __attribute__((always_inline)) {
@@ -1117,9 +1147,8 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
     auto group = [&](auto has_next, auto has_fetch, int grp, f32x4 (&off)[3], f32x4 (&Tm)[12], f32x4 (&off_n)[3]) __attribute__((always_inline)) {
         constexpr bool HAS_NEXT = decltype(has_next)::value;
         constexpr bool FETCH = decltype(has_fetch)::value && !(PNDF_LBS_DIAG & 2);
-        const int k = grp - grp0;
-        const char* B = smem_s + (k % 3) * SBB;
-        const char* Bn = smem_s + ((k + 1) % 3) * SBB;
+        const char* B = smem_s + rot0;
+        const char* Bn = smem_s + rot1;
         GState q;
         PTile tl[FLA + 1];
         f32x4 gt[3];
@@ -1146,7 +1175,7 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
             fwd_mfma(m, tl, off_n, Tm);
             __builtin_amdgcn_sched_barrier(0);
             if (!(PNDF_LBS_DIAG & 16)) fwd_reads(Bn, m, tl);
-            if constexpr (FETCH && m % 4 == 1 && m / 4 < DMA_PIECES) dma_piece(grp + 2, (k + 2) % 3, m / 4);
+            if constexpr (FETCH && m % 4 == 1 && m / 4 < DMA_PIECES) dma_piece(grp + 2, rot2, m / 4);
             if constexpr (m < NP1) valu_piece(m, q, B, off, Tm);
             else if constexpr (m < NP1 + NG1) g_piece(m - NP1);
         };
@@ -1213,7 +1242,7 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
             // when the kernel stores its results (36 instead of 48 MFMAs per group for d L / d A).
             f16x8 AW[3];
             {
-                const f16x4 wh = lds_row(rb.wh), wl = lds_row(rb.wl), wm = lds_row(rb.wm);
+                const f16x4 wh = lds_row(rb.q + PNDF_LBS_SB_WH), wl = lds_row(rb.q + PNDF_LBS_SB_WL), wm = lds_row(rb.wm);
                 AW[0] = cat(wh, wh);
                 AW[1] = cat(wl, zero4);
                 AW[2] = cat(wm, wm);
@@ -1221,7 +1250,7 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
 #pragma unroll
             for (int kt = 0; kt < RLA; ++kt)
 #pragma unroll
-                for (int w = 0; w < 6; ++w) rev_ld(rb, kt, w, rt[kt]);
+                for (int w = 0; w < (PNDF_LBS_PAIR_READS ? 3 : 6); ++w) rev_ld(rb, kt, w, rt[kt]);
             f32x4 X;
             f16x4 xh, xl;
             f16x8 Xe[2];
@@ -1255,8 +1284,12 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
                 __builtin_amdgcn_sched_barrier(0);
                 // (the registers of tile kt + RLA are those of tile kt - 1: free since its last MFMA)
                 if (kt + RLA < KT && !(PNDF_LBS_DIAG & 32)) {
+#if PNDF_LBS_PAIR_READS
+                    if (t < 3) rev_ld(rb, kt + RLA, t, rt[(kt + RLA) % (RLA + 1)]);
+#else
                     rev_ld(rb, kt + RLA, t, rt[(kt + RLA) % (RLA + 1)]);
                     if (t == 4) rev_ld(rb, kt + RLA, 5, rt[(kt + RLA) % (RLA + 1)]);
+#endif
                 }
             };
 #pragma unroll
@@ -1287,14 +1320,16 @@ __device__ __forceinline__ void lbs_vertex_split_body(const PndfLbsSplitArgs& sa
 #pragma unroll
             for (int c3 = 0; c3 < 3; ++c3) off[c3] = off_n[c3];
         }
+        const uint32_t r = rot0;
+        rot0 = rot1; rot1 = rot2; rot2 = r;
     };
     f32x4 off[3], Tm[12], off_n[3];      // accumulators: p_scale 2^12 x pose-blend offset, w_scale a_scale x sum_j W[v, j] A_j
     if (grp0 < grp1) {
 #pragma unroll
-        for (int j = 0; j < DMA_PIECES; ++j) dma_piece(grp0, 0, j);
+        for (int j = 0; j < DMA_PIECES; ++j) dma_piece(grp0, 0u, j);
         if (grp0 + 1 < grp1) {
 #pragma unroll
-            for (int j = 0; j < DMA_PIECES; ++j) dma_piece(grp0 + 1, 1, j);
+            for (int j = 0; j < DMA_PIECES; ++j) dma_piece(grp0 + 1, (uint32_t)SBB, j);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
