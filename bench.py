@@ -47,59 +47,108 @@ def _cpu_model():
     return "unknown CPU"
 
 
+def _physical_cores():
+    """One hardware thread per physical core among the CPUs this process may run on (SMT siblings share a core's FPUs:
+    two torch threads on one core are one thread's worth of matmul), in CPU order (= socket by socket)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, picked = set(), []
+    for c in allowed:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                sib = f.read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            picked.append(c)
+    return picked, len(allowed)
+
+
+def _pin_process(cpus):
+    """CPU affinity of EVERY thread of this process (torch's intra-op pool exists already: new masks are not inherited
+    by running threads).  Returns what to pass back to restore."""
+    before = {}
+    for t in os.listdir("/proc/self/task"):
+        try:
+            before[int(t)] = os.sched_getaffinity(int(t))
+            os.sched_setaffinity(int(t), cpus)
+        except OSError:
+            pass
+    return before
+
+
+def _unpin_process(before):
+    for t, mask in before.items():
+        try:
+            os.sched_setaffinity(t, mask)
+        except OSError:
+            pass
+
+
 def cpu_baseline(act, sd, proj_steps, budget_s=24.0, runs=3, batch=4096):
     """The reference's CPU PyTorch path (restated in oracle/posendf_torch.py) on this box's host cores, SURVEY.md 8d:
-    B = 4,096 poses (fixed: matmuls large enough for the threads to have work), thread count chosen by a short
-    calibration over {8, 16, 32, 64} (64 threads on a [742 x 1024] matmul was oversubscription), then
-    `runs` timed projections (median reported).  Every projection step does identical work, so when the full 100 steps
-    at B = 4,096 do not fit the budget the timed run does fewer steps and is scaled linearly -- the sample says so.
-    Plus BASELINE.json configs[0] (B = 256, forward only, median of 10)."""
+    B = 4,096 poses (fixed: matmuls large enough for the threads to have work); the process is confined to ONE hardware
+    thread per physical core and the thread count is chosen by a calibration over {8, 16, 32, 64} of those cores (3 steps
+    each, best of two; the box's host is shared), then `runs` timed projections (median reported).
+    Every projection step does identical work, so when the full 100 steps at B = 4,096 do not fit the budget the timed
+    run does fewer steps and is scaled linearly -- the sample says so.  Plus BASELINE.json configs[0] (B = 256, forward
+    only, median of 10)."""
     import statistics
     import torch
     from oracle.posendf_torch import RefNet, project
     from posendf_amd import synth
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    phys, visible = _physical_cores()
     net = RefNet(act)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     q = torch.from_numpy(synth.make_poses(batch, seed=1234))
-    candidates = sorted({t for t in (8, 16, 32, 64) if t <= cores} or {max(1, cores)})
+    candidates = sorted({t for t in (8, 16, 32, 64) if t <= len(phys)} or {max(1, len(phys))})
+    load_before = os.getloadavg()
     calib = {}
-    for t in candidates:                                        # calibration: pose-steps per second at B = 4,096, 1 step
-        torch.set_num_threads(t)
-        project(net, q, 1)                                      # warm-up (thread pool, allocator)
-        t0 = time.perf_counter()
-        project(net, q, 1)
-        calib[t] = batch / (time.perf_counter() - t0)
-    threads = max(calib, key=calib.get)
-    torch.set_num_threads(threads)
-    timed_steps = int(min(proj_steps, max(5, calib[threads] * budget_s / runs / batch)))
-    times = []
-    for _ in range(runs):
-        t0 = time.perf_counter()
-        project(net, q, timed_steps)
-        times.append(time.perf_counter() - t0)
-    dt = statistics.median(times) * proj_steps / timed_steps   # seconds per full projection of the batch
-    # configs[0]: batch = 256, PoseNDF.forward() distance only, PyTorch CPU
-    q0 = q[:256]
-    with torch.no_grad():
-        for _ in range(3):
-            net(q0)
-        f_t = []
-        for _ in range(10):
+    restore = _pin_process(set(phys))
+    try:
+        for t in candidates:                                    # calibration: pose-steps per second at B = 4,096, 3 steps
+            _pin_process(set(phys[:t]))
+            torch.set_num_threads(t)
+            project(net, q, 1)                                  # warm-up (thread pool, allocator)
+            best = 0.0
+            for _ in range(2):
+                t0 = time.perf_counter()
+                project(net, q, 3)
+                best = max(best, 3 * batch / (time.perf_counter() - t0))
+            calib[t] = best
+        threads = max(calib, key=calib.get)
+        _pin_process(set(phys[:threads]))
+        torch.set_num_threads(threads)
+        timed_steps = int(min(proj_steps, max(5, calib[threads] * budget_s / runs / batch)))
+        times = []
+        for _ in range(runs):
             t0 = time.perf_counter()
-            net(q0)
-            f_t.append(time.perf_counter() - t0)
-    f_med = statistics.median(f_t)
+            project(net, q, timed_steps)
+            times.append(time.perf_counter() - t0)
+        dt = statistics.median(times) * proj_steps / timed_steps   # seconds per full projection of the batch
+        # configs[0]: batch = 256, PoseNDF.forward() distance only, PyTorch CPU
+        q0 = q[:256]
+        with torch.no_grad():
+            for _ in range(3):
+                net(q0)
+            f_t = []
+            for _ in range(10):
+                t0 = time.perf_counter()
+                net(q0)
+                f_t.append(time.perf_counter() - t0)
+        f_med = statistics.median(f_t)
+    finally:
+        _unpin_process(restore)
     scaled = "" if timed_steps == proj_steps else f" ({timed_steps} steps timed, scaled linearly to {proj_steps}: every step does identical work)"
     return {"value": batch / dt, "unit": "projected poses/s", "cores": threads, "kind": "port", "cpu": _cpu_model(),
             "batch": batch, "timed_steps": timed_steps, "runs_s": [round(t, 3) for t in times],
+            "runs_spread": round((max(times) - min(times)) / statistics.median(times), 3),
             "thread_calibration_pose_steps_per_s": {str(t): round(v, 1) for t, v in calib.items()},
+            "pinned_to": f"{threads} distinct physical cores (one hardware thread each) of {len(phys)} visible",
+            "host_loadavg_before_after": [[round(x, 1) for x in load_before], [round(x, 1) for x in os.getloadavg()]],
             "sample": f"B={batch} poses x {proj_steps} steps{scaled}, median of {runs} runs = {dt:.1f} s per projection; "
-                      f"PyTorch-CPU restatement of the reference (oracle/posendf_torch.py), {threads} threads (best of "
-                      f"{candidates} in a one-step calibration) on {cores} visible cores of a {_cpu_model()}",
+                      f"PyTorch-CPU restatement of the reference (oracle/posendf_torch.py), {threads} threads pinned to distinct "
+                      f"physical cores (best of {candidates} in a 3-step calibration) on {visible} visible hardware threads of a {_cpu_model()}",
             "config0_forward_only": {"workload": "BASELINE.json configs[0]: batch=256, forward() distance only, PyTorch CPU",
                                      "ms": f_med * 1e3, "poses_per_s": 256 / f_med, "runs": 10}}
 
@@ -187,6 +236,69 @@ class GpuTelemetry:
         return {"sclk_mhz": None, "package_w": None, "telemetry_samples": 0, "telemetry_source": "unavailable"}
 
 
+def box_block(dev_index, lib):
+    """What the box is, so that a slow line can be told from a slow box: partition modes, clock
+    tables and firmware of the device matched by PCI address, the runtime's view of it, the host's load, and the memory
+    subsystem as the weight stream sees it (pndf_debug_mem_probe: dependent-load latency with the footprint in L2 /
+    Infinity Cache / HBM, streaming read bandwidth).  Read once, outside the timed region."""
+    import ctypes
+    import glob
+    import torch
+    pr = torch.cuda.get_device_properties(dev_index)
+    out = {"device": pr.name, "arch": getattr(pr, "gcnArchName", None), "compute_units": pr.multi_processor_count,
+           "hbm_gib": round(pr.total_memory / 2**30, 1), "l2_bytes": getattr(pr, "L2_cache_size", None),
+           "hip": torch.version.hip, "torch": torch.__version__,
+           "host_loadavg": [round(x, 2) for x in os.getloadavg()], "host_cpus_visible": len(os.sched_getaffinity(0))}
+    try:
+        want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except AttributeError:
+        want = None
+    out["pci"] = want
+
+    def rd(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+    devdir = None
+    for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        if os.path.basename(os.path.realpath(d)).lower() == want:
+            devdir = d
+    out["sysfs_devices_visible"] = len(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+    if devdir:
+        for key in ("current_compute_partition", "current_memory_partition", "vbios_version", "power_dpm_force_performance_level",
+                    "mem_busy_percent", "gpu_busy_percent"):
+            out[key] = rd(os.path.join(devdir, key))
+        for clk in ("sclk", "mclk", "fclk", "socclk"):
+            t = rd(os.path.join(devdir, "pp_dpm_" + clk))
+            if t is not None:      # "0: 132Mhz\n1: 2400Mhz *": the table and the level in use
+                levels = [ln.strip() for ln in t.splitlines()]
+                out["pp_dpm_" + clk] = {"levels": [ln.rstrip(" *") for ln in levels], "current": next((ln.rstrip(" *") for ln in levels if ln.endswith("*")), None)}
+        fw = {}
+        for f in sorted(glob.glob(os.path.join(devdir, "fw_version", "*_fw_version"))):
+            name = os.path.basename(f)[:-len("_fw_version")]
+            if name in ("smc", "mec", "sdma", "vcn", "rlc", "pfp", "me", "sos", "asd"):
+                fw[name] = rd(f)
+        out["fw_version"] = fw
+        hw = sorted(glob.glob(os.path.join(devdir, "hwmon", "hwmon*")))
+        if hw:
+            cap = rd(os.path.join(hw[0], "power1_cap"))
+            out["power_cap_w"] = float(cap) / 1e6 if cap else None
+            for n, key in (("freq1_input", "sclk_idle_mhz"), ("freq2_input", "mclk_idle_mhz")):
+                v = rd(os.path.join(hw[0], n))
+                out[key] = float(v) / 1e6 if v else None
+    out["amdgpu_driver"] = rd("/sys/module/amdgpu/version")
+    probe = (ctypes.c_double * 6)()
+    rc = lib.pndf_debug_mem_probe(int(dev_index), probe, 6)
+    out["mem_probe"] = ({"l2_hit_latency_ns": round(probe[0], 1), "infinity_cache_latency_ns": round(probe[1], 1),
+                         "hbm_latency_ns": round(probe[2], 1), "stream_read_gbps": round(probe[3], 1),
+                         "what": "dependent-load latency of one lane walking 128-byte lines of a 1 MiB / 64 MiB / 1 GiB footprint "
+                                 f"({int(probe[5])} hops each, wall-clock counter at {probe[4]:.0f} MHz); read bandwidth over 1 GiB, all CUs "
+                                 "(posendf_amd/csrc/pndf_probe.hip)"} if rc == 0 else {"error": rc})
+    return out
+
+
 def smi_snapshot():
     """One rocm-smi reading (fallback when the hwmon files are absent); called while a launch is in flight."""
     import re
@@ -267,6 +379,7 @@ def main():
     ap.add_argument("--frames", type=int, default=300, help="--workload denoise: frames per sequence")
     ap.add_argument("--adam-steps", type=int, default=10, help="--workload denoise: Adam steps per harness step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-box", action="store_true", help="skip the `box` / `regions` diagnostics blocks")
     ap.add_argument("--no-gpu-torch-baseline", action="store_true")
     ap.add_argument("--lbs-torch-baseline", action="store_true", help="also time a PyTorch restatement of the body-model terms (4 x 300 frames)")
     ap.add_argument("--no-motion-denoise", action="store_true", help="skip the configs[4] side block")
@@ -520,6 +633,24 @@ def main():
 
     side = world == 1 and not args.no_fp32_ref      # the side runs belong to the N = 1 line; scaling runs stay short
     fwd_grad = host_ms = None
+    # Where the cycles of a step go ON THIS BOX: one 3-step launch of the instrumented build of the measured kernel right
+    # after the timed loop (s_memtime stamps per region; the weight ring's counted wait and barrier sampled every 16th slot),
+    # and what the box is.  A slow box must be diagnosable from its own line.
+    regions = box = None
+    if rank == 0 and args.workload == "project" and not args.no_box:
+        eng0 = net._engine_for(dev)
+        try:
+            if not (args.act == "softplus" and B > 64 * torch.cuda.get_device_properties(dev).multi_processor_count):
+                regions = eng0.project_timing(q0, steps=3)
+                regions["kernel"] = eng0.kernel_name() + "_timing"
+            if args.act != "softplus" and precision == "f16x3":
+                # the same launch through the exact-fp32 instrumented kernel: a ring that stalls the split kernel (a slot lasts
+                # ~300 cycles) but not this one (~2,200) is a latency problem; both alike is something else
+                r32 = build("fp32")._engine_for(dev).project_timing(q0, steps=3)
+                regions["fp32_kernel"] = {k: r32[k] for k in ("cycles_per_wave_step", "effective_sclk_ghz", "ring", "launch_ms")}
+        except Exception as exc:       # an analysis aid must not take the line down
+            regions = {"error": repr(exc)}
+        box = box_block(dev_index, eng0.lib)
     if side:
         host_ms = host_boundary_ms()
         ms1 = fwd_grad_ms(net)
@@ -676,6 +807,9 @@ def main():
                                           "tools/ubench/mfma_power.hip); the kernel is power-bound"}
                             if precision == "f16x3" else {}),
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/traffic.json)",
+                         "traffic_source": ("profiled on ANOTHER box with separate rocprofv3 --pmc passes of this command "
+                                            "(tools/gpu_profile.sh; same sources: traffic_stale false) -- a property of the kernel, "
+                                            "not a measurement of this run") if traffic is not None else None,
                          "algorithmic_bytes_per_launch": B * 676 + 10720 * 1024,
                          "kernel": kname, "kernel_ms": kern_ms,
                          "kernel_ms_median": float(np.median([e[0].elapsed_time(e[1]) for e in ev])) if args.steps else None,
@@ -684,6 +818,10 @@ def main():
         }
         if dist_info is not None:
             out["distributed"] = dist_info
+        if box is not None:
+            out["box"] = box
+        if regions is not None:
+            out["regions"] = regions
         if parity is not None:
             out["parity_sample"] = parity
         if host_ms is not None:

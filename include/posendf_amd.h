@@ -114,11 +114,22 @@ int pndf_debug_forward_grad(pndf_handle h, const float* q, float* d, float* dq, 
 int64_t pndf_debug_floats(void);
 
 /* Performance analysis aid: pndf_project through a kernel instrumented with s_memtime stamps.
- * cycles[(workgroup * 4 + wave) * pndf_debug_timing_regions() + r] = shader cycles spent in region r
- * (device buffer of ceil(B/64) * 4 * regions uint64). */
+ * cycles[(workgroup * 4 + wave) * pndf_debug_timing_regions() + r] = shader cycles of that wave, summed over the steps
+ * (device buffer of ceil(B/64) * 4 * regions uint64).  A row is [regions of a step | per-group stamps | ring events]:
+ * pndf_debug_timing_layout(0 / 1 / 2) = the three lengths.  Ring events (the weight ring's two synchronous events, sampled
+ * every pndf_debug_timing_layout(3)-th slot): [0] cycles in the counted vmcnt wait = the slot's DMA had not landed, i.e. the
+ * look-ahead of pndf_debug_timing_layout(4) - 1 slots did not cover the fetch latency; [1] cycles in the barrier; [2] sampled
+ * slots; [3] what two stamps back to back measure (the floor of [0] / [2]). */
 int pndf_debug_project_timing(pndf_handle h, const float* q_in, float* q_out, int64_t B, int steps,
                               unsigned long long* cycles, void* stream);
 int pndf_debug_timing_regions(void);
+int pndf_debug_timing_layout(int what);
+
+/* Measurement aid: the memory subsystem of `device` as the fused kernels' weight stream sees it -- dependent-load latency
+ * (ns) with the walked footprint resident in L2 (1 MiB), in the Infinity Cache (64 MiB) and in HBM (1 GiB): out[0..2];
+ * streaming read bandwidth (GB/s): out[3]; wall-clock counter rate (MHz): out[4]; hops timed: out[5].  n_out >= 6.
+ * Allocates 1 GiB for the duration of the call and synchronises the device (bench.py's `box` block). */
+int pndf_debug_mem_probe(int device, double* out, int n_out);
 
 /* ---- host twins (SURVEY.md 8b `pndf_*_cpu`): the same three operations on HOST pointers, for a caller whose
  * `train.device` is "cpu" (model/posendf.py:35,64 runs wherever the config says).  A separate handle type with no device

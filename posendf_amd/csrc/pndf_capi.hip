@@ -29,6 +29,7 @@ extern "C" __global__ void pndf_fused_half_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_half_relu_kernel_timing(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_relu_kernel_timing(PndfKernelArgs args);
 extern "C" int pndf_kernel_timing_regions();
+extern "C" int pndf_kernel_timing_layout(int what);
 extern "C" long long pndf_kernel_softplus_scratch_floats_per_wg();
 extern "C" __global__ void pndf_fused_relu_kernel_dbg(PndfKernelArgs args);
 extern "C" int pndf_kernel_lds_bytes();
@@ -55,7 +56,7 @@ struct pndf_engine {
     std::string err;
 };
 
-constexpr int STREAM_PAD_SLOTS = 4;           // RING_SLOTS - 1 of pndf_device.h: the ring's prefetch distance
+constexpr int STREAM_PAD_SLOTS = 5;           // >= RING_SLOTS - 1 of pndf_device.h (the ring's prefetch distance; 5 covers the six-buffer experiment arm)
 
 static thread_local std::string g_create_err;
 
@@ -591,6 +592,7 @@ extern "C" int pndf_debug_forward_grad(pndf_handle h, const float* q, float* d, 
 }
 
 extern "C" int pndf_debug_timing_regions(void) { return pndf_kernel_timing_regions(); }
+extern "C" int pndf_debug_timing_layout(int what) { return pndf_kernel_timing_layout(what); }
 
 // project() through the instrumented kernel; cycles[(wg * 4 + wave) * regions + r] = shader cycles
 extern "C" int pndf_debug_project_timing(pndf_handle h, const float* q_in, float* q_out, int64_t B, int steps,

@@ -21,13 +21,22 @@ constexpr int SLOT_BYTES = SLOT_TILES * TILE_BYTES;          // 16 KiB
 // constant LDS addresses above 64 KiB would each be materialised in an SGPR, hoisted out of the step loop
 // and spilled.  The DMA ring sits at the bottom so that its M0 base stays below 64 KiB.
 constexpr int FSTRIDE = 132;                                 // floats per pose in the feature buffer (bank skew)
-constexpr int RING_SLOTS = 5;
+#ifndef PNDF_RING_SLOTS
+#define PNDF_RING_SLOTS 5      // product: 5 buffers = a slot is fetched FOUR slots ahead.  3 / 4 (look-ahead 2 / 3) are the arms of the
+#endif                         // latency-margin curve (profiles/r05/ring_margin.txt); 6 only with -DPNDF_RING_ALIAS_F (timing only:
+                               // the feature buffer then overlays the pose tile -- WRONG results -- to make room for a sixth buffer)
+constexpr int RING_SLOTS = PNDF_RING_SLOTS;
+static_assert(RING_SLOTS >= 3 && RING_SLOTS <= 6, "ring depth");
 constexpr int MASK_ROWS = 48;                                // u8 [48][256]: x1 8 chunks, x3 32 chunks, x5 4 chunks x 2 bytes
 constexpr int LDS_RING = 0;                                  // 5 slots of 16 KiB (DMA target, lowest addresses)
 constexpr int LDS_BIAS = LDS_RING + RING_SLOTS * SLOT_BYTES; // BIAS_FLOATS floats (trunk + encoder biases)
 constexpr int LDS_MASK = LDS_BIAS + BIAS_FLOATS * 4;         // chunk-layer sign bits
 constexpr int LDS_Q = LDS_MASK + MASK_ROWS * WG_THREADS;     // float [64][84]  the pose tile
+#ifdef PNDF_RING_ALIAS_F
+constexpr int LDS_F = LDS_Q;                                 // (timing-only arm of the margin curve, see PNDF_RING_SLOTS)
+#else
 constexpr int LDS_F = LDS_Q + WG_POSES * NQ * 4;             // float [64][FSTRIDE]  features, then d d / d feature,
+#endif
 constexpr int LDS_GN = LDS_F;                                //   then (same rows) d d / d n of the pose
 constexpr int LDS_TOTAL = LDS_F + WG_POSES * FSTRIDE * 4;
 static_assert(LDS_BIAS % 16 == 0 && LDS_MASK % 16 == 0 && LDS_Q % 16 == 0 && LDS_F % 16 == 0, "16-byte LDS carve");
@@ -66,7 +75,14 @@ struct Ring {
     int lane;
     uint32_t nfetch;       // (PNDF_ABLATE & 32 only) uniform: fetches issued so far in this step
     uint32_t lane_off;     // (PNDF_ABLATE & 32 only) per lane: this lane's byte offset inside a slot
+    // (PNDF_RING_STAMPS only: the instrumented kernels' translation units) what the ring's two synchronous events cost this wave:
+    unsigned long long st_wait, st_bar;   // shader cycles spent in the counted vmcnt wait / in the barrier, summed over the SAMPLED slots
+    uint32_t st_n, st_k;                  // sampled slots, all slots
 };
+#ifndef PNDF_RING_STAMPS
+#define PNDF_RING_STAMPS 0     // 1: every RING_STAMP_PERIOD-th mid-slot event is bracketed by s_memtime stamps (pndf_kernel*_timing.hip)
+#endif
+constexpr uint32_t RING_STAMP_PERIOD = 16;      // 670 slots per step: the sampled positions rotate from step to step
 
 // LDS-DMA of one 16 KiB slot: each wave moves 4 tiles (global_load_lds_dwordx4 = 1 KiB per instruction,
 // LDS destination = M0 + lane * 16).  Issued from inline asm on purpose: when hipcc sees the builtin it
@@ -136,9 +152,10 @@ __device__ __forceinline__ void ring_wait_dma() { asm volatile("s_waitcnt vmcnt(
 #ifndef PNDF_SP_DIAG
 #define PNDF_SP_DIAG 0
 #endif
+constexpr int RING_INFLIGHT = 4 * (RING_SLOTS - 3);      // pieces of the slots after the next one (product: 8)
 __device__ __forceinline__ void ring_wait_next_slot() {
     if (PNDF_SP_DIAG & 32) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // (timing diagnostic only: see pndf_kernel_split.hip)
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(RING_INFLIGHT) : "memory");
 }
 
 // slots 0..3 into buffers 0..3; the caller waits vmcnt(0) + barrier.  The first slot boundary makes buffer 0 current
@@ -147,6 +164,7 @@ __device__ __forceinline__ void ring_start(Ring& r, int wave) {
     r.dst_base = (uint32_t)(size_t)(PNDF_LDS char*)(r.smem + LDS_RING) + wave * (4 * TILE_BYTES);
     r.fetch_off = wave * (4 * TILE_BYTES) + r.lane * 16 - SLOT_BYTES;
     r.nfetch = 0;
+    r.st_k = 0;
     r.lane_off = wave * (4 * TILE_BYTES) + r.lane * 16;
     r.prev_off = 0;
 #pragma unroll
@@ -172,6 +190,21 @@ __device__ __forceinline__ void ring_boundary(Ring& r) {
 // wave's DMA share of the next slot has landed (its own counted vmcnt above), and every read of the previous slot
 // returned long ago (its data has been consumed by MFMAs issued before this point).
 __device__ __forceinline__ void ring_midslot_sync(Ring& r) {
+    if constexpr (PNDF_RING_STAMPS != 0) {
+        // Instrumented kernels: how long does this wave sit in the counted wait (= the slot's DMA had not landed: the ring's
+        // look-ahead did not cover the fetch latency) and in the barrier (= the other waves were not there yet)?  One asm
+        // statement, so that nothing is scheduled between the stamps; s_memtime returns through lgkmcnt, i.e. a sampled event
+        // also drains the tile prefetch -- hence every RING_STAMP_PERIOD-th event only.
+        if ((r.st_k++ % RING_STAMP_PERIOD) == 0) {
+            unsigned long long t0, t1, t2;
+            asm volatile("s_memtime %0\n\ts_waitcnt vmcnt(%3)\n\ts_memtime %1\n\ts_barrier\n\ts_memtime %2\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&s"(t0), "=&s"(t1), "=&s"(t2) : "n"(RING_INFLIGHT) : "memory");
+            r.st_wait += t1 - t0;
+            r.st_bar += t2 - t1;
+            r.st_n++;
+            return;
+        }
+    }
     if (!(PNDF_ABLATE & 4)) ring_wait_next_slot();
     if (!(PNDF_ABLATE & 1)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -418,12 +451,23 @@ constexpr int SP_WG_FLOATS = SP_SLOTS * WG_THREADS * 4;
 
 constexpr int TIMING_REGIONS = 12;
 constexpr int TIMING_GROUPS = 32;     // per-group stamps inside the (lin2,lin3) phase
+constexpr int TIMING_RING = 4;        // ring events (PNDF_RING_STAMPS): wait cycles, barrier cycles, sampled slots, cycles of two stamps back to back
 // s_memtime stamps at region boundaries (TIMING instantiation only): accumulates shader cycles per region
 struct RegionClock {
     unsigned long long acc[TIMING_REGIONS];
     unsigned long long grp[TIMING_GROUPS];
     unsigned long long last;
 };
+// the ring's sampled events of this wave -> out[0 .. TIMING_RING) (zeros from a kernel built without PNDF_RING_STAMPS)
+__device__ __forceinline__ void ring_stamps_out(const Ring& r, unsigned long long* out) {
+    unsigned long long a = 0, b = 0;
+    if constexpr (PNDF_RING_STAMPS != 0)      // what two stamps back to back measure: the floor of `st_wait / st_n`
+        asm volatile("s_memtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : : "memory");
+    out[0] = PNDF_RING_STAMPS ? r.st_wait : 0ull;
+    out[1] = PNDF_RING_STAMPS ? r.st_bar : 0ull;
+    out[2] = PNDF_RING_STAMPS ? (unsigned long long)r.st_n : 0ull;
+    out[3] = b - a;
+}
 template <bool TIMING>
 __device__ __forceinline__ void tick(RegionClock& rc, int region) {
     if constexpr (TIMING) {

@@ -255,6 +255,8 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     ring.gstream = args.stream;
     ring.smem = smem;
     ring.lane = lane;
+    ring.st_wait = ring.st_bar = 0;
+    ring.st_n = 0;
     // ---- stage the biases in LDS once (coalesced)
     for (int i = tid; i < BIAS_FLOATS / 4; i += WG_THREADS)
         ((f32x4*)lds_bias)[i] = ((const f32x4*)args.bias)[i];
@@ -469,11 +471,12 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     }
     if constexpr (TIMING) {
         if (lane == 0 && args.dbg) {
-            unsigned long long* out = (unsigned long long*)args.dbg + ((size_t)blockIdx.x * 4 + wave) * (TIMING_REGIONS + TIMING_GROUPS);
+            unsigned long long* out = (unsigned long long*)args.dbg + ((size_t)blockIdx.x * 4 + wave) * (TIMING_REGIONS + TIMING_GROUPS + TIMING_RING);
 #pragma unroll
             for (int i = 0; i < TIMING_REGIONS; ++i) out[i] = rc.acc[i];
 #pragma unroll
             for (int i = 0; i < TIMING_GROUPS; ++i) out[TIMING_REGIONS + i] = rc.grp[i];
+            ring_stamps_out(ring, out + TIMING_REGIONS + TIMING_GROUPS);
         }
     }
 
@@ -496,6 +499,14 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     }   // block loop
 }
 
+#ifdef PNDF_TIMING_TU
+// relu-family kernel with s_memtime region stamps (performance analysis only; its own translation unit,
+// pndf_kernel_timing.hip, with the ring's sampled event stamps compiled in: pndf_device.h PNDF_RING_STAMPS)
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1)
+pndf_fused_relu_kernel_timing(PndfKernelArgs args) {
+    pndf_fused_body<false, false, true>(args);
+}
+#else
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1)
 pndf_fused_relu_kernel(PndfKernelArgs args) {
     pndf_fused_body<false, false>(args);
@@ -513,13 +524,9 @@ pndf_fused_relu_kernel_dbg(PndfKernelArgs args) {
     pndf_fused_body<true, false>(args);
 }
 
-// relu-family kernel with s_memtime region stamps (performance analysis only)
-extern "C" __global__ void __launch_bounds__(WG_THREADS, 1)
-pndf_fused_relu_kernel_timing(PndfKernelArgs args) {
-    pndf_fused_body<false, false, true>(args);
-}
-
-extern "C" int pndf_kernel_timing_regions() { return TIMING_REGIONS + TIMING_GROUPS; }
+extern "C" int pndf_kernel_timing_regions() { return TIMING_REGIONS + TIMING_GROUPS + TIMING_RING; }
+extern "C" int pndf_kernel_timing_layout(int what) { return what == 0 ? TIMING_REGIONS : what == 1 ? TIMING_GROUPS : what == 2 ? TIMING_RING : what == 3 ? (int)RING_STAMP_PERIOD : RING_SLOTS; }
 extern "C" int pndf_kernel_lds_bytes() { return LDS_TOTAL; }
 extern "C" int pndf_kernel_dbg_floats() { return DBG_TOTAL * WG_THREADS; }
 extern "C" long long pndf_kernel_softplus_scratch_floats_per_wg() { return SP_WG_FLOATS; }
+#endif

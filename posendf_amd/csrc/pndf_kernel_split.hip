@@ -887,6 +887,8 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
     ring.gstream = args.stream;
     ring.smem = smem;
     ring.lane = lane;
+    ring.st_wait = ring.st_bar = 0;
+    ring.st_n = 0;
     // ---- stage the biases in LDS once (coalesced)
     for (int i = tid; i < BIAS_FLOATS / 4; i += WG_THREADS)
         ((f32x4*)lds_bias)[i] = ((const f32x4*)args.bias)[i];
@@ -1130,11 +1132,12 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
     }
     if constexpr (TIMING) {
         if (lane == 0 && args.dbg) {
-            unsigned long long* out = (unsigned long long*)args.dbg + ((size_t)blockIdx.x * 4 + wave) * (TIMING_REGIONS + TIMING_GROUPS);
+            unsigned long long* out = (unsigned long long*)args.dbg + ((size_t)blockIdx.x * 4 + wave) * (TIMING_REGIONS + TIMING_GROUPS + TIMING_RING);
 #pragma unroll
             for (int i = 0; i < TIMING_REGIONS; ++i) out[i] = rc.acc[i];
 #pragma unroll
             for (int i = 0; i < TIMING_GROUPS; ++i) out[TIMING_REGIONS + i] = rc.grp[i];
+            ring_stamps_out(ring, out + TIMING_REGIONS + TIMING_GROUPS);
         }
     }
 
@@ -1155,14 +1158,22 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
     }   // block loop
 }
 
-#ifndef PNDF_SPLIT_X2_TU
-extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_relu_kernel(PndfKernelArgs args) {
-    pndf_fused_split_body<false, 3>(args);
-}
-
-// split-precision kernel with s_memtime region stamps (performance analysis only)
+#if defined(PNDF_SPLIT_TIMING_TU)
+// Instrumented kernels (performance analysis only; compiled as their own translation unit, pndf_kernel_split_timing.hip,
+// with PNDF_RING_STAMPS = 1): s_memtime stamps at the region boundaries of a step and around a sample of the ring's
+// synchronous events (pndf_device.h: ring_midslot_sync).
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_relu_kernel_timing(PndfKernelArgs args) {
     pndf_fused_split_body<true, 3>(args);
+}
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_softplus_kernel_timing(PndfKernelArgs args) {
+    pndf_fused_split_body<true, 3, true>(args);
+}
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_half_relu_kernel_timing(PndfKernelArgs args) {
+    pndf_fused_split_body<true, 3 - 2>(args);
+}
+#elif !defined(PNDF_SPLIT_X2_TU)
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_relu_kernel(PndfKernelArgs args) {
+    pndf_fused_split_body<false, 3>(args);
 }
 
 // Softplus(beta) on the split path (the reference's experiment scripts default to softplus checkpoints,
@@ -1171,18 +1182,10 @@ extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_sof
     pndf_fused_split_body<false, 3, true>(args);
 }
 
-// the same with s_memtime region stamps (performance analysis only)
-extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_softplus_kernel_timing(PndfKernelArgs args) {
-    pndf_fused_split_body<true, 3, true>(args);
-}
-
 // plain-fp16 kernel (precision "f16"): one MFMA per product block, operands rounded to fp16 -- a measured comparison
 // point (BASELINE.json configs[2] "fp32 vs bf16"), NOT within the 1e-4 parity bar
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_half_relu_kernel(PndfKernelArgs args) {
     pndf_fused_split_body<false, 1>(args);
-}
-extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_half_relu_kernel_timing(PndfKernelArgs args) {
-    pndf_fused_split_body<true, 3 - 2>(args);
 }
 #else
 // Two-term variants (compiled as their own translation unit, pndf_kernel_split_x2.hip): the split kernels for networks

@@ -1,0 +1,101 @@
+// Memory-subsystem probe of the box the engine runs on (measurement aid behind bench.py's `box` block):
+// the fused kernels stream their 11 MB of weights through L2 -> LDS every step, so two boxes can only be compared with the
+// latencies of the levels that stream crosses beside the kernel time.
+//   dependent-load latency (one lane, one 128-byte line per hop, full-period LCG walk) with the walked footprint
+//     1 MiB   -> resident in the XCD's 4 MB L2          (what 31 of 32 compute units of an XCD see of the weight stream)
+//     64 MiB  -> resident in the 256 MB Infinity Cache  (what the first one sees: an L2 miss served over the fabric)
+//     1 GiB   -> HBM (incl. the translation misses of a random walk)
+//   streaming read bandwidth of a 1 GiB buffer (all compute units, 16 B per lane)
+// Everything is allocated, measured and freed inside the call; it synchronises the device.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pndf_host.h"
+
+namespace {
+
+constexpr int LINE_WORDS = 32;                       // one hop per 128-byte line
+
+// next(i) = (a i + c) mod n, n a power of two, a = 1 (mod 4), c odd: one cycle through all n lines
+__global__ void probe_fill(uint32_t* buf, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) buf[(size_t)i * LINE_WORDS] = (i * 1664525u + 1013904223u) & (n - 1);
+}
+
+__global__ void probe_chase(const uint32_t* buf, int hops, unsigned long long* ticks, uint32_t* sink) {
+    if (threadIdx.x != 0) return;
+    uint32_t i = 0;
+    for (int k = 0; k < 64; ++k) {                   // settle (clock ramp, first translations)
+        i = buf[(size_t)i * LINE_WORDS];
+        asm volatile("" : "+v"(i));
+    }
+    const unsigned long long t0 = wall_clock64();
+    for (int k = 0; k < hops; ++k) {
+        i = buf[(size_t)i * LINE_WORDS];
+        asm volatile("" : "+v"(i));                  // a dependent chain the compiler cannot collapse
+    }
+    const unsigned long long t1 = wall_clock64();
+    *ticks = t1 - t0;
+    *sink = i;
+}
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) probe_stream(const f4* src, size_t n, float* sink) {
+    f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        acc += src[i];
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) *sink = acc.x;      // (never true: keeps the loads)
+}
+
+}  // namespace
+
+// out[0..2] = dependent-load latency in ns at the three footprints, out[3] = streaming read GB/s, out[4] = wall-clock
+// counter rate in MHz, out[5] = hops timed per footprint.  Returns 0 or a negative pndf_status.
+extern "C" int pndf_debug_mem_probe(int device, double* out, int n_out) {
+    if (!out || n_out < 6) return -1;
+    DeviceGuard guard(device);
+    if (!guard.ok) return -3;
+    int rate_khz = 0;
+    if (hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || rate_khz <= 0) rate_khz = 100000;
+    const size_t bytes = (size_t)1 << 30;
+    uint32_t* buf = nullptr;
+    unsigned long long* ticks = nullptr;
+    uint32_t* sink = nullptr;
+    if (hipMalloc((void**)&buf, bytes) != hipSuccess) return -3;
+    int rc = 0;
+    if (hipMalloc((void**)&ticks, 64) != hipSuccess || hipMalloc((void**)&sink, 64) != hipSuccess) rc = -3;
+    const int hops = 4096;
+    const size_t foot[3] = {(size_t)1 << 20, (size_t)64 << 20, bytes};
+    for (int f = 0; f < 3 && rc == 0; ++f) {
+        const uint32_t n = (uint32_t)(foot[f] / (LINE_WORDS * 4));
+        hipLaunchKernelGGL(probe_fill, dim3((n + 255) / 256), dim3(256), 0, 0, buf, n);
+        // bring the footprint into the level it fits in: two streaming passes over it (the 1 GiB one fits in none)
+        for (int pass = 0; pass < 2; ++pass)
+            hipLaunchKernelGGL(probe_stream, dim3(1024), dim3(256), 0, 0, (const f4*)buf, foot[f] / 16, (float*)sink);
+        hipLaunchKernelGGL(probe_chase, dim3(1), dim3(64), 0, 0, buf, hops, ticks, sink);
+        unsigned long long t = 0;
+        if (hipMemcpy(&t, ticks, sizeof(t), hipMemcpyDeviceToHost) != hipSuccess) { rc = -3; break; }
+        out[f] = (double)t / hops * 1e6 / rate_khz;      // ticks per hop -> ns
+    }
+    if (rc == 0) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        hipLaunchKernelGGL(probe_stream, dim3(2048), dim3(256), 0, 0, (const f4*)buf, bytes / 16, (float*)sink);
+        (void)hipEventRecord(e0, 0);
+        for (int r = 0; r < 3; ++r)
+            hipLaunchKernelGGL(probe_stream, dim3(2048), dim3(256), 0, 0, (const f4*)buf, bytes / 16, (float*)sink);
+        (void)hipEventRecord(e1, 0);
+        float ms = 0.f;
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) rc = -3;
+        else out[3] = 3.0 * (double)bytes / (ms * 1e-3) / 1e9;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    out[4] = rate_khz / 1e3;
+    out[5] = hops;
+    if (sink) (void)hipFree(sink);
+    if (ticks) (void)hipFree(ticks);
+    (void)hipFree(buf);
+    return rc;
+}

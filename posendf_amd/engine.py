@@ -60,6 +60,10 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.pndf_debug_project_timing.argtypes = [H, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]
     lib.pndf_debug_project_timing.restype = c_int
     lib.pndf_debug_timing_regions.restype = c_int
+    lib.pndf_debug_timing_layout.argtypes = [c_int]
+    lib.pndf_debug_timing_layout.restype = c_int
+    lib.pndf_debug_mem_probe.argtypes = [c_int, c_void_p, c_int]
+    lib.pndf_debug_mem_probe.restype = c_int
     lib.pndf_packed_sizes.argtypes = [POINTER(c_int64)] * 2
     lib.pndf_packed_sizes.restype = None
     lib.pndf_pack_host.argtypes = [POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p, c_void_p]
@@ -132,7 +136,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
 
 EXPORTS = ("pndf_default_config", "pndf_create", "pndf_destroy", "pndf_load_weights", "pndf_forward",
            "pndf_forward_grad", "pndf_project", "pndf_debug_forward_grad", "pndf_debug_floats",
-           "pndf_debug_project_timing", "pndf_debug_timing_regions",
+           "pndf_debug_project_timing", "pndf_debug_timing_regions", "pndf_debug_timing_layout", "pndf_debug_mem_probe",
            "pndf_packed_sizes", "pndf_pack_host", "pndf_pack_host_split", "pndf_aa2quat", "pndf_denoise_update", "pndf_denoise_update_body", "pndf_denoise_update_w", "pndf_lbs_terms_grad_w", "pndf_quat_topk",
            "pndf_lbs_create", "pndf_lbs_destroy", "pndf_lbs_set_precision", "pndf_lbs_precision", "pndf_lbs_num_joints", "pndf_lbs_num_vertices", "pndf_lbs_workspace_floats",
            "pndf_lbs_forward", "pndf_lbs_terms_grad", "pndf_lbs_backward", "pndf_lbs_packed_floats", "pndf_lbs_pack_host", "pndf_lbs_packed_split_bytes", "pndf_lbs_pack_split_host",
@@ -232,6 +236,46 @@ class Engine:
 
     def debug_floats(self):
         return int(self.lib.pndf_debug_floats())
+
+    REGION_NAMES = ("enc fwd + x0", "P1 lin0,lin1", "act x2", "P2 lin2,lin3", "act x4", "P3 lin4,lin5", "act x6+lin6+g6",
+                    "P4 lin5T,lin4T +dact", "P5 lin3T,lin2T +dact", "P6 lin1T,lin0T", "enc bwd", "norm bwd+update+sync")
+
+    def project_timing(self, q, steps=3, out=None):
+        """pndf_debug_project_timing on a CUDA tensor of poses: the instrumented kernel's per-region shader cycles of one
+        step (mean over waves), the effective shader clock, and the weight ring's sampled events -- how long a wave sits in
+        the ring's counted wait (the slot's DMA had not landed) and in its barrier, per slot."""
+        import torch
+        B = int(q.shape[0])
+        R = int(self.lib.pndf_debug_timing_regions())
+        nreg, ngrp, nring, period, slots = (int(self.lib.pndf_debug_timing_layout(i)) for i in range(5))
+        cyc = torch.zeros((-(-B // 64)) * 4 * R, dtype=torch.int64, device=q.device)
+        out = torch.empty_like(q) if out is None else out
+        st = torch.cuda.current_stream(q.device).cuda_stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._check(self.lib.pndf_debug_project_timing(self.handle, q.data_ptr(), out.data_ptr(), B, int(steps), cyc.data_ptr(), st),
+                    "pndf_debug_project_timing")
+        e1.record()
+        torch.cuda.synchronize(q.device)
+        ms = e0.elapsed_time(e1)
+        rows = cyc.cpu().numpy().reshape(-1, R).astype(np.float64)
+        reg = rows[:, :nreg].copy()
+        reg[:, 3] += rows[:, nreg:nreg + ngrp].sum(1)       # per-group stamps (if built in) take their time out of region 3
+        per_step = reg.mean(0) / steps
+        ring = rows[:, nreg + ngrp:nreg + ngrp + nring]
+        n = max(ring[:, 2].sum(), 1.0)
+        cus = torch.cuda.get_device_properties(q.device).multi_processor_count
+        rounds = -(-(-(-B // 64)) // cus)
+        total = float(per_step.sum())
+        return {"steps": int(steps), "launch_ms": ms, "workgroup_rounds": rounds,
+                "cycles_per_wave_step": total,
+                "effective_sclk_ghz": reg.sum(1).mean() * rounds / (ms * 1e-3) / 1e9,
+                "regions": {name: float(c) for name, c in zip(self.REGION_NAMES, per_step)},
+                "ring": {"look_ahead_slots": slots - 1, "sampled_every": period, "sampled_slots_per_wave": float(ring[:, 2].mean()),
+                         "wait_cycles_per_slot": float(ring[:, 0].sum() / n), "barrier_cycles_per_slot": float(ring[:, 1].sum() / n),
+                         "stamp_floor_cycles": float(ring[:, 3].mean()),
+                         "wait_cycles_per_slot_p99_wave": float(np.percentile(ring[:, 0] / np.maximum(ring[:, 2], 1), 99))},
+                "spread_over_waves": [float(reg.sum(1).min() / steps), float(reg.sum(1).max() / steps)]}
 
     def close(self):
         if getattr(self, "handle", None):

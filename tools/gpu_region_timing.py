@@ -64,6 +64,16 @@ def main():
         print("  part A(c+1):", " ".join(f"{v:5.0f}" for v in grp[:8]))
         print("  part B(c)  :", " ".join(f"{v:5.0f}" for v in grp[8:16]))
     print("spread over waves (min/max of total):", c.sum(1).min(), c.sum(1).max())
+    # the weight ring's two synchronous events, sampled (pndf_device.h: ring_midslot_sync, PNDF_RING_STAMPS)
+    nreg, ngrp, nring, period, slots = (int(eng.lib.pndf_debug_timing_layout(i)) for i in range(5))
+    ring = cyc.cpu().numpy().reshape(-1, R).astype(np.float64)[:, nreg + ngrp:nreg + ngrp + nring]
+    n = max(ring[:, 2].sum(), 1.0)
+    per_wave = ring[:, 0] / np.maximum(ring[:, 2], 1)
+    print(f"ring (look-ahead {slots - 1} slots; every {period}th slot sampled, {ring[:, 2].mean():.0f} samples per wave): counted vmcnt wait "
+          f"{ring[:, 0].sum() / n:6.1f} cycles per slot (two stamps back to back: {ring[:, 3].mean():.0f}), barrier {ring[:, 1].sum() / n:6.1f} "
+          f"cycles per slot; per-wave wait p50 / p99 / max {np.percentile(per_wave, 50):.0f} / {np.percentile(per_wave, 99):.0f} / {per_wave.max():.0f}")
+    print(f"  -> of the {tot:,.0f} cycles of a step, {670 * (ring[:, 0].sum() / n - ring[:, 3].mean()):,.0f} are spent waiting for a slot's DMA "
+          f"and {670 * ring[:, 1].sum() / n:,.0f} in the ring's barrier (670 slots per step)")
 
 
 if __name__ == "__main__":
