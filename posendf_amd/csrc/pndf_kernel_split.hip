@@ -191,25 +191,31 @@ __device__ __forceinline__ void dma_begin(DmaPieces& d, Ring& ring, bool loaded)
 #ifndef PNDF_NT_MODE
 #define PNDF_NT_MODE 0      // cache-policy experiments: 1 = `nt` on the two big phases' slot fetches, 2 = on every slot fetch
 #endif
-#define PNDF_DMA_VARIANTS(POLICY)                                                                                        \
-    if constexpr (TN == SLOT_TILES / 2 && !SECOND)                                                                       \
+#ifndef PNDF_DMA_EARLY
+#define PNDF_DMA_EARLY 0    // where the four 1-KiB pieces of a slot fetch are issued (round 5, profiles/r05/ring_margin.txt):
+#endif                      // 0 = behind MFMAs 9, 11 of the group that ran the mid-slot events and of the next one (rounds 1-4: the last
+                            //     piece leaves ~0.95 slot after the barrier, i.e. has ~2 slot times to land);
+                            // 1 = all four in the group of the barrier, behind its MFMAs 8..11 (no tile read shares those slots);
+                            // 2 = all four right behind the barrier, MFMAs 1..4 (each next to a tile read)
+#define PNDF_DMA_PIECE(POLICY)                                                                                           \
+    if constexpr (PIECE == 0)                                                                                            \
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" POLICY                              \
                      : : "v"(d.src.off), "s"(d.src.base), "s"(d.dst) : "memory", "m0");                                  \
-    else if constexpr (TN == SLOT_TILES / 2 && SECOND)                                                                   \
+    else if constexpr (PIECE == 1)                                                                                       \
         asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" POLICY : : "v"(d.src.off), "s"(d.src.base) : "memory"); \
-    else if constexpr (TN == 0 && !SECOND)                                                                               \
+    else if constexpr (PIECE == 2)                                                                                       \
         asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" POLICY : : "v"(d.src.off), "s"(d.src.base) : "memory"); \
     else                                                                                                                 \
         asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" POLICY : : "v"(d.src.off), "s"(d.src.base) : "memory");
-template <int TN, bool SECOND, bool BIG = false>
-__device__ __forceinline__ void dma_step(const DmaPieces& d) {
+template <int PIECE, bool BIG = false>
+__device__ __forceinline__ void dma_piece(const DmaPieces& d) {
     if (PNDF_ABLATE & 2) return;
     if constexpr (PNDF_NT_MODE == 2 || (PNDF_NT_MODE == 1 && BIG)) {
-        PNDF_DMA_VARIANTS(" nt")
+        PNDF_DMA_PIECE(" nt")
     } else {
-        PNDF_DMA_VARIANTS("")
+        PNDF_DMA_PIECE("")
         if constexpr ((PNDF_ABLATE & 512) != 0) {          // (additive energy experiment: every slot fetch issued twice)
-            PNDF_DMA_VARIANTS("")
+            PNDF_DMA_PIECE("")
         }
     }
 }
@@ -245,8 +251,17 @@ __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, 
         if (PNDF_ABLATE & 16) nxt[J - 4].l = nxt[J - 4].h;      // (energy-model experiment: no LDS read of the lo tiles)
         else if (loaded) nxt[J - 4].l = __builtin_bit_cast(f16x8, ring_tile(ring, TN + 2 * (J - 4) + 1));
     }
-    if constexpr (J == DMA0 || J == DMA1) {
-        if (TN == 0 || loaded) dma_step<TN, J == DMA1, BIG>(dp);
+    if constexpr (PNDF_DMA_EARLY == 0) {
+        // pieces 0, 1 in the group that ran the mid-slot events (TN == 8), pieces 2, 3 in the next one (TN == 0, same phase by
+        // construction: a phase starts on a slot boundary and fetches are only begun when a next group exists)
+        if constexpr (J == DMA0 || J == DMA1) {
+            if (TN == 0 || loaded) dma_piece<(TN == 0 ? 2 : 0) + (J == DMA1 ? 1 : 0), BIG>(dp);
+        }
+    } else {
+        constexpr int J0 = (PNDF_DMA_EARLY == 1) ? 4 * NT - 4 : 1;
+        if constexpr (TN == SLOT_TILES / 2 && J >= J0 && J < J0 + 4) {
+            if (loaded) dma_piece<J - J0, BIG>(dp);
+        }
     }
 }
 

@@ -195,8 +195,11 @@ class MotionDenoise:
         self.last_poses = out.reshape(noisy.shape)
         ref = noisy if gt_poses is None else gt_poses.to(self.device, torch.float32)
         with torch.no_grad():
-            def verts(p):
-                res = self.body_model(pose_body=p.reshape(-1, 69))
+            def verts(p):      # the same two calling conventions as _geometry: keyword for BodyModel, positional for a plain callable
+                flat = p.reshape(-1, 69)
+                if isinstance(self.body_model, BodyModel):
+                    return self.body_model(pose_body=flat).vertices
+                res = self.body_model(flat)
                 return res.vertices if hasattr(res, "vertices") else res[0]
             d = verts(self.last_poses) - verts(ref)
             v2v = torch.mean(torch.sqrt(torch.sum(d * d, dim=2))) * 100.0                # :118

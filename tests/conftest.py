@@ -171,13 +171,22 @@ def escalated_noise(q, sd, act, idx, truth, draws=32, seed=11, steps=0, kind="g"
         qk = (q[idx] * (1 + rng.uniform(-2.0 ** -23, 2.0 ** -23, q[idx].shape))).astype(np.float32)
         sdk = {k: (v * (1 + rng.uniform(-2.0 ** -23, 2.0 ** -23, v.shape))).astype(np.float32) for k, v in sd.items()}
         if steps > 0:
-            out, _ = onp.project(qk, sdk, steps=steps, act=act)
+            out, _ = onp.project(qk, sdk, steps=steps, act=act, dtype=np.float32)      # the reference's arithmetic, explicitly
         else:
             d32, g32 = onp.forward_grad(qk, sdk, act, dtype=np.float32)
             out = d32 if kind == "d" else g32
         num = np.abs(np.asarray(out, np.float64).reshape(len(idx), -1) - t_rows[idx]).max(axis=1)
         worst = np.maximum(worst, num / den)
     return worst
+
+
+ESCALATIONS = []      # every pose a gate excused through `escalate` (counted, printed at the end of the session)
+
+
+def pytest_terminal_summary(terminalreporter):
+    expl = [e for e in ESCALATIONS if e[3]]
+    terminalreporter.write_line(f"[escalations] {len(ESCALATIONS)} pose(s) went through the escalated envelope, {len(expl)} explained by it: "
+                                + "; ".join(f"{w} pose {i} err {e:.2e}" for w, i, e, _ in ESCALATIONS[:12]))
 
 
 def pose_gate(err, sigma, what="", factor=8.0, floor=8e-6, exempt=None, tol=1e-4, escalate=None):
@@ -199,6 +208,7 @@ def pose_gate(err, sigma, what="", factor=8.0, floor=8e-6, exempt=None, tol=1e-4
         print(f"[pose_gate {what}] escalated {idx.tolist()}: error {err[idx].tolist()} cheap sigma {sigma[idx].tolist()} "
               f"-> worst of the escalated reference evaluations {s2.tolist()}: {'FAIL' if still.any() else 'explained'}")
         bad[idx] = still
+        ESCALATIONS.extend((f"pose_gate {what}", int(i), float(err[i]), not bool(st)) for i, st in zip(idx, still))
     assert not bad.any(), (what, int(bad.sum()), np.flatnonzero(bad)[:8].tolist(), err[bad][:8].tolist(),
                            sigma[bad][:8].tolist())
     assert np.median(err) <= max(tol / 10, factor * float(np.median(sigma))), (what, float(np.median(err)))
@@ -256,6 +266,7 @@ def outlier_gate(mine_rows, ref_rows, tol=1e-4, what="", ratio=2.0, margin=None,
         print(f"[gate {what}] escalated {idx.tolist()}: error {mine_rows[idx].tolist()} -> worst of the escalated reference "
               f"evaluations {s2.tolist()}: {'FAIL' if still.any() else 'explained'}")
         unexplained[idx] = still
+        ESCALATIONS.extend((f"gate {what}", int(i), float(mine_rows[i]), not bool(st)) for i, st in zip(idx, still))
         by_sigma = by_sigma.copy()
         by_sigma[idx[~still]] = True
     assert not unexplained.any(), (what, "outliers that neither the reference's fp32 error nor a kink explains",

@@ -276,6 +276,11 @@ def test_constructor_and_argument_hardening(tmp_path):
         bm(pose_body=pose, betas=zeros)
     with pytest.raises(PndfError):
         bm(pose_body=pose, betas=torch.ones(1, 10, device="cuda"))
+    # a TEMPORARY zero tensor, then a fresh tensor that the caching allocator puts at the same address (same shape, version 0):
+    # the validated tensor is remembered by identity, not by address
+    bm(pose_body=pose, betas=torch.zeros(1, 10, device="cuda"))
+    with pytest.raises(PndfError):
+        bm(pose_body=pose, betas=torch.ones(1, 10, device="cuda"))
     # terms_grad: inputs are coerced, a wrong output buffer or shape is refused
     th_t = torch.from_numpy(th).cuda()
     j0 = bm.joints_of(th_t + 0.02)

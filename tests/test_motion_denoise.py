@@ -251,6 +251,19 @@ def test_body_model_terms_are_pluggable(precision):
         MotionDenoise(net, body_model=_LinearBlendBody("cuda:0"), device="cuda:0").denoise(noisy, fused=True)
 
 
+def test_optimize_calls_a_plain_callable_positionally():
+    """optimize() must call a user's body model the way _geometry does: positionally -- a callable whose
+    parameter is not named `pose_body` used to run the whole optimisation and then fail in the final v2v computation."""
+    from posendf_amd.motion_denoise import MotionDenoise
+    inner = _LinearBlendBody("cpu")
+
+    def body(theta):                                     # positional, another parameter name
+        return inner(theta)
+    md = MotionDenoise(_OraclePrior("lrelu", golden_weights("live")), body_model=body, device="cpu")
+    v2v = md.optimize(_noisy_sequences(1, 6, seed=4)[0], iterations=1, steps_per_iter=2)
+    assert v2v.shape == () and np.isfinite(v2v) and v2v >= 0
+
+
 def test_body_model_hook_cpu():
     """The body-model plumbing itself, without a GPU: gradients of the vertex / joint terms reach the poses."""
     from posendf_amd.motion_denoise import MotionDenoise
