@@ -180,10 +180,9 @@ template <int T0>
 __device__ __forceinline__ void dma_begin(DmaPieces& d, Ring& ring, bool loaded) {
     if (group_has_mid<8, T0>() && loaded) ring_dma_begin(ring, d.src, d.dst);
 }
-// The four pieces of a slot fetch are spread over the two tile groups that follow the barrier: pieces 0, 1 in the
-// group that ran the mid-slot events (TN == 8), pieces 2, 3 in the next one (TN == 0, same phase by construction:
-// a phase starts on a slot boundary and fetches are only begun when a next group exists).  Each group sets M0 for
-// its first piece; the second one, two MFMAs later, reuses it (M0: see ring_dma_piece).
+// The four pieces of a slot fetch are dealt out behind MFMAs of the tile group that ran the mid-slot events (TN == 8; rounds
+// 1 - 4: two there, two in the next group -- PNDF_DMA_EARLY below).  The first piece sets M0, the others reuse it (M0: see
+// ring_dma_piece; tools/isa_hazards.py checks that nothing else writes it).
 #ifndef PNDF_GROUP_STAMPS
 #define PNDF_GROUP_STAMPS 0   // 1: the instrumented kernel also stamps every group of the (lin2,lin3) loop.  s_memtime returns
 #endif                        // through lgkmcnt, so every stamp drains the tile prefetch: the groups then take ~1,100 cycles
@@ -192,11 +191,16 @@ __device__ __forceinline__ void dma_begin(DmaPieces& d, Ring& ring, bool loaded)
 #define PNDF_NT_MODE 0      // cache-policy experiments: 1 = `nt` on the two big phases' slot fetches, 2 = on every slot fetch
 #endif
 #ifndef PNDF_DMA_EARLY
-#define PNDF_DMA_EARLY 0    // where the four 1-KiB pieces of a slot fetch are issued (round 5, profiles/r05/ring_margin.txt):
+#define PNDF_DMA_EARLY 3    // where the four 1-KiB pieces of a slot fetch are issued (round 5, profiles/r05/ring_margin.txt):
 #endif                      // 0 = behind MFMAs 9, 11 of the group that ran the mid-slot events and of the next one (rounds 1-4: the last
                             //     piece leaves ~0.95 slot after the barrier, i.e. has ~2 slot times to land);
                             // 1 = all four in the group of the barrier, behind its MFMAs 8..11 (no tile read shares those slots);
                             // 2 = all four right behind the barrier, MFMAs 1..4 (each next to a tile read)
+                            // 3 = behind MFMAs 1, 3, 5, 7 of the barrier's group (PRODUCT since round 5: the last piece leaves a third of
+                            //     a slot after the barrier instead of a whole one -- +0.4 % on a box whose L2 / fabric latency fits under
+                            //     the old placement, but the kernel then loses 0.7 % instead of 4 - 11 % when a slot of look-ahead is
+                            //     taken away, i.e. it tolerates ~150 ns more fetch latency);
+                            // 4 = behind MFMAs 2, 5, 8, 11 (two-term kernels: as 3);  5 = behind MFMAs 5, 7, 9, 11 (two-term: 1, 3, 5, 7)
 #define PNDF_DMA_PIECE(POLICY)                                                                                           \
     if constexpr (PIECE == 0)                                                                                            \
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" POLICY                              \
@@ -223,7 +227,7 @@ __device__ __forceinline__ void dma_piece(const DmaPieces& d) {
 // What follows MFMA J (0..11) of a group, for the group after it (first tile TN of its slot):
 //   J = 0      ring events of the next group (slot boundary / mid-slot wait + barrier + fetch set-up)
 //   J = 0..3   its four hi tiles, J = 4..7 its four lo tiles (needed only by that group's MFMAs 8..11)
-//   J = 9, 11  one DMA piece each: the four pieces of a slot fetch are spread over the two groups after the barrier
+//   J = 1, 3, 5, 7 of the group that ran the mid-slot events: one DMA piece each (PNDF_DMA_EARLY)
 // One LDS read per MFMA instead of a burst of eight: right after the workgroup barrier all four waves used to issue
 // their bursts at once and sat in the LDS queue with an empty MFMA pipe (tools/ubench/split_rate.hip: barrier cost
 // 150 -> 33 cycles per slot).
@@ -258,9 +262,11 @@ __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, 
             if (TN == 0 || loaded) dma_piece<(TN == 0 ? 2 : 0) + (J == DMA1 ? 1 : 0), BIG>(dp);
         }
     } else {
-        constexpr int J0 = (PNDF_DMA_EARLY == 1) ? 4 * NT - 4 : 1;
-        if constexpr (TN == SLOT_TILES / 2 && J >= J0 && J < J0 + 4) {
-            if (loaded) dma_piece<J - J0, BIG>(dp);
+        // all four pieces in the group of the barrier, behind its MFMAs J0, J0 + DJ, J0 + 2 DJ, J0 + 3 DJ
+        constexpr int J0 = (PNDF_DMA_EARLY == 1) ? 4 * NT - 4 : (PNDF_DMA_EARLY == 4 && NT == 3) ? 2 : (PNDF_DMA_EARLY == 5 && NT == 3) ? 5 : 1;
+        constexpr int DJ = (PNDF_DMA_EARLY <= 2) ? 1 : (PNDF_DMA_EARLY == 4 && NT == 3) ? 3 : 2;
+        if constexpr (TN == SLOT_TILES / 2 && J >= J0 && (J - J0) % DJ == 0 && (J - J0) / DJ < 4) {
+            if (loaded) dma_piece<(J - J0) / DJ, BIG>(dp);
         }
     }
 }

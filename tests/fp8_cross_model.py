@@ -49,8 +49,20 @@ def _q8_blocks(a, block, axis):
     return np.moveaxis(out, -1, axis)
 
 
+def q_i8(a, axis, tie=None):
+    """round to nearest int8 fixed point, one power-of-two scale per row (axis = 1: per output row of W / per pose of x) with
+    the largest |value| in [64, 128); `tie` = (scale of the matching hi operand, shift): the scale is that one x 2^shift instead
+    (the combined K = 64 instruction accumulates Wh xl and Wl xh in ONE int32, so scale(Wh) scale(xl) = scale(Wl) scale(xh))."""
+    a = np.asarray(a, np.float64)
+    s = _pow2_scale(a, 128.0, axis=axis) if tie is None else tie[0] * 2.0 ** tie[1]
+    return np.clip(np.round(a * s), -127, 127) / s, s
+
+
 def split_matmul(x, W, mode, block=32):
-    """x [B,K] @ W[N,K]^T under the emulated arithmetic.  mode: 'f16x3' (product), 'f16f8' (cross terms on fp8)."""
+    """x [B,K] @ W[N,K]^T under the emulated arithmetic.  mode: 'f16x3' (product), 'f16f8' (cross terms on fp8),
+    'f16i8' (cross terms on int8, every operand with its own per-row / per-pose scale: two v_mfma_i32_16x16x64_i8 with
+    separate int32 accumulators), 'f16i8c' (the ONE-instruction form of VERDICT r4 item 2: [Wh | Wl] . [xl ; xh], K = 64, lo
+    scales tied to the hi scales by 2^10 so that both products share one int32 scale)."""
     sw = _pow2_scale(W, 2.0 ** 13)                                # per layer
     sx = _pow2_scale(x, 2.0 ** 14, axis=1)                        # per pose
     Wh, Wl = _split16(W * sw)
@@ -58,6 +70,12 @@ def split_matmul(x, W, mode, block=32):
     acc = (xh @ Wh.T).astype(np.float32).astype(np.float64)
     if mode == "f16x3":
         acc = acc + xl @ Wh.T + xh @ Wl.T
+    elif mode in ("f16i8", "f16i8c"):
+        Wh8, s_wh = q_i8(Wh, 1)
+        xh8, s_xh = q_i8(xh, 1)
+        Wl8, _ = q_i8(Wl, 1, (s_wh, 10) if mode == "f16i8c" else None)
+        xl8, _ = q_i8(xl, 1, (s_xh, 10) if mode == "f16i8c" else None)
+        acc = acc + (xl8 @ Wh8.T + xh8 @ Wl8.T)             # exact in int32 (|sum| < 2^31: 1,024 terms of < 2^14)
     else:
         acc = acc + _q8_blocks(xl, block, 1) @ _q8_blocks(Wh, block, 1).T + _q8_blocks(xh, block, 1) @ _q8_blocks(Wl, block, 1).T
     return (acc.astype(np.float32).astype(np.float64) / sx) / sw
