@@ -299,6 +299,74 @@ def box_block(dev_index, lib):
     return out
 
 
+def _amdsmi_metric():
+    """One `amd-smi metric --json` reading of the visible device: the firmware's lifetime accumulators (energy, throttler
+    residencies at ~1 kHz) and the instantaneous power / clock / temperatures.  None when the tool is missing or fails."""
+    import subprocess
+    try:
+        out = subprocess.run(["amd-smi", "metric", "--json"], capture_output=True, text=True, timeout=40).stdout
+        g = json.loads(out[out.index("{"):])
+        g = (g.get("gpu_data") or [g])[0] if isinstance(g, dict) else g[0]
+        thr = g.get("throttle") or {}
+
+        def val(x):
+            return x.get("value") if isinstance(x, dict) else x
+        num = lambda x: float(x) if isinstance(x, (int, float)) else None      # noqa: E731
+        return {"energy_j": num(val((g.get("energy") or {}).get("total_energy_consumption"))),
+                "acc": num(thr.get("accumulation_counter")), "ppt": num(thr.get("ppt_accumulated")),
+                "prochot": num(thr.get("prochot_accumulated")), "socket_thm": num(thr.get("socket_thermal_accumulated")),
+                "vr_thm": num(thr.get("vr_thermal_accumulated")), "hbm_thm": num(thr.get("hbm_thermal_accumulated")),
+                "socket_power_w": num(val((g.get("power") or {}).get("socket_power"))),
+                "gfx_clk_mhz": num(val((((g.get("clock") or {}).get("gfx_0") or {}).get("clk")))),
+                "hotspot_c": num(val((g.get("temperature") or {}).get("hotspot"))),
+                "mem_c": num(val((g.get("temperature") or {}).get("mem")))}
+    except Exception:
+        return None
+
+
+def power_window(hot, sync, kernel_ms, min_s=3.0, max_s=45.0):
+    """Which limiter holds the clock while the measured kernel runs, and what a launch costs in energy: two firmware readings
+    (`amd-smi metric`: energy accumulator, throttler residency counters) taken by a helper thread WHILE the main thread keeps
+    the kernel running back to back.  Between the readings: mean package power = d energy / d time (the firmware's own ~1 kHz
+    sample counter is the clock), fraction of the samples in which the package-power (PPT) / thermal / PROCHOT limiters were
+    active.  Outside the timed region; one GPU, rank 0."""
+    import threading
+    reads = []
+
+    def sampler():
+        a = _amdsmi_metric()
+        reads.append(a)
+        if a is None:
+            return
+        time.sleep(min_s)
+        reads.append(_amdsmi_metric())
+    th = threading.Thread(target=sampler, daemon=True)
+    t0 = time.perf_counter()
+    n = 0
+    th.start()
+    while th.is_alive() and time.perf_counter() - t0 < max_s:
+        hot()
+        sync()
+        n += 1
+    th.join(timeout=1.0)
+    if len(reads) < 2 or reads[0] is None or reads[1] is None:
+        return {"error": "amd-smi metric unavailable"}
+    a, b = reads
+    if None in (a["acc"], b["acc"], a["energy_j"], b["energy_j"]) or b["acc"] <= a["acc"]:
+        return {"error": "accumulators missing", "first": a, "second": b}
+    dt = (b["acc"] - a["acc"]) * 1e-3                             # the accumulation counter runs at ~1 kHz
+    frac = lambda k: (None if (a[k] is None or b[k] is None) else (b[k] - a[k]) / (b["acc"] - a["acc"]))      # noqa: E731
+    watts = (b["energy_j"] - a["energy_j"]) / dt
+    return {"what": "two `amd-smi metric` readings while the measured kernel runs back to back (launches kept up by the main "
+                    "thread); rates between the readings, the firmware's ~1 kHz accumulation counter as the clock",
+            "window_s": dt, "launches_during_window_and_tool_startup": n, "mean_package_w": watts,
+            "energy_j_per_launch": watts * kernel_ms * 1e-3,
+            "ppt_limited_frac": frac("ppt"), "socket_thermal_limited_frac": frac("socket_thm"), "vr_thermal_limited_frac": frac("vr_thm"),
+            "hbm_thermal_limited_frac": frac("hbm_thm"), "prochot_frac": frac("prochot"),
+            "socket_power_w_inst": [a["socket_power_w"], b["socket_power_w"]], "gfx_clk_mhz_inst": [a["gfx_clk_mhz"], b["gfx_clk_mhz"]],
+            "hotspot_c": [a["hotspot_c"], b["hotspot_c"]], "hbm_c": [a["mem_c"], b["mem_c"]]}
+
+
 def smi_snapshot():
     """One rocm-smi reading (fallback when the hwmon files are absent); called while a launch is in flight."""
     import re
@@ -380,6 +448,7 @@ def main():
     ap.add_argument("--adam-steps", type=int, default=10, help="--workload denoise: Adam steps per harness step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-box", action="store_true", help="skip the `box` / `regions` diagnostics blocks")
+    ap.add_argument("--no-power-window", action="store_true", help="skip the energy / throttler reading of the `box` block (~10 s)")
     ap.add_argument("--no-gpu-torch-baseline", action="store_true")
     ap.add_argument("--lbs-torch-baseline", action="store_true", help="also time a PyTorch restatement of the body-model terms (4 x 300 frames)")
     ap.add_argument("--no-motion-denoise", action="store_true", help="skip the configs[4] side block")
@@ -651,6 +720,8 @@ def main():
         except Exception as exc:       # an analysis aid must not take the line down
             regions = {"error": repr(exc)}
         box = box_block(dev_index, eng0.lib)
+        if not args.no_power_window:
+            box["power_window"] = power_window(hot, torch.cuda.synchronize, kern_ms)
     if side:
         host_ms = host_boundary_ms()
         ms1 = fwd_grad_ms(net)

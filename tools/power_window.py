@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Energy per launch and throttler residency of the fused kernels (bench.py: power_window -- two `amd-smi metric` readings
+while the kernel runs back to back): which limiter holds the clock, per kernel.  usage: python tools/power_window.py
+[precision:act ...]   default: f16x3:lrelu f16x3:softplus fp32:lrelu f16:lrelu
+       python tools/power_window.py --libs name=path.so ... [precision:act]   the same arm through several library builds
+       (tools/build_variants.py), one process each (PNDF_LIBRARY): the energy of what an ablation build leaves out"""
+import json
+import os
+import sys
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+from posendf_amd import PoseNDF, amass_config, synth  # noqa: E402
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--libs":
+        import subprocess
+        libs = [a for a in sys.argv[2:] if "=" in a]
+        arms = [a for a in sys.argv[2:] if "=" not in a] or ["f16x3:lrelu"]
+        for spec in libs:
+            name, _, path = spec.partition("=")
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), *arms], env=dict(os.environ, PNDF_LIBRARY=os.path.abspath(path)),
+                               capture_output=True, text=True, timeout=600)
+            for line in p.stdout.splitlines():
+                if line.startswith("{"):
+                    print(json.dumps({"build": name, **json.loads(line)}), flush=True)
+            if p.returncode != 0:
+                print(json.dumps({"build": name, "error": p.stderr[-400:]}), flush=True)
+        return
+    arms = sys.argv[1:] or ["f16x3:lrelu", "f16x3:softplus", "fp32:lrelu", "f16:lrelu"]
+    q = torch.from_numpy(synth.make_poses(65536, seed=1234)).cuda()
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_weights(0, 2.0, 0.1).items()}
+    for arm in arms:
+        prec, act = arm.split(":")
+        cfg = amass_config(act, "cuda:0")
+        cfg["engine"] = {"precision": prec}
+        net = PoseNDF(cfg)
+        net.load_state_dict(sd)
+        net.eval()
+        for _ in range(3):
+            net.project(q, steps=100)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            net.project(q, steps=100)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        r = bench.power_window(lambda: net.project(q, steps=100), torch.cuda.synchronize, ms)
+        r.pop("what", None)
+        print(json.dumps({"kernel": net._engine_for(q.device).kernel_name(), "kernel_ms": ms, **r}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
