@@ -312,7 +312,16 @@ def _amdsmi_metric():
         def val(x):
             return x.get("value") if isinstance(x, dict) else x
         num = lambda x: float(x) if isinstance(x, (int, float)) else None      # noqa: E731
-        return {"energy_j": num(val((g.get("energy") or {}).get("total_energy_consumption"))),
+
+        def xcd_sum(key):      # per-XCD accumulators of the first partition: {"xcp_0": [8 values]} -> their sum
+            v = thr.get(key)
+            v = v.get("xcp_0") if isinstance(v, dict) else None
+            return float(sum(x for x in v if isinstance(x, (int, float)))) if isinstance(v, list) and any(isinstance(x, (int, float)) for x in v) else None
+        return {"below_limit_power": xcd_sum("gfx_clk_below_host_limit_power_accumulated"),
+                "below_limit_thermal": xcd_sum("gfx_clk_below_host_limit_thermal_accumulated"),
+                "below_limit_total": xcd_sum("total_gfx_clk_below_host_limit_accumulated"),
+                "low_utilization": xcd_sum("low_utilization_accumulated"),
+                "energy_j": num(val((g.get("energy") or {}).get("total_energy_consumption"))),
                 "acc": num(thr.get("accumulation_counter")), "ppt": num(thr.get("ppt_accumulated")),
                 "prochot": num(thr.get("prochot_accumulated")), "socket_thm": num(thr.get("socket_thermal_accumulated")),
                 "vr_thm": num(thr.get("vr_thermal_accumulated")), "hbm_thm": num(thr.get("hbm_thermal_accumulated")),
@@ -363,6 +372,9 @@ def power_window(hot, sync, kernel_ms, min_s=3.0, max_s=45.0):
             "energy_j_per_launch": watts * kernel_ms * 1e-3,
             "ppt_limited_frac": frac("ppt"), "socket_thermal_limited_frac": frac("socket_thm"), "vr_thermal_limited_frac": frac("vr_thm"),
             "hbm_thermal_limited_frac": frac("hbm_thm"), "prochot_frac": frac("prochot"),
+            # per-XCD residencies (sum over the 8 XCDs / 8): shader clock below the host limit because of power / temperature / any reason
+            "xcd_clk_below_limit_frac": {k: (None if frac(k) is None else frac(k) / 8.0)
+                                         for k in ("below_limit_power", "below_limit_thermal", "below_limit_total", "low_utilization")},
             "socket_power_w_inst": [a["socket_power_w"], b["socket_power_w"]], "gfx_clk_mhz_inst": [a["gfx_clk_mhz"], b["gfx_clk_mhz"]],
             "hotspot_c": [a["hotspot_c"], b["hotspot_c"]], "hbm_c": [a["mem_c"], b["mem_c"]]}
 

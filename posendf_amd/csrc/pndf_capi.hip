@@ -328,6 +328,14 @@ namespace {
 inline void split_f16(float w, _Float16& hi, _Float16& lo) {
     hi = (_Float16)w;                       // round to nearest even
     lo = (_Float16)(w - (float)hi);
+#ifdef PNDF_EXP_LO_BITS                     // (energy experiment, profiles/r05/energy_breakdown.txt: the lo half keeps this many
+    {                                       // explicit mantissa bits -- does the matrix pipe pay for operand bits that toggle?)
+        uint16_t u = __builtin_bit_cast(uint16_t, lo);
+        const int drop = 10 - PNDF_EXP_LO_BITS;
+        u = (uint16_t)((u + (1u << (drop - 1))) & ~((1u << drop) - 1));
+        lo = __builtin_bit_cast(_Float16, u);
+    }
+#endif
 }
 // block(M, nt, kb): hi tile then lo tile, 8 halfs per lane each; returns whether any lo half is non-zero
 bool emit_pair(const Mat& m, int nt, int kb, float* dst, float scale) {

@@ -188,7 +188,7 @@ __device__ __forceinline__ void dma_begin(DmaPieces& d, Ring& ring, bool loaded)
 #endif                        // through lgkmcnt, so every stamp drains the tile prefetch: the groups then take ~1,100 cycles
                               // instead of ~270 (profiles/r02/group_stamps.txt) -- kept only as a documented dead end
 #ifndef PNDF_NT_MODE
-#define PNDF_NT_MODE 0      // cache-policy experiments: 1 = `nt` on the two big phases' slot fetches, 2 = on every slot fetch
+#define PNDF_NT_MODE 0      // cache-policy experiments: 1 = `nt` on the two big phases' slot fetches, 2 = on every slot fetch; 3 .. 6 = sc1 / sc0 sc1 / sc0 / sc1 nt
 #endif
 #ifndef PNDF_DMA_EARLY
 #define PNDF_DMA_EARLY 3    // where the four 1-KiB pieces of a slot fetch are issued (round 5, profiles/r05/ring_margin.txt):
@@ -216,6 +216,14 @@ __device__ __forceinline__ void dma_piece(const DmaPieces& d) {
     if (PNDF_ABLATE & 2) return;
     if constexpr (PNDF_NT_MODE == 2 || (PNDF_NT_MODE == 1 && BIG)) {
         PNDF_DMA_PIECE(" nt")
+    } else if constexpr (PNDF_NT_MODE == 3) {       // (round 5, energy experiments: scope bits on the trunk's slot fetches)
+        PNDF_DMA_PIECE(" sc1")
+    } else if constexpr (PNDF_NT_MODE == 4) {
+        PNDF_DMA_PIECE(" sc0 sc1")
+    } else if constexpr (PNDF_NT_MODE == 5) {
+        PNDF_DMA_PIECE(" sc0")
+    } else if constexpr (PNDF_NT_MODE == 6) {
+        PNDF_DMA_PIECE(" sc1 nt")
     } else {
         PNDF_DMA_PIECE("")
         if constexpr ((PNDF_ABLATE & 512) != 0) {          // (additive energy experiment: every slot fetch issued twice)

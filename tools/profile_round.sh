@@ -23,6 +23,8 @@ echo "bench rc=$?"
 python tools/gpu_region_timing.py 3 f16x3 lrelu > "$OUT/regions_f16x3_lrelu.txt" 2>&1
 python tools/gpu_region_timing.py 3 f16x3 softplus > "$OUT/regions_f16x3_softplus.txt" 2>&1
 python tools/gpu_region_timing.py 3 fp32 lrelu > "$OUT/regions_fp32_lrelu.txt" 2>&1
+# energy per launch and throttler residency of the four fused kernels (firmware accumulators, tools/power_window.py)
+python tools/power_window.py > "$OUT/power_window.txt" 2> "$OUT/power_window.err"
 # package power and shader clock while the projection loop runs (rocm-smi sampled every 0.6 s)
 smi() { rocm-smi --showpower --showclocks 2>/dev/null | grep -E "sclk|Package Power" | sed 's/GPU\[0\]\s*: //' | tr '\n' ' '; echo; }
 {
