@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""VERDICT r4 item 3, CPU stage: which storage formats of the softplus derivative (written forward, read backward: 207 GB per
+launch as fp32) do the per-pose gates of tests/conftest.py survive?  The fp32 numpy oracle with its derivative e / (1 + e)
+rounded to the candidate format in every layer (trunk and encoder), d d / d q against the fp64 oracle, per weight set:
+median / p95 / max of the per-pose relative error and the largest error / (8 sigma + 8e-6) (pose_gate: 1.00 = at the gate).
+No GPU.  usage: python tools/sp_derivative_formats.py > profiles/r05/softplus_bytes.txt"""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from conftest import d_rows, rel_err_rows, fp32_noise
+from oracle import posendf_np as onp
+from posendf_amd import synth
+orig=onp._dact
+def quant(kind):
+    def f(z, act, beta):
+        d=orig(z,act,beta)
+        if act!="softplus": return d
+        dt=d.dtype
+        if kind=="u16": return (np.round(d.astype(np.float64)*65535)/65535).astype(dt)
+        if kind=="f16": return d.astype(np.float16).astype(dt)
+        if kind=="f16+8":   # fp16 hi (rne) + 8-bit signed lo in units of the hi's ulp/256
+            hi=d.astype(np.float16).astype(np.float64); 
+            ulp=np.spacing(np.abs(hi).astype(np.float16)).astype(np.float64)
+            lo=np.clip(np.round((d.astype(np.float64)-hi)/(ulp/256)),-128,127)*(ulp/256)
+            return (hi+lo).astype(dt)
+        if kind=="u24": return (np.round(d.astype(np.float64)*(2**24))/2**24).astype(dt)
+        return d
+    return f
+print("# softplus derivative storage formats against the per-pose gradient gate (tools/sp_derivative_formats.py; 256 poses per weight set)")
+print("# fp32 = product (4 B); u16 = unsigned fixed point round(d 65535) (2 B); f16 = fp16 rne (2 B); f16+8 = fp16 hi + 8-bit lo in 1/256 ulp (3 B); u24 = 24-bit fixed point (3 B)")
+sets=[(0,2.0,0.1),(0,2.5,0.1),(1,1.0,0.1),(3,0.5,0.1),(4,2.5,0.05),(2,3.0,0.1),(11,1.5,0.1),(14,2.8,0.1),(17,3.6,0.1)]
+for ws in sets:
+    sd=synth.make_weights(*ws); q=synth.make_poses(256, seed=77)
+    sig_d,sig_g,d64,g64=fp32_noise(q,sd,"softplus")
+    row=f"s{ws[0]}g{ws[1]}"
+    for kind in ("fp32","u16","f16","f16+8","u24"):
+        onp._dact=quant(kind)
+        d,g=onp.forward_grad(q,sd,"softplus",dtype=np.float32)
+        onp._dact=orig
+        eg=rel_err_rows(g,g64)
+        ratio=(eg/(8*sig_g+8e-6)).max()
+        row+=f" | {kind}: dq med {np.median(eg):.1e} p95 {np.percentile(eg,95):.1e} max {eg.max():.1e} gate {ratio:.2f}"
+    print(row,flush=True)
