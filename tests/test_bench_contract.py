@@ -60,6 +60,18 @@ def test_bench_json_line_default_precision():
     assert d["roofline"]["traffic"] is None and d["roofline"]["traffic_stale"] is None      # only quoted for the profiled workload
     gt = d["gpu_torch_baseline"]                  # the denominator of north_star's ">= 10x", measured in the same run
     assert gt["value"] > 0 and abs(gt["speedup_of_value"] - d["value"] / gt["value"]) < 1e-9
+    # the line describes its box and says where a step's cycles went on it
+    box, reg = d["box"], d["regions"]
+    assert box["compute_units"] > 0 and {"device", "arch", "pci", "host_loadavg", "mem_probe", "power_window"} <= set(box)
+    mp = box["mem_probe"]
+    assert 50 < mp["l2_hit_latency_ns"] < mp["hbm_latency_ns"] * 1.05 and 500 < mp["stream_read_gbps"] < 9000
+    pw = box["power_window"]                      # firmware accumulators; a box without amd-smi reports the error instead
+    assert "error" in pw or (pw["mean_package_w"] > 100 and pw["energy_j_per_launch"] > 0 and 0 <= pw["ppt_limited_frac"] <= 1)
+    assert reg["kernel"] == "pndf_fused_split_relu_kernel_timing" and len(reg["regions"]) == 12
+    assert reg["cycles_per_wave_step"] > 1e5 and reg["ring"]["look_ahead_slots"] == 4
+    assert reg["ring"]["wait_cycles_per_slot"] > 0 and reg["ring"]["barrier_cycles_per_slot"] > 0
+    assert reg["fp32_kernel"]["cycles_per_wave_step"] > reg["cycles_per_wave_step"]
+    assert cb["pinned_to"].startswith(f"{cb['cores']} distinct physical cores") and len(cb["host_loadavg_before_after"]) == 2
 
 
 @pytest.mark.gpu
@@ -165,3 +177,9 @@ def test_full_size_relations_in_the_committed_bench_line():
     assert d["f16_single"]["kernel_ms"] < d["fp16_checkpoint"]["kernel_ms"] < d["softplus"]["kernel_ms"] < d["fp32_exact"]["kernel_ms"]
     assert abs(d["ms_per_step"] - k) < 0.02 * k                         # one launch per harness step, nothing else in the timed region
     assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    if "regions" in d:      # (lines committed since round 5) the ring's own numbers: on a healthy box the look-ahead hides the fetches
+        ring = d["regions"]["ring"]
+        assert ring["wait_cycles_per_slot"] < 40 and ring["barrier_cycles_per_slot"] < 80, ring
+        assert d["regions"]["cycles_per_wave_step"] < 1.5 * 404e3
+        pw = d["box"]["power_window"]
+        assert "error" in pw or 90 < pw["energy_j_per_launch"] < 150
