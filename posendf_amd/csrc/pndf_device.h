@@ -152,7 +152,18 @@ __device__ __forceinline__ void ring_wait_dma() { asm volatile("s_waitcnt vmcnt(
 #ifndef PNDF_SP_DIAG
 #define PNDF_SP_DIAG 0
 #endif
-constexpr int RING_INFLIGHT = 4 * (RING_SLOTS - 3);      // pieces of the slots after the next one (product: 8)
+// Pieces (1 KiB each, per wave) that a TRUNK slot's fetch issues.  4 = all of the wave's four tiles.  2 (the two-term kernels'
+// translation unit, pndf_kernel_split_x2.hip): only the hi tiles -- those kernels run networks whose lo tiles are all zero and
+// never read them, so their half of the stream need not be delivered at all (round 5: the delivery of the weight stream into LDS
+// is a third of a launch's energy).  Encoder slots and the ring's start always fetch all four.
+#ifndef PNDF_RING_PIECES
+#define PNDF_RING_PIECES 4
+#endif
+static_assert(PNDF_RING_PIECES == 4 || PNDF_RING_PIECES == 2, "pieces per trunk slot");
+// the counted wait before the mid-slot barrier: at most this many of the wave's fetch operations may still be in flight -- the
+// pieces of the slots after the next one, counted with the SMALLEST number a slot can issue (a slot that issued more only makes
+// the wait stricter)
+constexpr int RING_INFLIGHT = PNDF_RING_PIECES * (RING_SLOTS - 3);      // product: 8
 __device__ __forceinline__ void ring_wait_next_slot() {
     if (PNDF_SP_DIAG & 32) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // (timing diagnostic only: see pndf_kernel_split.hip)
     else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(RING_INFLIGHT) : "memory");
@@ -173,6 +184,27 @@ __device__ __forceinline__ void ring_start(Ring& r, int wave) {
         r.prev_off += SLOT_BYTES;
     }
     r.cur_off = (RING_SLOTS - 1) * SLOT_BYTES;
+}
+
+// PNDF_RING_PIECES == 2 only.  The trunk's slot fetches run RING_SLOTS - 1 slots ahead, i.e. the last ones of the backward
+// trunk target the encoder's backward section and the first slot of the next step -- fp32 tiles, all of them needed -- and
+// brought only their even tiles.  Once per step, between the trunk and the encoder: fetch the odd tiles of those slots (the
+// buffers after the current one, in ring order; the fetch pointer stands at the last of them), then drain.  The caller's
+// workgroup barrier publishes them.
+__device__ __forceinline__ void ring_complete_lookahead(Ring& r) {
+    if constexpr (PNDF_RING_PIECES == 2) {
+        uint32_t boff = r.cur_off;
+#pragma unroll
+        for (int k = 0; k < RING_SLOTS - 1; ++k) {
+            boff = (boff == (RING_SLOTS - 1) * SLOT_BYTES) ? 0u : boff + SLOT_BYTES;
+            const uint32_t off = r.fetch_off - (uint32_t)(RING_SLOTS - 2 - k) * SLOT_BYTES;
+            const uint32_t dst = r.dst_base + boff;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %0, %1 offset:3072"
+                         : : "v"(off), "s"(r.gstream), "s"(dst) : "memory", "m0");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 }
 
 // top of projection step 1, 2, ...: the fetch pointer has run one step's length (into the replica of the first slots)

@@ -214,6 +214,7 @@ __device__ __forceinline__ void dma_begin(DmaPieces& d, Ring& ring, bool loaded)
 template <int PIECE, bool BIG = false>
 __device__ __forceinline__ void dma_piece(const DmaPieces& d) {
     if (PNDF_ABLATE & 2) return;
+    if constexpr (PNDF_RING_PIECES == 2 && (PIECE & 1) != 0) return;      // two-term kernels: the lo tiles (odd tiles of the wave's window) stay where they are
     if constexpr (PNDF_NT_MODE == 2 || (PNDF_NT_MODE == 1 && BIG)) {
         PNDF_DMA_PIECE(" nt")
     } else if constexpr (PNDF_NT_MODE == 3) {       // (round 5, energy experiments: scope bits on the trunk's slot fetches)
@@ -570,7 +571,7 @@ struct SplitPhase {
     // (Round 3 measured a fetch TWO chunks ahead into a double-buffered window -- the part A of (lin5^T, lin4^T) is only
     // 24 MFMAs long -- and found no gain: 105.5 ms one ahead, 104.9 .. 113 ms two ahead, same bits; profiles/r03/ab_sp_stage.txt.
     // The phase's overhead is issue-bound VALU work, not the latency of these tiles.)
-    static constexpr int STAGE_YOUNGER = (2 * AG < 12) ? 2 * AG : 12;
+    static constexpr int STAGE_YOUNGER = (PNDF_RING_PIECES * AG / 2 < 12) ? PNDF_RING_PIECES * AG / 2 : 12;      // AG / 2 slots in part A
     static __device__ __forceinline__ void init_chunk(f32x4 (&ch)[3][CT], const float* biasA, int c, int g, const SAct& act) {
         if constexpr (SP && BWD) {
 #pragma unroll
@@ -1116,6 +1117,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
 #pragma unroll
             for (int t = 0; t < 8; ++t) *(f32x4*)(my_f + 16 * t + 4 * g) = g0[t] * g0_true;
         }
+        ring_complete_lookahead(ring);      // (two-term kernels: the odd tiles of the slots fetched ahead of the trunk's end)
         __syncthreads();
 
         tick<TIMING>(rc, 9);

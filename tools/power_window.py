@@ -36,10 +36,12 @@ def main():
     sd = {k: torch.from_numpy(v) for k, v in synth.make_weights(0, 2.0, 0.1).items()}
     for arm in arms:
         prec, act = arm.split(":")
+        half_ckpt = prec.endswith("h")                  # "f16x3h": the same network as a half-precision checkpoint (two-term kernels)
+        prec = prec.rstrip("h")
         cfg = amass_config(act, "cuda:0")
         cfg["engine"] = {"precision": prec}
         net = PoseNDF(cfg)
-        net.load_state_dict(sd)
+        net.load_state_dict({k: v.half().float() for k, v in sd.items()} if half_ckpt else sd)
         net.eval()
         for _ in range(3):
             net.project(q, steps=100)
