@@ -28,17 +28,21 @@ def quant(kind):
             ulp=np.spacing(np.abs(hi).astype(np.float16)).astype(np.float64)
             lo=np.clip(np.round((d.astype(np.float64)-hi)/(ulp/256)),-128,127)*(ulp/256)
             return (hi+lo).astype(dt)
+        if kind=="fp24":    # the top three bytes of the fp32 (8-bit exponent, 15 explicit mantissa bits), round to nearest
+            u=d.astype(np.float32).view(np.uint32).astype(np.uint64)
+            u=((u+0x80)&0xFFFFFF00).astype(np.uint32)
+            return u.view(np.float32).astype(dt)
         if kind=="u24": return (np.round(d.astype(np.float64)*(2**24))/2**24).astype(dt)
         return d
     return f
 print("# softplus derivative storage formats against the per-pose gradient gate (tools/sp_derivative_formats.py; 256 poses per weight set)")
-print("# fp32 = product (4 B); u16 = unsigned fixed point round(d 65535) (2 B); f16 = fp16 rne (2 B); f16+8 = fp16 hi + 8-bit lo in 1/256 ulp (3 B); u24 = 24-bit fixed point (3 B)")
+print("# fp32 = product (4 B); u16 = unsigned fixed point round(d 65535) (2 B); f16 = fp16 rne (2 B); f16+8 = fp16 hi + 8-bit lo in 1/256 ulp (3 B); fp24 = the top three bytes of the fp32, rne (3 B); u24 = 24-bit fixed point (3 B)")
 sets=[(0,2.0,0.1),(0,2.5,0.1),(1,1.0,0.1),(3,0.5,0.1),(4,2.5,0.05),(2,3.0,0.1),(11,1.5,0.1),(14,2.8,0.1),(17,3.6,0.1)]
 for ws in sets:
     sd=synth.make_weights(*ws); q=synth.make_poses(256, seed=77)
     sig_d,sig_g,d64,g64=fp32_noise(q,sd,"softplus")
     row=f"s{ws[0]}g{ws[1]}"
-    for kind in ("fp32","u16","f16","f16+8","u24"):
+    for kind in ("fp32","u16","f16","f16+8","fp24","u24"):
         onp._dact=quant(kind)
         d,g=onp.forward_grad(q,sd,"softplus",dtype=np.float32)
         onp._dact=orig
