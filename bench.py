@@ -718,7 +718,7 @@ def main():
     # after the timed loop (s_memtime stamps per region; the weight ring's counted wait and barrier sampled every 16th slot),
     # and what the box is.  A slow box must be diagnosable from its own line.
     regions = box = None
-    if rank == 0 and args.workload == "project" and not args.no_box:
+    if rank == 0 and world == 1 and args.workload == "project" and not args.no_box:      # (N = 1 line only, like the side runs)
         eng0 = net._engine_for(dev)
         try:
             if not (args.act == "softplus" and B > 64 * torch.cuda.get_device_properties(dev).multi_processor_count):
