@@ -289,10 +289,13 @@ def box_block(dev_index, lib):
                 v = rd(os.path.join(hw[0], n))
                 out[key] = float(v) / 1e6 if v else None
     out["amdgpu_driver"] = rd("/sys/module/amdgpu/version")
-    probe = (ctypes.c_double * 6)()
-    rc = lib.pndf_debug_mem_probe(int(dev_index), probe, 6)
+    probe = (ctypes.c_double * 8)()
+    rc = lib.pndf_debug_mem_probe(int(dev_index), probe, 8)
     out["mem_probe"] = ({"l2_hit_latency_ns": round(probe[0], 1), "infinity_cache_latency_ns": round(probe[1], 1),
                          "hbm_latency_ns": round(probe[2], 1), "stream_read_gbps": round(probe[3], 1),
+                         # the weight ring alone (no arithmetic), all CUs: what one CU's LDS ring is fed at on this box
+                         "ring_only_gbps_per_cu": round(probe[6], 1), "ring_only_ns_per_slot": round(probe[7], 1),
+                         "ring_needed_gbps_per_cu": {"f16x3": 51, "fp32": 17},
                          "what": "dependent-load latency of one lane walking 128-byte lines of a 1 MiB / 64 MiB / 1 GiB footprint "
                                  f"({int(probe[5])} hops each, wall-clock counter at {probe[4]:.0f} MHz); read bandwidth over 1 GiB, all CUs "
                                  "(posendf_amd/csrc/pndf_probe.hip)"} if rc == 0 else {"error": rc})

@@ -127,7 +127,10 @@ int pndf_debug_timing_layout(int what);
 
 /* Measurement aid: the memory subsystem of `device` as the fused kernels' weight stream sees it -- dependent-load latency
  * (ns) with the walked footprint resident in L2 (1 MiB), in the Infinity Cache (64 MiB) and in HBM (1 GiB): out[0..2];
- * streaming read bandwidth (GB/s): out[3]; wall-clock counter rate (MHz): out[4]; hops timed: out[5].  n_out >= 6.
+ * streaming read bandwidth (GB/s): out[3]; wall-clock counter rate (MHz): out[4]; hops timed: out[5].  n_out >= 6; with
+ * n_out >= 8 also the weight ring ALONE -- one workgroup per compute unit streaming 11 MB through a five-slot LDS ring with the
+ * kernels' own instructions, waits and barriers, no arithmetic: GB/s delivered per compute unit while all of them run (out[6];
+ * the f16x3 kernel consumes ~51) and ns per 16-KiB slot (out[7]).
  * Allocates 1 GiB for the duration of the call and synchronises the device (bench.py's `box` block). */
 int pndf_debug_mem_probe(int device, double* out, int n_out);
 

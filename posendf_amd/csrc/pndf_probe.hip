@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "pndf_host.h"
 
 namespace {
@@ -47,10 +49,50 @@ __global__ void __launch_bounds__(256) probe_stream(const f4* src, size_t n, flo
     if (acc.x + acc.y + acc.z + acc.w == 123.456f) *sink = acc.x;      // (never true: keeps the loads)
 }
 
+// The weight ring alone: every workgroup (one per CU, 4 waves) streams the same 11 MB through LDS exactly as the fused kernels
+// do -- 16-KiB slots, each wave moves 4 KiB with four global_load_lds_dwordx4, four slots in flight, a counted wait and a barrier
+// per slot -- with no arithmetic behind it.  What it delivers per CU is the ceiling the kernels' stream lives under on this box.
+constexpr int PR_SLOT = 16 * 1024, PR_SLOTS = 5, PR_STREAM_SLOTS = 670;
+__global__ void __launch_bounds__(256, 1) probe_ring(const char* stream, int passes, unsigned long long* ticks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem + wave * 4096;
+    uint32_t off = wave * 4096 + lane * 16;
+    auto fetch = [&](uint32_t buf) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
+                     : : "v"(off), "s"(stream), "s"(lds0 + buf * PR_SLOT) : "memory", "m0");
+    };
+    const unsigned long long t0 = wall_clock64();
+    for (int p = 0; p < passes; ++p) {
+        off = wave * 4096 + lane * 16;
+        uint32_t buf = 0;
+        for (int b = 0; b < PR_SLOTS - 1; ++b) {          // four slots in flight
+            fetch(buf);
+            off += PR_SLOT;
+            buf = (buf + 1 == PR_SLOTS) ? 0 : buf + 1;
+        }
+        for (int s = 0; s < PR_STREAM_SLOTS; ++s) {
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // the oldest slot has landed (this wave's share)
+            __builtin_amdgcn_s_barrier();                          // ... and every wave's: its buffer may be refilled
+            if (s + PR_SLOTS - 1 < PR_STREAM_SLOTS) fetch(buf);
+            else asm volatile("s_nop 0" ::: "memory");
+            off += PR_SLOT;
+            buf = (buf + 1 == PR_SLOTS) ? 0 : buf + 1;
+            if (s + PR_SLOTS - 1 >= PR_STREAM_SLOTS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tail: nothing new behind it
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    const unsigned long long t1 = wall_clock64();
+    if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+}
+
 }  // namespace
 
 // out[0..2] = dependent-load latency in ns at the three footprints, out[3] = streaming read GB/s, out[4] = wall-clock
-// counter rate in MHz, out[5] = hops timed per footprint.  Returns 0 or a negative pndf_status.
+// counter rate in MHz, out[5] = hops timed per footprint; with n_out >= 8 also out[6], out[7]: the weight ring alone (below).
+// Returns 0 or a negative pndf_status.
 extern "C" int pndf_debug_mem_probe(int device, double* out, int n_out) {
     if (!out || n_out < 6) return -1;
     DeviceGuard guard(device);
@@ -94,6 +136,31 @@ extern "C" int pndf_debug_mem_probe(int device, double* out, int n_out) {
     }
     out[4] = rate_khz / 1e3;
     out[5] = hops;
+    if (rc == 0 && n_out >= 8) {
+        // out[6] = GB/s that ONE compute unit pulls through its LDS ring while all of them do (the fused f16x3 kernel needs ~51),
+        // out[7] = ns per 16-KiB slot.  Mean over the workgroups, one per CU.
+        hipDeviceProp_t prop;
+        int cus = 256;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        unsigned long long* tk = nullptr;
+        const int passes = 8;
+        if (hipMalloc((void**)&tk, (size_t)cus * sizeof(unsigned long long)) != hipSuccess) rc = -3;
+        if (rc == 0 && hipFuncSetAttribute((const void*)probe_ring, hipFuncAttributeMaxDynamicSharedMemorySize, PR_SLOTS * PR_SLOT) != hipSuccess) rc = -3;
+        if (rc == 0) {
+            hipLaunchKernelGGL(probe_ring, dim3(cus), dim3(256), PR_SLOTS * PR_SLOT, 0, (const char*)buf, 1, tk);      // warm
+            hipLaunchKernelGGL(probe_ring, dim3(cus), dim3(256), PR_SLOTS * PR_SLOT, 0, (const char*)buf, passes, tk);
+            std::vector<unsigned long long> h(cus);
+            if (hipMemcpy(h.data(), tk, (size_t)cus * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = -3;
+            else {
+                double sum = 0;
+                for (int i = 0; i < cus; ++i) sum += (double)h[i];
+                const double sec = sum / cus / (rate_khz * 1e3);
+                out[6] = (double)passes * PR_STREAM_SLOTS * PR_SLOT / sec / 1e9;
+                out[7] = sec / ((double)passes * PR_STREAM_SLOTS) * 1e9;
+            }
+        }
+        if (tk) (void)hipFree(tk);
+    }
     if (sink) (void)hipFree(sink);
     if (ticks) (void)hipFree(ticks);
     (void)hipFree(buf);

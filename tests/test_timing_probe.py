@@ -45,9 +45,11 @@ def test_instrumented_kernel_projects_like_the_product_kernel(precision, act):
 @pytest.mark.gpu
 def test_mem_probe_orders_the_levels():
     lib = engine.load_library()
-    out = (ctypes.c_double * 6)()
-    assert lib.pndf_debug_mem_probe(0, out, 6) == 0
-    l2, mall, hbm, gbps, mhz, hops = list(out)
+    out = (ctypes.c_double * 8)()
+    assert lib.pndf_debug_mem_probe(0, out, 8) == 0
+    l2, mall, hbm, gbps, mhz, hops, ring_gbps, ring_ns = list(out)
     assert 50 < l2 < mall * 1.05 and mall < hbm * 1.05 and hbm < 20000, (l2, mall, hbm)
     assert 500 < gbps < 9000 and mhz > 0 and hops == 4096
+    # the ring alone must deliver more than the f16x3 kernel consumes (~51 GB/s per CU), or that kernel is fetch-bound here
+    assert 51 < ring_gbps < 1000 and abs(ring_ns * ring_gbps - 16384) < 1.0, (ring_gbps, ring_ns)
     assert lib.pndf_debug_mem_probe(0, out, 5) < 0                 # too small an output buffer is refused
