@@ -133,6 +133,9 @@ int pndf_debug_timing_layout(int what);
  * the f16x3 kernel consumes ~51) and ns per 16-KiB slot (out[7]).
  * Allocates 1 GiB for the duration of the call and synchronises the device (bench.py's `box` block). */
 int pndf_debug_mem_probe(int device, double* out, int n_out);
+/* The ring-only stream of the probe as a sustained load (`passes` walks of 11 MB by one workgroup per compute unit, synchronous;
+ * seconds per pass in *sec_per_pass, may be NULL): tools/power_window.py --ring-only reads the package power under it. */
+int pndf_debug_ring_stream(int device, int passes, double* sec_per_pass);
 
 /* ---- host twins (SURVEY.md 8b `pndf_*_cpu`): the same three operations on HOST pointers, for a caller whose
  * `train.device` is "cpu" (model/posendf.py:35,64 runs wherever the config says).  A separate handle type with no device

@@ -155,7 +155,7 @@ __device__ __forceinline__ void ring_wait_dma() { asm volatile("s_waitcnt vmcnt(
 // Pieces (1 KiB each, per wave) that a TRUNK slot's fetch issues.  4 = all of the wave's four tiles.  2 (the two-term kernels'
 // translation unit, pndf_kernel_split_x2.hip): only the hi tiles -- those kernels run networks whose lo tiles are all zero and
 // never read them, so their half of the stream need not be delivered at all (round 5: the delivery of the weight stream into LDS
-// is a third of a launch's energy).  Encoder slots and the ring's start always fetch all four.
+// is a fifth of a launch's energy and what pushes the kernel over the power cap).  Encoder slots and the ring's start always fetch all four.
 #ifndef PNDF_RING_PIECES
 #define PNDF_RING_PIECES 4
 #endif

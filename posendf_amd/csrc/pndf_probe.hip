@@ -24,6 +24,15 @@ __global__ void probe_fill(uint32_t* buf, uint32_t n) {
     if (i < n) buf[(size_t)i * LINE_WORDS] = (i * 1664525u + 1013904223u) & (n - 1);
 }
 
+// pseudo-random words (the weights are random bits to the memory path: operand toggling costs energy)
+__global__ void probe_fill_random(uint32_t* buf, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)i * 2654435761u + 12345u;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        buf[i] = x;
+    }
+}
+
 __global__ void probe_chase(const uint32_t* buf, int hops, unsigned long long* ticks, uint32_t* sink) {
     if (threadIdx.x != 0) return;
     uint32_t i = 0;
@@ -165,4 +174,33 @@ extern "C" int pndf_debug_mem_probe(int device, double* out, int n_out) {
     if (ticks) (void)hipFree(ticks);
     (void)hipFree(buf);
     return rc;
+}
+
+// The ring-only stream of pndf_debug_mem_probe as a load of its own: `passes` walks of an 11 MB buffer by one workgroup per
+// compute unit, synchronous.  tools/power_window.py --ring-only reads the package power while it runs: what delivering the weight
+// stream into LDS costs in energy with nothing else going on.  Returns seconds per pass in *sec_per_pass (may be NULL).
+extern "C" int pndf_debug_ring_stream(int device, int passes, double* sec_per_pass) {
+    if (passes <= 0) return -1;
+    DeviceGuard guard(device);
+    if (!guard.ok) return -3;
+    int rate_khz = 0;
+    if (hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || rate_khz <= 0) rate_khz = 100000;
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    static char* buf = nullptr;               // (a debugging aid: the 12 MB are kept for the life of the process)
+    static unsigned long long* tk = nullptr;
+    if (!buf) {
+        const size_t bytes = (size_t)(PR_STREAM_SLOTS + PR_SLOTS) * PR_SLOT;
+        if (hipMalloc((void**)&buf, bytes) != hipSuccess) return -3;
+        hipLaunchKernelGGL(probe_fill_random, dim3(1024), dim3(256), 0, 0, (uint32_t*)buf, bytes / 4);
+    }
+    if (!tk && hipMalloc((void**)&tk, 1024 * sizeof(unsigned long long)) != hipSuccess) return -3;
+    if (cus > 1024) cus = 1024;
+    if (hipFuncSetAttribute((const void*)probe_ring, hipFuncAttributeMaxDynamicSharedMemorySize, PR_SLOTS * PR_SLOT) != hipSuccess) return -3;
+    hipLaunchKernelGGL(probe_ring, dim3(cus), dim3(256), PR_SLOTS * PR_SLOT, 0, (const char*)buf, passes, tk);
+    unsigned long long t = 0;
+    if (hipMemcpy(&t, tk, sizeof(t), hipMemcpyDeviceToHost) != hipSuccess) return -3;
+    if (sec_per_pass) *sec_per_pass = (double)t / (rate_khz * 1e3) / passes;
+    return 0;
 }

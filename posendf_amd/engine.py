@@ -64,6 +64,8 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.pndf_debug_timing_layout.restype = c_int
     lib.pndf_debug_mem_probe.argtypes = [c_int, c_void_p, c_int]
     lib.pndf_debug_mem_probe.restype = c_int
+    lib.pndf_debug_ring_stream.argtypes = [c_int, c_int, c_void_p]
+    lib.pndf_debug_ring_stream.restype = c_int
     lib.pndf_packed_sizes.argtypes = [POINTER(c_int64)] * 2
     lib.pndf_packed_sizes.restype = None
     lib.pndf_pack_host.argtypes = [POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p, c_void_p]
@@ -136,7 +138,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
 
 EXPORTS = ("pndf_default_config", "pndf_create", "pndf_destroy", "pndf_load_weights", "pndf_forward",
            "pndf_forward_grad", "pndf_project", "pndf_debug_forward_grad", "pndf_debug_floats",
-           "pndf_debug_project_timing", "pndf_debug_timing_regions", "pndf_debug_timing_layout", "pndf_debug_mem_probe",
+           "pndf_debug_project_timing", "pndf_debug_timing_regions", "pndf_debug_timing_layout", "pndf_debug_mem_probe", "pndf_debug_ring_stream",
            "pndf_packed_sizes", "pndf_pack_host", "pndf_pack_host_split", "pndf_aa2quat", "pndf_denoise_update", "pndf_denoise_update_body", "pndf_denoise_update_w", "pndf_lbs_terms_grad_w", "pndf_quat_topk",
            "pndf_lbs_create", "pndf_lbs_destroy", "pndf_lbs_set_precision", "pndf_lbs_precision", "pndf_lbs_num_joints", "pndf_lbs_num_vertices", "pndf_lbs_workspace_floats",
            "pndf_lbs_forward", "pndf_lbs_terms_grad", "pndf_lbs_backward", "pndf_lbs_packed_floats", "pndf_lbs_pack_host", "pndf_lbs_packed_split_bytes", "pndf_lbs_pack_split_host",

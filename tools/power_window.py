@@ -31,6 +31,24 @@ def main():
             if p.returncode != 0:
                 print(json.dumps({"build": name, "error": p.stderr[-400:]}), flush=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--ring-only":
+        # the weight ring alone (csrc/pndf_probe.hip: probe_ring), no arithmetic: package power while every CU streams 11 MB passes
+        import ctypes
+        from posendf_amd import engine
+        lib = engine.load_library()
+        torch.zeros(1, device="cuda")
+        sec = ctypes.c_double()
+        passes = 1000
+        assert lib.pndf_debug_ring_stream(0, passes, ctypes.byref(sec)) == 0
+        idle = bench._amdsmi_metric()
+        r = bench.power_window(lambda: lib.pndf_debug_ring_stream(0, passes, ctypes.byref(sec)), lambda: None, sec.value * passes * 1e3)
+        r.pop("what", None)
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        bytes_per_call = passes * 670 * 16384 * cus
+        print(json.dumps({"load": "ring only (probe_ring)", "sec_per_pass": sec.value, "tb_per_s_into_lds": 670 * 16384 * cus / sec.value / 1e12,
+                          "idle_socket_power_w_before": idle and idle["socket_power_w"], "bytes_per_call": bytes_per_call,
+                          "pj_per_byte_incl_idle_power": r.get("energy_j_per_launch", 0) / bytes_per_call * 1e12, **r}), flush=True)
+        return
     arms = sys.argv[1:] or ["f16x3:lrelu", "f16x3:softplus", "fp32:lrelu", "f16:lrelu"]
     q = torch.from_numpy(synth.make_poses(65536, seed=1234)).cuda()
     sd = {k: torch.from_numpy(v) for k, v in synth.make_weights(0, 2.0, 0.1).items()}
