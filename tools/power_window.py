@@ -49,6 +49,31 @@ def main():
                           "idle_socket_power_w_before": idle and idle["socket_power_w"], "bytes_per_call": bytes_per_call,
                           "pj_per_byte_incl_idle_power": r.get("energy_j_per_launch", 0) / bytes_per_call * 1e12, **r}), flush=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--lbs":
+        # the body-model pass (pndf_lbs_terms_grad, 512 x 300 frames) through the same window: is IT held by the power limit?
+        from posendf_amd import BodyModel
+        S, T = 512, 300
+        m = synth.make_body_model(seed=11)
+        for prec in ("f16x3", "fp32"):
+            bm = BodyModel(m, device="cuda:0", extra_joint_vertex=m["extra_joint_vertex"], precision=prec)
+            g = torch.Generator().manual_seed(0)
+            theta = (torch.cumsum(0.02 * torch.randn(S, T, 69, generator=g), dim=1) + 0.3 * torch.randn(S, 1, 69, generator=g)).cuda()
+            j0 = bm.joints_of(theta + 0.02)
+            out = torch.empty_like(theta)
+            for _ in range(3):
+                bm.terms_grad(theta, j0, 2, out=out)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                bm.terms_grad(theta, j0, 2, out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            r = bench.power_window(lambda: bm.terms_grad(theta, j0, 2, out=out), torch.cuda.synchronize, ms)
+            r.pop("what", None)
+            print(json.dumps({"load": f"pndf_lbs_terms_grad {S} x {T} frames, {prec}", "kernel_ms": ms, **r}), flush=True)
+        return
     arms = sys.argv[1:] or ["f16x3:lrelu", "f16x3:softplus", "fp32:lrelu", "f16:lrelu"]
     q = torch.from_numpy(synth.make_poses(65536, seed=1234)).cuda()
     sd = {k: torch.from_numpy(v) for k, v in synth.make_weights(0, 2.0, 0.1).items()}
