@@ -208,3 +208,46 @@ def test_two_term_kernel_full_width_bit_identity(torch_cuda, act, monkeypatch):
     pose_gate(d_rows(two[1][:512].cpu().numpy(), d64), sig_d, "d")
     ex = None if act == "softplus" else onp.kink_margin(qn[:512], sd, act) < 1e-5
     pose_gate(rel_err_rows(two[5].cpu().numpy(), g64), sig_g, "dq", exempt=ex)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("encoder", [True, False], ids=["enc", "noenc"])
+@pytest.mark.parametrize("act", ["lrelu", "softplus"])
+def test_two_term_kernels_fetch_hi_tiles_only_same_bits(torch_cuda, act, encoder, monkeypatch):
+    """Round 5: the two-term kernels do not FETCH the lo tiles of the trunk either (csrc/pndf_device.h PNDF_RING_PIECES), and
+    complete the slots their look-ahead ran into the encoder's backward section / the next step's first slot once per step
+    (ring_complete_lookahead).  The full-width network as a half-precision checkpoint, with and without the structure
+    encoder, a batch of several workgroup rounds (the softplus kernels walk their blocks with a persistent grid: the ring
+    restarts per block), 25 free-running steps: bit-identical to the three-term kernels, which fetch everything."""
+    torch = torch_cuda
+    from posendf_amd import PoseNDF, amass_config, synth
+    sd = {k: v.astype(np.float16).astype(np.float32) for k, v in synth.make_weights(5, 2.0, 0.1).items()}
+    if not encoder:
+        sd = {k: v for k, v in sd.items() if k.startswith("dfnet.")}
+        rng = np.random.default_rng(5)
+        sd["dfnet.lin0.weight"] = rng.uniform(-0.2, 0.2, (256, 84)).astype(np.float16).astype(np.float32)
+    q0 = torch.from_numpy(synth.make_poses(256 * 64 + 37, seed=9)).cuda()          # > one round of workgroups, ragged tail
+
+    def run():
+        cfg = amass_config(act, "cuda:0")
+        cfg["model"]["StrEnc"]["use"] = encoder
+        if not encoder:
+            cfg["model"]["DFNet"]["in_dim"] = 84
+        cfg["engine"] = {"precision": "f16x3"}
+        net = PoseNDF(cfg)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net.eval()
+        qp, dl = net.project(q0, steps=25)
+        q = q0[:1000].clone().requires_grad_(True)
+        d = net(q, train=False)["dist_pred"]
+        (dq,) = torch.autograd.grad(d.sum(), q)
+        return net._engine_for(q0.device).kernel_name(), qp, dl, d.detach(), dq
+
+    name2, *out2 = run()
+    monkeypatch.setenv("PNDF_THREE_TERMS", "1")
+    name3, *out3 = run()
+    monkeypatch.delenv("PNDF_THREE_TERMS")
+    fam = "softplus" if act == "softplus" else "relu"
+    assert name2 == f"pndf_fused_split2_{fam}_kernel" and name3 == f"pndf_fused_split_{fam}_kernel"
+    for a, b in zip(out2, out3):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
