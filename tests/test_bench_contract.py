@@ -183,3 +183,23 @@ def test_full_size_relations_in_the_committed_bench_line():
         assert d["regions"]["cycles_per_wave_step"] < 1.5 * 404e3
         pw = d["box"]["power_window"]
         assert "error" in pw or 90 < pw["energy_j_per_launch"] < 150
+
+
+def test_diagnose_box_reads_the_committed_lines(capsys):
+    """tools/diagnose_box.py turns a line's `box` / `regions` blocks into a verdict: the profile of record of round 5 ran on
+    a chip that needs 125 J per launch (power-limited 97 % of the time, everything else in range); a line without the blocks
+    (the driver's r04 line) is reported as undiagnosable rather than guessed at."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import diagnose_box
+    old = sys.argv
+    try:
+        sys.argv = ["diagnose_box.py", os.path.join(REPO, "profiles", "r05", "bench_head.json"), os.path.join(REPO, "BENCH_r04.json")]
+        if not os.path.exists(sys.argv[2]):
+            sys.argv.pop()
+        diagnose_box.main()
+    finally:
+        sys.argv = old
+    out = capsys.readouterr().out
+    assert "a power-limited chip that spends 125 J" in out and "weight ring: 11.3 cycles per slot in the DMA wait (within" in out
+    if os.path.exists(os.path.join(REPO, "BENCH_r04.json")):
+        assert "nothing to diagnose from" in out
