@@ -734,9 +734,12 @@ def main():
                 regions["fp32_kernel"] = {k: r32[k] for k in ("cycles_per_wave_step", "effective_sclk_ghz", "ring", "launch_ms")}
         except Exception as exc:       # an analysis aid must not take the line down
             regions = {"error": repr(exc)}
-        box = box_block(dev_index, eng0.lib)
-        if not args.no_power_window:
-            box["power_window"] = power_window(hot, torch.cuda.synchronize, kern_ms)
+        try:
+            box = box_block(dev_index, eng0.lib)
+            if not args.no_power_window:
+                box["power_window"] = power_window(hot, torch.cuda.synchronize, kern_ms)
+        except Exception as exc:           # (a diagnostics block must never cost the line)
+            box = {"error": repr(exc)}
     if side:
         host_ms = host_boundary_ms()
         ms1 = fwd_grad_ms(net)
