@@ -47,10 +47,17 @@ def _cpu_model():
     return "unknown CPU"
 
 
+def _getaffinity(tid=0):
+    try:
+        return os.sched_getaffinity(tid)
+    except AttributeError:      # (platform without the call: the baseline then runs unpinned)
+        return set(range(os.cpu_count() or 1))
+
+
 def _physical_cores():
     """One hardware thread per physical core among the CPUs this process may run on (SMT siblings share a core's FPUs:
     two torch threads on one core are one thread's worth of matmul), in CPU order (= socket by socket)."""
-    allowed = sorted(os.sched_getaffinity(0))
+    allowed = sorted(_getaffinity(0))
     seen, picked = set(), []
     for c in allowed:
         try:
@@ -64,13 +71,61 @@ def _physical_cores():
     return picked, len(allowed)
 
 
+def _cgroup_cpu_quota():
+    """CPUs' worth of CFS quota of this container (cgroup v2 cpu.max / v1 cpu.cfs_quota_us), None when unlimited or unknown:
+    more threads than that are throttled, whatever the affinity mask says."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = float(f.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+def _idlest_first(cpus, window_s=0.25):
+    """`cpus` ordered by how idle each was over a short window (/proc/stat), idlest first.  The GPU boxes' hosts are shared
+    and every tenant starts pinning at CPU 0: a thread of an OpenMP region that shares its core with another tenant's work
+    makes all the others wait at every one of the ~260 barriers of a projection step."""
+    def snap():
+        out = {}
+        try:
+            with open("/proc/stat") as f:
+                for line in f:
+                    if line.startswith("cpu") and line[3].isdigit():
+                        v = line.split()
+                        t = [float(x) for x in v[1:9]]
+                        out[int(v[0][3:])] = (t[3] + t[4], sum(t))      # idle + iowait, total
+        except OSError:
+            pass
+        return out
+    a = snap()
+    time.sleep(window_s)
+    b = snap()
+
+    def busy(c):
+        if c not in a or c not in b or b[c][1] <= a[c][1]:
+            return 0.0
+        return 1.0 - (b[c][0] - a[c][0]) / (b[c][1] - a[c][1])
+    return sorted(cpus, key=lambda c: (round(busy(c), 2), c))
+
+
 def _pin_process(cpus):
     """CPU affinity of EVERY thread of this process (torch's intra-op pool exists already: new masks are not inherited
-    by running threads).  Returns what to pass back to restore."""
-    before = {}
+    by running threads).  Returns what to pass back to `_unpin_process`."""
+    before = {"main": _getaffinity(0), "tasks": {}}
+    if not hasattr(os, "sched_setaffinity"):
+        return before
     for t in os.listdir("/proc/self/task"):
         try:
-            before[int(t)] = os.sched_getaffinity(int(t))
+            before["tasks"][int(t)] = os.sched_getaffinity(int(t))
             os.sched_setaffinity(int(t), cpus)
         except OSError:
             pass
@@ -78,48 +133,53 @@ def _pin_process(cpus):
 
 
 def _unpin_process(before):
-    for t, mask in before.items():
+    """Every task that exists NOW gets its old mask back; tasks born while the process was pinned (torch's intra-op and
+    OpenMP workers spawned during the baseline inherit the narrowed mask) get the main thread's original one."""
+    if not hasattr(os, "sched_setaffinity"):
+        return
+    for t in os.listdir("/proc/self/task"):
         try:
-            os.sched_setaffinity(t, mask)
+            os.sched_setaffinity(int(t), before["tasks"].get(int(t), before["main"]))
         except OSError:
             pass
 
 
-def cpu_baseline(act, sd, proj_steps, budget_s=24.0, runs=3, batch=4096):
+def cpu_baseline(act, sd, proj_steps, budget_s=12.0, runs=3, batch=4096):
     """The reference's CPU PyTorch path (restated in oracle/posendf_torch.py) on this box's host cores, SURVEY.md 8d:
-    B = 4,096 poses (fixed: matmuls large enough for the threads to have work); the process is confined to ONE hardware
-    thread per physical core and the thread count is chosen by a calibration over {8, 16, 32, 64} of those cores (3 steps
-    each, best of two; the box's host is shared), then `runs` timed projections (median reported).
-    Every projection step does identical work, so when the full 100 steps at B = 4,096 do not fit the budget the timed
-    run does fewer steps and is scaled linearly -- the sample says so.  Plus BASELINE.json configs[0] (B = 256, forward
-    only, median of 10)."""
+    B = 4,096 poses (fixed: matmuls large enough for the threads to have work), `torch.set_num_threads(all physical
+    cores)` with the process confined to ONE hardware thread per physical core, `runs` timed projections (median
+    reported).  Every projection step does identical work, so when the full 100 steps at B = 4,096 do not fit the budget
+    the timed run does fewer steps and is scaled linearly -- the sample says so.  Beside it, NOT chosen by it (VERDICT r5
+    item 6): a 2-step calibration of smaller thread counts (the boxes' hosts are shared: fewer threads are often faster).
+    Plus BASELINE.json configs[0] (B = 256, forward only, median of 10)."""
     import statistics
     import torch
     from oracle.posendf_torch import RefNet, project
     from posendf_amd import synth
     phys, visible = _physical_cores()
+    phys = _idlest_first(phys)
+    quota = _cgroup_cpu_quota()
     net = RefNet(act)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     q = torch.from_numpy(synth.make_poses(batch, seed=1234))
-    candidates = sorted({t for t in (8, 16, 32, 64) if t <= len(phys)} or {max(1, len(phys))})
+    # all physical cores this container can actually run on: the affinity mask, capped by the cgroup's CPU quota
+    threads = max(1, min(len(phys), int(quota)) if quota else len(phys))
     load_before = os.getloadavg()
     calib = {}
+    threads_before = torch.get_num_threads()
     restore = _pin_process(set(phys))
+    t_begin = time.perf_counter()
     try:
-        for t in candidates:                                    # calibration: pose-steps per second at B = 4,096, 3 steps
-            _pin_process(set(phys[:t]))
-            torch.set_num_threads(t)
-            project(net, q, 1)                                  # warm-up (thread pool, allocator)
-            best = 0.0
-            for _ in range(2):
-                t0 = time.perf_counter()
-                project(net, q, 3)
-                best = max(best, 3 * batch / (time.perf_counter() - t0))
-            calib[t] = best
-        threads = max(calib, key=calib.get)
         _pin_process(set(phys[:threads]))
         torch.set_num_threads(threads)
-        timed_steps = int(min(proj_steps, max(5, calib[threads] * budget_s / runs / batch)))
+        project(net, q, 1)                                      # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        project(net, q, 1)
+        step_s = time.perf_counter() - t0                       # one projection step of the batch, to size the timed runs
+        calib[threads] = batch / step_s
+        if step_s * 3 > budget_s * 0.8:      # a host so contended that three one-step runs do not fit: one run of one step
+            runs = 1
+        timed_steps = int(min(proj_steps, max(1, budget_s * 0.8 / runs / step_s)))
         times = []
         for _ in range(runs):
             t0 = time.perf_counter()
@@ -129,28 +189,43 @@ def cpu_baseline(act, sd, proj_steps, budget_s=24.0, runs=3, batch=4096):
         # configs[0]: batch = 256, PoseNDF.forward() distance only, PyTorch CPU
         q0 = q[:256]
         with torch.no_grad():
-            for _ in range(3):
-                net(q0)
+            net(q0)
+            t0 = time.perf_counter()
+            net(q0)
+            n0 = 10 if time.perf_counter() - t0 < 0.2 else 3
             f_t = []
-            for _ in range(10):
+            for _ in range(n0):
                 t0 = time.perf_counter()
                 net(q0)
                 f_t.append(time.perf_counter() - t0)
         f_med = statistics.median(f_t)
+        for t in sorted({t for t in (8, 16, 32, 64) if t < threads}):      # beside the figure, never its choice
+            if time.perf_counter() - t_begin > 2.0 * budget_s:
+                break
+            _pin_process(set(phys[:t]))
+            torch.set_num_threads(t)
+            project(net, q, 1)
+            t0 = time.perf_counter()
+            project(net, q, 1)
+            calib[t] = batch / (time.perf_counter() - t0)
     finally:
+        torch.set_num_threads(threads_before)
         _unpin_process(restore)
     scaled = "" if timed_steps == proj_steps else f" ({timed_steps} steps timed, scaled linearly to {proj_steps}: every step does identical work)"
     return {"value": batch / dt, "unit": "projected poses/s", "cores": threads, "kind": "port", "cpu": _cpu_model(),
             "batch": batch, "timed_steps": timed_steps, "runs_s": [round(t, 3) for t in times],
             "runs_spread": round((max(times) - min(times)) / statistics.median(times), 3),
-            "thread_calibration_pose_steps_per_s": {str(t): round(v, 1) for t, v in calib.items()},
-            "pinned_to": f"{threads} distinct physical cores (one hardware thread each) of {len(phys)} visible",
+            "thread_calibration_pose_steps_per_s": {str(t): round(v, 1) for t, v in sorted(calib.items())},
+            "best_calibrated_threads": max(calib, key=calib.get),
+            "pinned_to": f"{threads} distinct physical cores (one hardware thread each, the idlest first) of {visible} visible hardware threads",
+            "cgroup_cpu_quota": quota, "physical_cores_visible": len(phys),
             "host_loadavg_before_after": [[round(x, 1) for x in load_before], [round(x, 1) for x in os.getloadavg()]],
             "sample": f"B={batch} poses x {proj_steps} steps{scaled}, median of {runs} runs = {dt:.1f} s per projection; "
-                      f"PyTorch-CPU restatement of the reference (oracle/posendf_torch.py), {threads} threads pinned to distinct "
-                      f"physical cores (best of {candidates} in a 3-step calibration) on {visible} visible hardware threads of a {_cpu_model()}",
+                      f"PyTorch-CPU restatement of the reference (oracle/posendf_torch.py), {threads} threads = all physical cores"
+                      + (f" within the container's CPU quota of {quota:g}" if quota and quota < len(phys) else "")
+                      + f", one hardware thread each, of {visible} visible hardware threads of a {_cpu_model()}",
             "config0_forward_only": {"workload": "BASELINE.json configs[0]: batch=256, forward() distance only, PyTorch CPU",
-                                     "ms": f_med * 1e3, "poses_per_s": 256 / f_med, "runs": 10}}
+                                     "ms": f_med * 1e3, "poses_per_s": 256 / f_med, "runs": n0}}
 
 
 class GpuTelemetry:
@@ -302,14 +377,69 @@ def box_block(dev_index, lib):
     return out
 
 
-def _amdsmi_metric():
-    """One `amd-smi metric --json` reading of the visible device: the firmware's lifetime accumulators (energy, throttler
-    residencies at ~1 kHz) and the instantaneous power / clock / temperatures.  None when the tool is missing or fails."""
+_AMDSMI_INDEX = {}
+
+
+def _json_after_banner(out):
+    """The JSON document of a tool's stdout that may start with banner / warning lines."""
+    for i, ch in enumerate(out):
+        if ch in "[{":
+            try:
+                return json.loads(out[i:])
+            except ValueError:
+                continue
+    raise ValueError("no JSON document in the output")
+
+
+def device_bdf(dev_index):
+    """PCI address (domain:bus:device.function) of HIP device `dev_index`, as sysfs and amd-smi spell it."""
+    import torch
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        return f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except (AttributeError, RuntimeError):
+        return None
+
+
+def _amdsmi_gpu_index(bdf):
+    """amd-smi's own index of the GPU at PCI address `bdf` (`amd-smi list --json`).  amd-smi enumerates every GPU of the
+    node whatever HIP_/ROCR_VISIBLE_DEVICES say, so entry 0 of an unfiltered `amd-smi metric` need not be cuda:0.
+    None when the tool is missing or no entry matches."""
+    import subprocess
+    if bdf in _AMDSMI_INDEX:
+        return _AMDSMI_INDEX[bdf]
+    idx = None
+    try:
+        out = subprocess.run(["amd-smi", "list", "--json"], capture_output=True, text=True, timeout=40).stdout
+        lst = _json_after_banner(out)
+        if isinstance(lst, dict):
+            lst = lst.get("gpu_data") or lst.get("gpus") or [lst]
+        for k, g in enumerate(lst):
+            if str(g.get("bdf", "")).lower() == str(bdf).lower():
+                idx = int(g.get("gpu", k))
+        if idx is None and len(lst) == 1:      # a one-GPU node: nothing to confuse it with, whatever the listing calls its address
+            idx = int(lst[0].get("gpu", 0))
+    except Exception:
+        idx = None
+    _AMDSMI_INDEX[bdf] = idx
+    return idx
+
+
+def _amdsmi_metric(bdf=None):
+    """One `amd-smi metric --json` reading of the device at PCI address `bdf` (None: the only / first device -- single-GPU
+    tools): the firmware's lifetime accumulators (energy, throttler residencies at ~1 kHz) and the instantaneous power /
+    clock / temperatures.  None when the tool is missing or fails, or when `bdf` is given and amd-smi lists no such device."""
     import subprocess
     try:
-        out = subprocess.run(["amd-smi", "metric", "--json"], capture_output=True, text=True, timeout=40).stdout
-        g = json.loads(out[out.index("{"):])
-        g = (g.get("gpu_data") or [g])[0] if isinstance(g, dict) else g[0]
+        cmd, idx = ["amd-smi", "metric", "--json"], None
+        if bdf is not None:
+            idx = _amdsmi_gpu_index(bdf)
+            if idx is None:
+                return None
+            cmd = ["amd-smi", "metric", "-g", str(idx), "--json"]
+        g = _json_after_banner(subprocess.run(cmd, capture_output=True, text=True, timeout=40).stdout)
+        entries = (g.get("gpu_data") or [g]) if isinstance(g, dict) else g
+        g = next((e for e in entries if idx is not None and e.get("gpu") == idx), entries[0])
         thr = g.get("throttle") or {}
 
         def val(x):
@@ -336,22 +466,25 @@ def _amdsmi_metric():
         return None
 
 
-def power_window(hot, sync, kernel_ms, min_s=3.0, max_s=45.0):
+def power_window(hot, sync, kernel_ms, min_s=3.0, max_s=45.0, bdf=None):
     """Which limiter holds the clock while the measured kernel runs, and what a launch costs in energy: two firmware readings
     (`amd-smi metric`: energy accumulator, throttler residency counters) taken by a helper thread WHILE the main thread keeps
     the kernel running back to back.  Between the readings: mean package power = d energy / d time (the firmware's own ~1 kHz
     sample counter is the clock), fraction of the samples in which the package-power (PPT) / thermal / PROCHOT limiters were
-    active.  Outside the timed region; one GPU, rank 0."""
+    active.  Outside the timed region; one GPU, rank 0.  `bdf`: PCI address of the device the kernel runs on (device_bdf):
+    the readings are taken from THAT device of the node; an error block when amd-smi does not list it."""
     import threading
     reads = []
+    if bdf is not None and _amdsmi_gpu_index(bdf) is None:
+        return {"error": f"amd-smi lists no device at {bdf} (or the tool is missing)"}
 
     def sampler():
-        a = _amdsmi_metric()
+        a = _amdsmi_metric(bdf)
         reads.append(a)
         if a is None:
             return
         time.sleep(min_s)
-        reads.append(_amdsmi_metric())
+        reads.append(_amdsmi_metric(bdf))
     th = threading.Thread(target=sampler, daemon=True)
     t0 = time.perf_counter()
     n = 0
@@ -371,7 +504,7 @@ def power_window(hot, sync, kernel_ms, min_s=3.0, max_s=45.0):
     watts = (b["energy_j"] - a["energy_j"]) / dt
     return {"what": "two `amd-smi metric` readings while the measured kernel runs back to back (launches kept up by the main "
                     "thread); rates between the readings, the firmware's ~1 kHz accumulation counter as the clock",
-            "window_s": dt, "launches_during_window_and_tool_startup": n, "mean_package_w": watts,
+            "device_bdf": bdf, "window_s": dt, "launches_during_window_and_tool_startup": n, "mean_package_w": watts,
             "energy_j_per_launch": watts * kernel_ms * 1e-3,
             "ppt_limited_frac": frac("ppt"), "socket_thermal_limited_frac": frac("socket_thm"), "vr_thermal_limited_frac": frac("vr_thm"),
             "hbm_thermal_limited_frac": frac("hbm_thm"), "prochot_frac": frac("prochot"),
@@ -454,7 +587,10 @@ def main():
                          "headline")
     ap.add_argument("--no-fp32-ref", action="store_true",
                     help="skip the short exact-fp32 and plain-f16 runs reported beside f16x3")
-    ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of CPU baseline work")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work")
+    ap.add_argument("--diagnostics", action="store_true",
+                    help="also emit the analysis blocks that are not part of the contract line: box (+ mem_probe, power_window), "
+                         "regions, f16_single, fp16_checkpoint, host_twin, host_boundary, motion_denoise_config4 (~40 s more)")
     ap.add_argument("--workload", default="project", choices=["project", "denoise"],
                     help="project (default): BASELINE.json configs[2]/[3], the headline; denoise: configs[4], whole sequences "
                          "sharded over the ranks, fused Adam steps of the reference's objective, final gather of the poses")
@@ -462,11 +598,11 @@ def main():
     ap.add_argument("--frames", type=int, default=300, help="--workload denoise: frames per sequence")
     ap.add_argument("--adam-steps", type=int, default=10, help="--workload denoise: Adam steps per harness step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-box", action="store_true", help="skip the `box` / `regions` diagnostics blocks")
-    ap.add_argument("--no-power-window", action="store_true", help="skip the energy / throttler reading of the `box` block (~10 s)")
+    ap.add_argument("--no-box", action="store_true", help="--diagnostics: skip the `box` / `regions` blocks")
+    ap.add_argument("--no-power-window", action="store_true", help="--diagnostics: skip the energy / throttler reading of the `box` block (~10 s)")
     ap.add_argument("--no-gpu-torch-baseline", action="store_true")
     ap.add_argument("--lbs-torch-baseline", action="store_true", help="also time a PyTorch restatement of the body-model terms (4 x 300 frames)")
-    ap.add_argument("--no-motion-denoise", action="store_true", help="skip the configs[4] side block")
+    ap.add_argument("--no-motion-denoise", action="store_true", help="--diagnostics: skip the configs[4] side block")
     ap.add_argument("--no-parity-sample", action="store_true", help="skip the oracle check of a sample of the timed result")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -553,13 +689,24 @@ def main():
             out, _ = md.denoise(theta, iterations=2, steps_per_iter=half, fused=True, record=False)
             return out, None
         out_shape = (T, 69)
-    # receive buffer of the final gather, allocated once: equal blocks go straight into it (all_gather_into_tensor)
-    gathered = torch.empty((rows * world,) + out_shape, device=dev, dtype=torch.float32) if use_dist else None
+    # receive buffer of the final gather, allocated once: equal blocks go straight into it (all_gather_into_tensor).
+    # project: ONE collective carries poses AND last distances, 85 floats per pose (sharding.gather_projected)
+    from posendf_amd.sharding import ROW_FLOATS, gather_projected
+    if args.workload == "project":
+        gathered = torch.empty((rows * world, ROW_FLOATS), device=dev, dtype=torch.float32) if use_dist else None
+    else:
+        gathered = torch.empty((rows * world,) + out_shape, device=dev, dtype=torch.float32) if use_dist else None
+
+    def final_gather(qp, d):                                    # the only collective of a pass: final gather over xGMI
+        if args.workload == "project":
+            gather_projected(qp, d, rows * world, out=gathered)
+        else:
+            all_gather_blocks(qp, rows * world, out=gathered)
 
     def one_pass():
         qp, d = hot()
         if use_dist:
-            all_gather_blocks(qp, rows * world, out=gathered)   # the only collective: final gather over xGMI
+            final_gather(qp, d)
         return qp, d
 
     for _ in range(args.warmup):
@@ -576,7 +723,7 @@ def main():
         qp, d = hot()                                           # bracketed by HIP events on the launch stream
         ev[k][1].record()
         if use_dist:
-            all_gather_blocks(qp, rows * world, out=gathered)
+            final_gather(qp, d)
         ev[k][2].record()
     smi = smi_snapshot() if (tele.src is None and rank == 0 and args.steps) else None      # (launches still in flight)
     if use_dist:
@@ -591,7 +738,11 @@ def main():
     if use_dist:
         # every rank's own numbers travel to rank 0, so that the line PROVES its rank count
         # the gathered buffer holds every rank's block in rank order: each rank finds its own result in its own window
-        own = bool(torch.equal(gathered[rank * rows:(rank + 1) * rows], qp)) if args.steps else None
+        mine_rows = gathered[rank * rows:(rank + 1) * rows]
+        if args.workload == "project":      # [rows, 85]: the pose columns and the distance column of this rank's window
+            own = bool(torch.equal(mine_rows[:, :ROW_FLOATS - 1], qp.reshape(rows, -1)) and torch.equal(mine_rows[:, ROW_FLOATS - 1:], d.reshape(rows, 1))) if args.steps else None
+        else:
+            own = bool(torch.equal(mine_rows, qp)) if args.steps else None
         mine = {"rank": rank, "local_rank": local, "device": dev_index, "pid": os.getpid(), "elapsed_s": elapsed,
                 "kernel_ms": kern_ms, "gather_ms": gather_ms, "rows": rows, "own_block_in_gather": own}
         per_rank = [None] * world
@@ -603,9 +754,16 @@ def main():
             raise SystemExit(f"final gather misplaced a block: {per_rank}")
     dist_info = None
     if use_dist:
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())      # torch's nccl IS RCCL on ROCm
+        except Exception as exc:
+            rccl = f"unavailable ({exc!r})"
+        seen = {(r["pid"], r["device"]) for r in per_rank if r}
         dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices_visible": ndev,
+                     "rccl_version": rccl, "ranks_seen": len(seen), "devices_used": len({r["device"] for r in per_rank if r}),
+                     "collectives_per_pass": 1,
                      "ranks_share_devices": bool(shared and world > ndev), "gather_ms": gather_ms, "per_rank": per_rank,
-                     "gathered_rows": int(gathered.shape[0])}
+                     "gathered_rows": int(gathered.shape[0]), "floats_per_gathered_row": int(gathered[0].numel())}
 
     if args.workload == "denoise":
         if rank == 0:
@@ -721,7 +879,8 @@ def main():
     # after the timed loop (s_memtime stamps per region; the weight ring's counted wait and barrier sampled every 16th slot),
     # and what the box is.  A slow box must be diagnosable from its own line.
     regions = box = None
-    if rank == 0 and world == 1 and args.workload == "project" and not args.no_box:      # (N = 1 line only, like the side runs)
+    diag = bool(args.diagnostics)
+    if rank == 0 and world == 1 and args.workload == "project" and diag and not args.no_box:      # (N = 1 line only, like the side runs)
         eng0 = net._engine_for(dev)
         try:
             if not (args.act == "softplus" and B > 64 * torch.cuda.get_device_properties(dev).multi_processor_count):
@@ -737,11 +896,12 @@ def main():
         try:
             box = box_block(dev_index, eng0.lib)
             if not args.no_power_window:
-                box["power_window"] = power_window(hot, torch.cuda.synchronize, kern_ms)
+                box["power_window"] = power_window(hot, torch.cuda.synchronize, kern_ms, bdf=device_bdf(dev_index))
         except Exception as exc:           # (a diagnostics block must never cost the line)
             box = {"error": repr(exc)}
     if side:
-        host_ms = host_boundary_ms()
+        if diag:
+            host_ms = host_boundary_ms()
         ms1 = fwd_grad_ms(net)
         fwd_grad = {"workload": f"BASELINE.json configs[1]: one forward + d d/d q launch, batch={B}", "precision": precision,
                     "ms": ms1, "pose_steps_per_s": B / (ms1 * 1e-3),
@@ -823,7 +983,7 @@ def main():
                 "gpu_torch_baseline": torch_ref,
                 "finite": bool(torch.isfinite(res).all()), "parity": "unpinned (smplx is third-party and absent; oracle/lbs_np.py)"}
 
-    denoise = motion_denoise_block() if (side and not args.no_motion_denoise and args.act != "softplus") else None
+    denoise = motion_denoise_block() if (side and diag and not args.no_motion_denoise and args.act != "softplus") else None
 
     fp32_ref = f16_ref = sp_ref = h16_ref = None
     if precision == "f16x3" and side and args.act != "softplus":
@@ -831,7 +991,7 @@ def main():
         sp_ref = side_run("f16x3", "softplus")
         sp_ref["frac_of_fp16_mfma_peak"] = sp_ref["achieved_tflops"] / PEAK_F16_MFMA_TFLOPS
         sp_ref.pop("median_rel_diff_of_projected_poses_vs_f16x3")     # another network: not comparable
-    if precision == "f16x3" and side and args.act != "softplus":
+    if precision == "f16x3" and side and diag and args.act != "softplus":
         # a half-precision checkpoint (the same network with its weights rounded to fp16): ANOTHER network, on which the
         # lo*hi term of the split arithmetic vanishes identically and the engine selects the two-term kernels by itself
         h16_ref = side_run("f16x3", weights={k: v.astype(np.float16).astype(np.float32) for k, v in sd.items()})
@@ -842,7 +1002,7 @@ def main():
     if precision == "f16x3" and side:
         fp32_ref = side_run("fp32")
         fp32_ref["frac_of_fp32_mfma_peak"] = fp32_ref["achieved_tflops"] / PEAK_FP32_MFMA_TFLOPS
-    if precision == "f16x3" and side and args.act != "softplus":
+    if precision == "f16x3" and side and diag and args.act != "softplus":
         f16_ref = side_run("f16")
         f16_ref["frac_of_fp16_mfma_peak"] = f16_ref["achieved_tflops"] / PEAK_F16_MFMA_TFLOPS
         f16_ref["note"] = ("reduced precision: operands rounded to fp16, one MFMA per product block; outside the 1e-4 "
@@ -856,8 +1016,8 @@ def main():
         # (tools/gpu_profile.sh -> profiles/traffic.json); bench.py itself cannot run rocprofv3
         traffic, traffic_stale = None, None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
+        from posendf_amd.build_id import source_id
         if os.path.exists(tpath) and B == 65536 and args.proj_steps == 100:
-            from posendf_amd.build_id import source_id
             with open(tpath) as f:
                 entry = json.load(f).get(kname) or {}
             traffic = entry.get("hbm_bytes_per_launch")
@@ -878,10 +1038,16 @@ def main():
             "vs_baseline": None,
             "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[2]: batch={B} poses/GPU, {args.proj_steps}-step "
-                                   f"project() loop, precision={precision}, act={args.act}, amass.yaml arch, "
-                                   f"random-init weights (uniform +-2/sqrt(fan_in), lin6.bias=0.1)",
+            # (the driver's record keeps ~120 characters of a string: what was measured comes first)
+            "config": {"workload": (f"cfg[2] B={B}/GPU x{args.proj_steps} steps {args.act}: "
+                                    + {"f16x3": "f16x3 (fp32-split) timed, fp32 (exact) reported, bf16 not built (f16 dominates it)",
+                                       "fp32": "fp32 (exact) timed", "f16": "f16 (NOT parity grade) timed"}[precision]
+                                    + f"; BASELINE.json configs[2], {args.proj_steps}-step project() loop, amass.yaml arch, random-init "
+                                      "weights (uniform +-2/sqrt(fan_in), lin6.bias=0.1)"),
                        "precision": precision,
+                       "precisions": ("f16x3 = fp32 operands split into fp16 hi+lo, 3 MFMAs per block, fp32 accumulate (timed); "
+                                      "fp32 = exact fp32 MFMA (reported beside it: fp32_exact); bf16 of configs[2] not built: fp16 has "
+                                      "3 more mantissa bits at the same MFMA rate (f16_single under --diagnostics, not parity grade)"),
                        "parity": ("NOT parity grade (fp16-rounded operands)" if precision == "f16" else
                                   "same 1e-4 gates as the fp32 kernel (tests/test_gpu_parity.py, both precisions)"),
                        "global_batch": B * world, "proj_steps": args.proj_steps,
@@ -918,8 +1084,14 @@ def main():
                                     "ms": host_ms, "poses_per_s": B / (host_ms * 1e-3)}
         if fwd_grad is not None:
             out["forward_grad_single_launch"] = fwd_grad
+        rl = out["roofline"]
         if fp32_ref is not None:
+            # the SAME-arithmetic figure (exact fp32 products): first-class, and as scalars of `roofline` so that it survives
+            # in the driver's record next to the split-precision headline
             out["fp32_exact"] = fp32_ref
+            rl["fp32_exact_poses_per_s"] = fp32_ref["poses_per_s_per_gpu"]
+            rl["fp32_exact_kernel_ms"] = fp32_ref["kernel_ms"]
+            rl["fp32_exact_frac_of_fp32_mfma_peak"] = fp32_ref["frac_of_fp32_mfma_peak"]
         if f16_ref is not None:
             out["f16_single"] = f16_ref
         if sp_ref is not None:
@@ -930,6 +1102,27 @@ def main():
                 gts["speedup_of_softplus_kernel"] = sp_ref["poses_per_s_per_gpu"] / gts["value"]
                 sp_ref["gpu_torch_baseline"] = gts
             out["softplus"] = sp_ref
+            # the activation of the reference's own checkpoints gets its own roofline block: the same
+            # algorithmic work, its own kernel, time and fabric traffic (the fp32 derivative scratch)
+            sp_traffic = sp_stale = None
+            if os.path.exists(tpath) and B == 65536 and args.proj_steps == 100:
+                with open(tpath) as f:
+                    e_sp = json.load(f).get(sp_ref["kernel"]) or {}
+                sp_traffic, sp_stale = e_sp.get("hbm_bytes_per_launch"), e_sp.get("source_id") != source_id()
+            out["roofline_softplus"] = {
+                "bound": "mfma", "achieved": sp_ref["achieved_tflops"], "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": sp_ref["achieved_tflops"] / PEAK_F16_MFMA_TFLOPS, "traffic": sp_traffic, "traffic_stale": sp_stale,
+                "kernel": sp_ref["kernel"], "kernel_ms": sp_ref["kernel_ms"], "poses_per_s": sp_ref["poses_per_s_per_gpu"],
+                "algorithmic_bytes_per_launch": B * 676 + 10720 * 1024,
+                "algorithmic_flop_per_launch": B * args.proj_steps * FLOP_PER_POSE_STEP,
+                "derivative_scratch_bytes_per_launch": 2 * 2624 * 4 * B * args.proj_steps,
+                "vs_lrelu_kernel_ms": sp_ref["kernel_ms"] / kern_ms,
+                "what": "one launch of the softplus kernel on the same batch (outside the timed region); traffic = PMC passes of "
+                        "`bench.py --act softplus` (profiles/traffic.json): fp32 derivatives written forward, read backward"}
+            rl["softplus_poses_per_s"] = sp_ref["poses_per_s_per_gpu"]
+            rl["softplus_kernel_ms"] = sp_ref["kernel_ms"]
+            rl["softplus_frac"] = sp_ref["achieved_tflops"] / PEAK_F16_MFMA_TFLOPS
+            rl["softplus_traffic"] = sp_traffic
         if denoise is not None:
             out["motion_denoise_config4"] = denoise
         if h16_ref is not None:
@@ -940,8 +1133,11 @@ def main():
             if fp32_ref is not None:
                 gt["speedup_of_fp32_exact"] = fp32_ref["poses_per_s_per_gpu"] / gt["value"]
             out["gpu_torch_baseline"] = gt
+            rl["gpu_torch_poses_per_s"] = gt["value"]      # (scalars again: the >= 10x denominator stays with the record)
+            rl["speedup_vs_gpu_torch"] = gt["speedup_of_value"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.act, sd, args.proj_steps, args.cpu_budget)
+        if world == 1 and diag:
             # the library's own host twins (pndf_*_cpu, plain C++; what a `train.device: cpu` config runs) on the same sample:
             # product code beside the reference's CPU path, informational -- never `value`, never the baseline
             cfg_h = amass_config(args.act, "cpu")

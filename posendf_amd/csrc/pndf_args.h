@@ -3,6 +3,7 @@
 // another translation unit: both sides include this header, and the static_asserts pin the layout the kernels were
 // written against (a silent mismatch between two copies would corrupt every launch).
 #pragma once
+#include "pndf_experiment.h"
 #include <stddef.h>
 #include <stdint.h>
 

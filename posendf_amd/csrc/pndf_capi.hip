@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/posendf_amd.h"
+#include "../../include/posendf_amd_debug.h"
 #include "pndf_layout.h"
 #include "pndf_args.h"
 #include "pndf_host.h"
@@ -72,7 +73,25 @@ static int fail(pndf_engine* h, int code, const std::string& msg) {
             return fail(h, PNDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-extern "C" const char* pndf_version(void) { return "posendf_amd 0.3 (gfx950; fp32 MFMA 16x16x4 and split-fp16 MFMA 16x16x32; relu, lrelu, softplus)"; }
+// The lab is quarantined from the product (pndf_experiment.h): every translation unit exports one word with a bit per tuning /
+// ablation macro that differs from its product default; a product library reports 0.
+PNDF_EXPORT_EXPERIMENT_WORD(capi)
+extern "C" {
+extern const unsigned pndf_experiment_word_fp32, pndf_experiment_word_fp32_timing, pndf_experiment_word_split,
+    pndf_experiment_word_split_x2, pndf_experiment_word_split_timing, pndf_experiment_word_lbs;
+}
+extern "C" unsigned pndf_experiment_word(void) {
+    return pndf_experiment_word_capi | pndf_experiment_word_fp32 | pndf_experiment_word_fp32_timing | pndf_experiment_word_split |
+           pndf_experiment_word_split_x2 | pndf_experiment_word_split_timing | pndf_experiment_word_lbs;
+}
+extern "C" const char* pndf_version(void) {
+    static const std::string v = [] {
+        char w[16];
+        snprintf(w, sizeof w, "0x%08x", pndf_experiment_word());
+        return std::string("posendf_amd 0.4 (gfx950; fp32 MFMA 16x16x4 and split-fp16 MFMA 16x16x32; relu, lrelu, softplus; experiments=") + w + ")";
+    }();
+    return v.c_str();
+}
 
 extern "C" const char* pndf_last_error(pndf_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 

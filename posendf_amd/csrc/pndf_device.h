@@ -21,10 +21,9 @@ constexpr int SLOT_BYTES = SLOT_TILES * TILE_BYTES;          // 16 KiB
 // constant LDS addresses above 64 KiB would each be materialised in an SGPR, hoisted out of the step loop
 // and spilled.  The DMA ring sits at the bottom so that its M0 base stays below 64 KiB.
 constexpr int FSTRIDE = 132;                                 // floats per pose in the feature buffer (bank skew)
-#ifndef PNDF_RING_SLOTS
-#define PNDF_RING_SLOTS 5      // product: 5 buffers = a slot is fetched FOUR slots ahead.  3 / 4 (look-ahead 2 / 3) are the arms of the
-#endif                         // latency-margin curve (profiles/r05/ring_margin.txt); 6 only with -DPNDF_RING_ALIAS_F (timing only:
-                               // the feature buffer then overlays the pose tile -- WRONG results -- to make room for a sixth buffer)
+// PNDF_RING_SLOTS (pndf_experiment.h): product 5 buffers = a slot is fetched FOUR slots ahead.  3 / 4 (look-ahead 2 / 3) are the arms
+// of the latency-margin curve (profiles/r05/ring_margin.txt); 6 only with -DPNDF_RING_ALIAS_F (timing only: the feature buffer
+// then overlays the pose tile -- WRONG results -- to make room for a sixth buffer)
 constexpr int RING_SLOTS = PNDF_RING_SLOTS;
 static_assert(RING_SLOTS >= 3 && RING_SLOTS <= 6, "ring depth");
 constexpr int MASK_ROWS = 48;                                // u8 [48][256]: x1 8 chunks, x3 32 chunks, x5 4 chunks x 2 bytes
@@ -79,9 +78,7 @@ struct Ring {
     unsigned long long st_wait, st_bar;   // shader cycles spent in the counted vmcnt wait / in the barrier, summed over the SAMPLED slots
     uint32_t st_n, st_k;                  // sampled slots, all slots
 };
-#ifndef PNDF_RING_STAMPS
-#define PNDF_RING_STAMPS 0     // 1: every RING_STAMP_PERIOD-th mid-slot event is bracketed by s_memtime stamps (pndf_kernel*_timing.hip)
-#endif
+// PNDF_RING_STAMPS 1 (the *_timing.hip translation units): every RING_STAMP_PERIOD-th mid-slot event is bracketed by s_memtime stamps
 constexpr uint32_t RING_STAMP_PERIOD = 16;      // 670 slots per step: the sampled positions rotate from step to step
 
 // LDS-DMA of one 16 KiB slot: each wave moves 4 tiles (global_load_lds_dwordx4 = 1 KiB per instruction,
@@ -100,12 +97,11 @@ struct DmaSrc {
 // M0 is declared clobbered and never restored: hipcc treats M0 as a reserved scratch register that it sets right
 // before each of its own uses (there is none in these kernels: the only M0 writes in the ISA are the ones below), so
 // saving / restoring it only costs issue slots.  Pieces 1..3 rely on M0 still holding piece 0's value.
-#ifndef PNDF_ABLATE
-#define PNDF_ABLATE 0     // timing experiments ONLY (wrong results): 1 = no mid-slot barrier, 2 = no slot fetches after the
-#endif                    // first four, 4 = no counted vmcnt wait -- what each ring event costs (profiles/r02/ablation.txt);
-                          // 32 = the backward half of a step walks the forward half's slots in reverse (L2 reuse experiment;
-                          // +64 = its control arm, -DPNDF_WRAP_SLOTS=N = wrapped footprint), 256 / 512 = every tile read /
-                          // slot fetch of the split kernel issued twice (profiles/r02/ab_mirror_walk.txt, ab_additive.txt)
+// PNDF_ABLATE (pndf_experiment.h; timing experiments ONLY, wrong results): 1 = no mid-slot barrier, 2 = no slot fetches after the
+// first four, 4 = no counted vmcnt wait -- what each ring event costs (profiles/r02/ablation.txt); 8 / 16 = no third MFMA term / no
+// lo-tile reads; 32 = the backward half of a step walks the forward half's slots in reverse (L2 reuse experiment; +64 = its control
+// arm, -DPNDF_WRAP_SLOTS=N = wrapped footprint), 256 / 512 = every tile read / slot fetch of the split kernel issued twice
+// (profiles/r02/ab_mirror_walk.txt, ab_additive.txt); 1024 / 2048 = no slot fetch in the backward / forward big phase (round 6)
 __device__ __forceinline__ void ring_dma_piece(const DmaSrc& src, uint32_t dst, int j) {
     if (PNDF_ABLATE & 2) return;
     if (j == 0)
@@ -149,16 +145,10 @@ __device__ __forceinline__ void ring_dma(Ring& r) {
 
 __device__ __forceinline__ void ring_wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // at most two slot fetches (4 pieces each) of this wave may still be in flight
-#ifndef PNDF_SP_DIAG
-#define PNDF_SP_DIAG 0
-#endif
 // Pieces (1 KiB each, per wave) that a TRUNK slot's fetch issues.  4 = all of the wave's four tiles.  2 (the two-term kernels'
 // translation unit, pndf_kernel_split_x2.hip): only the hi tiles -- those kernels run networks whose lo tiles are all zero and
 // never read them, so their half of the stream need not be delivered at all (round 5: the delivery of the weight stream into LDS
 // is a fifth of a launch's energy and what pushes the kernel over the power cap).  Encoder slots and the ring's start always fetch all four.
-#ifndef PNDF_RING_PIECES
-#define PNDF_RING_PIECES 4
-#endif
 static_assert(PNDF_RING_PIECES == 4 || PNDF_RING_PIECES == 2, "pieces per trunk slot");
 // the counted wait before the mid-slot barrier: at most this many of the wave's fetch operations may still be in flight -- the
 // pieces of the slots after the next one, counted with the SMALLEST number a slot can issue (a slot that issued more only makes
@@ -310,9 +300,6 @@ __device__ __forceinline__ float relu_factor(float step, float slope) { return f
 //   returns the computed value (at beta z within rounding of 20 the two agree to an ulp);
 // * (e - (u - 1)) ru puts the rounding of 1 + e back to first order: a saturated-low unit keeps softplus = e / beta, not 0.
 // PNDF_SP_FORM 0: rounds 1-3 (kept for same-box A/B builds).
-#ifndef PNDF_SP_FORM
-#define PNDF_SP_FORM 1
-#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct SpK {            // uniform constants of the activation
     float beta, b2, c, invb;      // beta, beta log2(e), ln 2 / beta, 1 / beta
@@ -350,19 +337,7 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
     return r;
 }
 
-// per-site overrides for bisection builds (default: PNDF_SP_FORM everywhere)
-#ifndef PNDF_SP_FORM_OUT
-#define PNDF_SP_FORM_OUT PNDF_SP_FORM
-#endif
-#ifndef PNDF_SP_FORM_ENC
-#define PNDF_SP_FORM_ENC PNDF_SP_FORM
-#endif
-#ifndef PNDF_SP_FORM_TILES
-#define PNDF_SP_FORM_TILES PNDF_SP_FORM
-#endif
-#ifndef PNDF_SP_FORM_CHUNK
-#define PNDF_SP_FORM_CHUNK PNDF_SP_FORM
-#endif
+// (per-site overrides for bisection builds, PNDF_SP_FORM_{OUT,ENC,TILES,CHUNK}: pndf_experiment.h)
 template <int FORM = PNDF_SP_FORM>
 __device__ __forceinline__ float act_softplus(float z, const SpK& k, float& deriv) {
   if constexpr (FORM == 0) {
@@ -431,9 +406,6 @@ __device__ __forceinline__ void act_softplus4(f32x4& z, const SpK& k, f32x4& der
 // + a 32-bit per-lane byte offset: `global_load/store v_off, .., s[base:base+1]`.  As per-lane 64-bit pointers (round 1)
 // the ~200 slot addresses were computed ahead, hoisted and spilled -- and every spill reload is a VMEM load whose
 // vmcnt(0) drains the ring's DMA.
-#ifndef PNDF_SP_NT
-#define PNDF_SP_NT 0
-#endif
 struct SpRef {
     const char* base;   // uniform: this workgroup's block of the scratch
     uint32_t off;       // per lane: tid * 16

@@ -530,3 +530,8 @@ extern "C" int pndf_kernel_lds_bytes() { return LDS_TOTAL; }
 extern "C" int pndf_kernel_dbg_floats() { return DBG_TOTAL * WG_THREADS; }
 extern "C" long long pndf_kernel_softplus_scratch_floats_per_wg() { return SP_WG_FLOATS; }
 #endif
+
+#ifndef PNDF_TU_TAG
+#define PNDF_TU_TAG fp32
+#endif
+PNDF_EXPORT_EXPERIMENT_WORD(PNDF_TU_TAG)

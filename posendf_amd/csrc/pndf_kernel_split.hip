@@ -12,14 +12,12 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-#ifndef PNDF_SP_DIAG_DOC   // (the macro itself is defined in pndf_device.h, included above: bit 32 lives in the ring)
-#define PNDF_SP_DIAG_DOC 0  // timing diagnostics of the softplus kernels (WRONG results): 1 = no wait for the staged tiles of the backward
-#endif                      // pass, 2 = no staging DMA either (profiles/r03/sp_stage_diag.txt); round 4, forward chunk epilogue: 4 = the
-                            // derivative tiles are not stored, 8 = the three transcendentals of a value are plain multiplies
-                            // 16 = they all go to ONE slot per layer (an L2-resident line), 32 = the ring's counted wait tolerates two more
-                            // operations in flight (pndf_device.h; UNSAFE), 64 = only every other tile is stored, 128 = two 8-byte stores per lane
-                            // instead of one 16-byte store (profiles/r04/sp_forward_diag.txt; the LDS-parking experiment of that file -- tiles
-                            // stored eight at a time, +1.3 % -- was removed again: git history, commit "softplus: asm v_max padded ...")
+// PNDF_SP_DIAG (pndf_experiment.h; timing diagnostics of the softplus kernels, WRONG results): 1 = no wait for the staged tiles of the
+// backward pass, 2 = no staging DMA either (profiles/r03/sp_stage_diag.txt); round 4, forward chunk epilogue: 4 = the derivative tiles are
+// not stored, 8 = the three transcendentals of a value are plain multiplies, 16 = they all go to ONE slot per layer (an L2-resident line),
+// 32 = the ring's counted wait tolerates two more operations in flight (pndf_device.h; UNSAFE), 64 = only every other tile is stored,
+// 128 = two 8-byte stores per lane instead of one 16-byte store (profiles/r04/sp_forward_diag.txt; the LDS-parking experiment of that
+// file -- tiles stored eight at a time, +1.3 % -- was removed again: git history, commit "softplus: asm v_max padded ...")
 
 namespace {
 
@@ -39,9 +37,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // (a, b) -> packed fp16 pairs: hi = rtz(a, b) (one v_cvt_pkrtz), lo = rne(a - hi_a, b - hi_b).  The remainders
 // are exact in fp32; rounding lo to NEAREST keeps the residual error unbiased (+-2^-23 relative) -- with a
 // truncated lo the error of a 1024-term contraction accumulates linearly instead of as a random walk.
-#ifndef PNDF_SPLIT_FOUR
-#define PNDF_SPLIT_FOUR 0
-#endif
 template <bool SINGLE>
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
     if constexpr (SINGLE) {        // plain fp16 operands: round to nearest, no lo part
@@ -183,16 +178,13 @@ __device__ __forceinline__ void dma_begin(DmaPieces& d, Ring& ring, bool loaded)
 // The four pieces of a slot fetch are dealt out behind MFMAs of the tile group that ran the mid-slot events (TN == 8; rounds
 // 1 - 4: two there, two in the next group -- PNDF_DMA_EARLY below).  The first piece sets M0, the others reuse it (M0: see
 // ring_dma_piece; tools/isa_hazards.py checks that nothing else writes it).
-#ifndef PNDF_GROUP_STAMPS
-#define PNDF_GROUP_STAMPS 0   // 1: the instrumented kernel also stamps every group of the (lin2,lin3) loop.  s_memtime returns
-#endif                        // through lgkmcnt, so every stamp drains the tile prefetch: the groups then take ~1,100 cycles
-                              // instead of ~270 (profiles/r02/group_stamps.txt) -- kept only as a documented dead end
-#ifndef PNDF_NT_MODE
-#define PNDF_NT_MODE 0      // cache-policy experiments: 1 = `nt` on the two big phases' slot fetches, 2 = on every slot fetch; 3 .. 6 = sc1 / sc0 sc1 / sc0 / sc1 nt
-#endif
-#ifndef PNDF_DMA_EARLY
-#define PNDF_DMA_EARLY 3    // where the four 1-KiB pieces of a slot fetch are issued (round 5, profiles/r05/ring_margin.txt):
-#endif                      // 0 = behind MFMAs 9, 11 of the group that ran the mid-slot events and of the next one (rounds 1-4: the last
+// (defaults of the three macros below: pndf_experiment.h)
+// PNDF_GROUP_STAMPS 1: the instrumented kernel also stamps every group of the (lin2,lin3) loop.  s_memtime returns through lgkmcnt,
+//     so every stamp drains the tile prefetch: the groups then take ~1,100 cycles instead of ~270 (profiles/r02/group_stamps.txt) --
+//     kept only as a documented dead end
+// PNDF_NT_MODE: cache-policy experiments: 1 = `nt` on the two big phases' slot fetches, 2 = on every slot fetch; 3 .. 6 = sc1 / sc0 sc1 / sc0 / sc1 nt
+// PNDF_DMA_EARLY (product 3): where the four 1-KiB pieces of a slot fetch are issued (round 5, profiles/r05/ring_margin.txt):
+                            // 0 = behind MFMAs 9, 11 of the group that ran the mid-slot events and of the next one (rounds 1-4: the last
                             //     piece leaves ~0.95 slot after the barrier, i.e. has ~2 slot times to land);
                             // 1 = all four in the group of the barrier, behind its MFMAs 8..11 (no tile read shares those slots);
                             // 2 = all four right behind the barrier, MFMAs 1..4 (each next to a tile read)
@@ -211,9 +203,13 @@ __device__ __forceinline__ void dma_begin(DmaPieces& d, Ring& ring, bool loaded)
         asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" POLICY : : "v"(d.src.off), "s"(d.src.base) : "memory"); \
     else                                                                                                                 \
         asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" POLICY : : "v"(d.src.off), "s"(d.src.base) : "memory");
-template <int PIECE, bool BIG = false>
+template <int PIECE, int BIG = 0>      // BIG: 0 = a small phase, 1 = (lin2,lin3), 2 = (lin3^T,lin2^T)
 __device__ __forceinline__ void dma_piece(const DmaPieces& d) {
     if (PNDF_ABLATE & 2) return;
+    // (round 6, timing / energy arms of the "one slot serves both directions" lever -- WRONG results: 1024 = the backward big
+    // phase issues no slot fetch, 2048 = the forward big phase issues none; profiles/r06/shared_slot_arm.txt)
+    if constexpr ((PNDF_ABLATE & 1024) != 0 && BIG == 2) return;
+    if constexpr ((PNDF_ABLATE & 2048) != 0 && BIG == 1) return;
     if constexpr (PNDF_RING_PIECES == 2 && (PIECE & 1) != 0) return;      // two-term kernels: the lo tiles (odd tiles of the wave's window) stay where they are
     if constexpr (PNDF_NT_MODE == 2 || (PNDF_NT_MODE == 1 && BIG)) {
         PNDF_DMA_PIECE(" nt")
@@ -240,7 +236,7 @@ __device__ __forceinline__ void dma_piece(const DmaPieces& d) {
 // One LDS read per MFMA instead of a burst of eight: right after the workgroup barrier all four waves used to issue
 // their bursts at once and sat in the LDS queue with an empty MFMA pipe (tools/ubench/split_rate.hip: barrier cost
 // 150 -> 33 cycles per slot).
-template <int TN, int J, bool BIG = false, int NT = 3>
+template <int TN, int J, int BIG = 0, int NT = 3>
 __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, bool loaded) {
     if constexpr (J == 0) {
         if (loaded) {
@@ -287,9 +283,6 @@ __device__ __forceinline__ void feed(Pair (&nxt)[4], Ring& ring, DmaPieces& dp, 
 //   1  hh_i and hl_i adjacent (they share A = Wh_i), lh last: -2.2 % time, same cycle count
 //   2  as 1, snaking: hh0 hl0 | hl1 hh1 | hh2 hl2 | hl3 hh3 | lh0..3 -- B changes only every second MFMA too: -2.4 % time
 //      (profiles/r02/ab_mfma_order.txt).  Back-to-back MFMAs on one accumulator cost no cycles.
-#ifndef PNDF_MFMA_ORDER
-#define PNDF_MFMA_ORDER 3
-#endif
 //   3  (default) pair-major: hh_i hl_i lh_i back to back -- A = Wh_i kept for two MFMAs AND chains of three MFMAs on one
 //      accumulator (the micro-benchmark sustains 11 % more when every MFMA accumulates onto the result of a just-issued
 //      one: the accumulator need not come from the register file); needs all eight tiles of a group at its start.
@@ -327,7 +320,7 @@ struct SplitPhase {
     static constexpr int AG = AP / 4, BG = BP / 4;    // groups of 4 pairs
     static constexpr int A_TILES = 2 * AP;
     static constexpr int PARTIALS = 1;                // accumulators per chunk tile (3 = one per term)
-    static constexpr bool BIG = (NC >= 32);           // the two 4 MiB phases (lin2,lin3) / (lin3^T,lin2^T)
+    static constexpr int BIG = (NC >= 32) ? (BWD ? 2 : 1) : 0;      // the two 4 MiB phases: 1 = (lin2,lin3), 2 = (lin3^T,lin2^T)
     static_assert(AP % 4 == 0 && BP % 4 == 0 && A_TILES % SLOT_TILES == 0, "group / slot alignment");
     static_assert(!SP || PARTIALS == 1, "the softplus epilogue reads one accumulator per chunk tile");
 
@@ -1230,3 +1223,8 @@ extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split2_so
     pndf_fused_split_body<false, 2, true>(args);
 }
 #endif
+
+#ifndef PNDF_TU_TAG
+#define PNDF_TU_TAG split
+#endif
+PNDF_EXPORT_EXPERIMENT_WORD(PNDF_TU_TAG)

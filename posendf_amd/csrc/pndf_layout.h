@@ -16,6 +16,7 @@
 // B: R_A -> N_B rows accumulated in registers), so the wider intermediate (256 / 1024 / 256 wide) is
 // never materialised beyond one chunk.  Backward phases use the transposed matrices.
 #pragma once
+#include "pndf_experiment.h"
 
 namespace pndf {
 
@@ -92,9 +93,7 @@ static_assert(2 * (phase_a_pairs(PHASES[2]) + phase_b_pairs(PHASES[2])) == phase
 
 // Experiment switch (split-precision stream and kernels only): chunk size of the two big phases (lin2,lin3) / (lin3^T,lin2^T).
 // 2 = product; 4 = part B's accumulators get chains of six MFMAs per chunk instead of three (DESIGN.md Appendix C 7.1 b).
-#ifndef PNDF_BIG_CT
-#define PNDF_BIG_CT 2
-#endif
+// (PNDF_BIG_CT: default in pndf_experiment.h)
 enum Precision { PREC_FP32 = 0, PREC_F16X3 = 1, PREC_F16 = 2 };
 
 // bias block (floats) copied to LDS: b0..b5, then w6 (64), then b6

@@ -788,18 +788,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int KB = PNDF_LBS_KB, SBB = PNDF_LBS_SB_BYTES, PLANE = PNDF_LBS_SB_PLANE;
-#ifndef PNDF_LBS_DIAG
-#define PNDF_LBS_DIAG 0     // timing diagnostics (WRONG results): 1 = no wait for the model fetch, 2 = no fetch, 4 = no barrier,
-#endif                      // 8 = no operand splits in the reverse pass, 16 / 32 = no forward / reverse tile reads after the first, 64 = no reverse MFMAs
-#ifndef PNDF_LBS_FLA
-#define PNDF_LBS_FLA 2      // forward steps / reverse row tiles whose LDS reads are in flight ahead of the MFMAs that use them
-#endif
-#ifndef PNDF_LBS_RLA
-#define PNDF_LBS_RLA 1
-#endif
-#ifndef PNDF_LBS_PAIR_READS
-#define PNDF_LBS_PAIR_READS 0
-#endif
+// (defaults: pndf_experiment.h)  PNDF_LBS_DIAG: timing diagnostics (WRONG results): 1 = no wait for the model fetch, 2 = no fetch,
+// 4 = no barrier, 8 = no operand splits in the reverse pass, 16 / 32 = no forward / reverse tile reads after the first, 64 = no reverse MFMAs
+// PNDF_LBS_FLA / PNDF_LBS_RLA: forward steps / reverse row tiles whose LDS reads are in flight ahead of the MFMAs that use them
 
 __device__ __forceinline__ f32x4 mf16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 // (a, b) -> packed fp16 pairs: hi = rtz(a, b), lo = rne(a - hi_a, b - hi_b); the remainders are exact in fp32
@@ -1845,3 +1836,5 @@ extern "C" int pndf_lbs_backward(pndf_lbs_handle h, const float* theta, const fl
     a.theta = theta; a.g_verts = g_verts; a.g_joints = g_joints; a.g_theta = g_theta; a.S = 1; a.T = (int)N;
     return lbs_launch(h, 2, a, workspace, stream);
 }
+
+PNDF_EXPORT_EXPERIMENT_WORD(lbs)

@@ -12,6 +12,8 @@
 
 #include <vector>
 
+#include "../../include/posendf_amd_debug.h"
+#include "pndf_experiment.h"
 #include "pndf_host.h"
 
 namespace {

@@ -128,6 +128,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.pndf_last_error.argtypes = [H]
     lib.pndf_last_error.restype = c_char_p
     lib.pndf_version.restype = c_char_p
+    lib.pndf_experiment_word.restype = ctypes.c_uint
     lib.pndf_kernel_name.argtypes = [H]
     lib.pndf_kernel_name.restype = c_char_p
     for name in ("pndf_create", "pndf_destroy", "pndf_load_weights", "pndf_forward", "pndf_forward_grad",
@@ -136,9 +137,27 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     return lib
 
 
+# bring-up / profiling / measurement aids: include/posendf_amd_debug.h, NOT the drop-in boundary
+DEBUG_EXPORTS = ("pndf_debug_forward_grad", "pndf_debug_floats", "pndf_debug_project_timing", "pndf_debug_timing_regions",
+                 "pndf_debug_timing_layout", "pndf_debug_mem_probe", "pndf_debug_ring_stream")
+# per-translation-unit experiment words (csrc/pndf_experiment.h): data symbols, all zero in a product build
+EXPERIMENT_WORDS = ("pndf_experiment_word_capi", "pndf_experiment_word_fp32", "pndf_experiment_word_fp32_timing", "pndf_experiment_word_split",
+                    "pndf_experiment_word_split_x2", "pndf_experiment_word_split_timing", "pndf_experiment_word_lbs")
+
+
+def experiment_word(lib=None) -> int:
+    """OR of the library's per-translation-unit experiment words, read from the data symbols themselves (not through
+    pndf_experiment_word(), which a lab build could have touched): 0 for a product build."""
+    lib = lib or load_library()
+    w = 0
+    for name in EXPERIMENT_WORDS:
+        w |= int(ctypes.c_uint.in_dll(lib, name).value)
+    return w
+
+
+# include/posendf_amd.h, the public header
 EXPORTS = ("pndf_default_config", "pndf_create", "pndf_destroy", "pndf_load_weights", "pndf_forward",
-           "pndf_forward_grad", "pndf_project", "pndf_debug_forward_grad", "pndf_debug_floats",
-           "pndf_debug_project_timing", "pndf_debug_timing_regions", "pndf_debug_timing_layout", "pndf_debug_mem_probe", "pndf_debug_ring_stream",
+           "pndf_forward_grad", "pndf_project", "pndf_experiment_word",
            "pndf_packed_sizes", "pndf_pack_host", "pndf_pack_host_split", "pndf_aa2quat", "pndf_denoise_update", "pndf_denoise_update_body", "pndf_denoise_update_w", "pndf_lbs_terms_grad_w", "pndf_quat_topk",
            "pndf_lbs_create", "pndf_lbs_destroy", "pndf_lbs_set_precision", "pndf_lbs_precision", "pndf_lbs_num_joints", "pndf_lbs_num_vertices", "pndf_lbs_workspace_floats",
            "pndf_lbs_forward", "pndf_lbs_terms_grad", "pndf_lbs_backward", "pndf_lbs_packed_floats", "pndf_lbs_pack_host", "pndf_lbs_packed_split_bytes", "pndf_lbs_pack_split_host",

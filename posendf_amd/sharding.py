@@ -37,6 +37,7 @@ def all_gather_blocks(x: torch.Tensor, total: int, group=None, out: torch.Tensor
         assert x.shape[0] == total // world, (x.shape, total, world)
         if out is None:
             out = x.new_empty((total,) + tuple(x.shape[1:]))
+        COLLECTIVES["all_gather_into_tensor"] += 1
         dist.all_gather_into_tensor(out, x, group=group)
         return out
     rows = -(-total // world)                  # the first total % world ranks hold `rows`, the others rows - 1
@@ -44,6 +45,7 @@ def all_gather_blocks(x: torch.Tensor, total: int, group=None, out: torch.Tensor
     if x.shape[0] < rows:
         pad = torch.cat([x, x.new_zeros((rows - x.shape[0],) + tuple(x.shape[1:]))])
     buf = x.new_empty((world * rows,) + tuple(x.shape[1:]))
+    COLLECTIVES["all_gather_into_tensor"] += 1
     dist.all_gather_into_tensor(buf, pad, group=group)
     parts = []
     for r in range(world):
@@ -56,11 +58,36 @@ def all_gather_blocks(x: torch.Tensor, total: int, group=None, out: torch.Tensor
     return res
 
 
-def project_sharded(project_fn, q_shard: torch.Tensor, steps: int, total: int, group=None):
-    """project_fn(q_shard, steps) -> (q_out, d_last) on this rank's block, then the single final gather.
-    Returns (q_all [total,21,4], d_all [total,1]) on every rank."""
+ROW_FLOATS = 85      # one projected pose on the wire: 84 quaternion components + its last distance (SURVEY.md 8e)
+
+
+def pack_rows(q_out: torch.Tensor, d_last: torch.Tensor) -> torch.Tensor:
+    """[rows,21,4] poses + [rows,1] distances -> ONE [rows,85] send buffer, so that the final gather is one collective
+    with one message per rank (22.3 MB for 65,536 poses) instead of two (a 22 MB and a 0.26 MB one)."""
+    rows = q_out.shape[0]
+    return torch.cat([q_out.reshape(rows, ROW_FLOATS - 1), d_last.reshape(rows, 1).to(q_out.dtype)], dim=1)
+
+
+def unpack_rows(rows85: torch.Tensor):
+    """Views (no copy) into a gathered [total,85] buffer: poses [total,21,4] (row stride 85) and distances [total,1]."""
+    return rows85[:, :ROW_FLOATS - 1].unflatten(1, (21, 4)), rows85[:, ROW_FLOATS - 1:]
+
+
+COLLECTIVES = {"all_gather_into_tensor": 0}      # calls issued by this module (the tests assert ONE per projection pass)
+
+
+def gather_projected(q_out: torch.Tensor, d_last: torch.Tensor, total: int, group=None, out: torch.Tensor | None = None):
+    """The single final collective of the projection path: every rank contributes its block of (pose, distance) rows,
+    every rank receives all of them in rank order.  `out`: a preallocated [total,85] receive buffer (bench.py allocates
+    it once).  Returns (q_all [total,21,4], d_all [total,1]) as views into the receive buffer."""
+    return unpack_rows(all_gather_blocks(pack_rows(q_out, d_last), total, group, out=out))
+
+
+def project_sharded(project_fn, q_shard: torch.Tensor, steps: int, total: int, group=None, out: torch.Tensor | None = None):
+    """project_fn(q_shard, steps) -> (q_out, d_last) on this rank's block, then the single final gather (ONE
+    all_gather_into_tensor of 85 floats per pose).  Returns (q_all [total,21,4], d_all [total,1]) on every rank."""
     q_out, d_last = project_fn(q_shard, steps)
-    return all_gather_blocks(q_out, total, group), all_gather_blocks(d_last, total, group)
+    return gather_projected(q_out, d_last, total, group, out=out)
 
 
 def denoise_sharded(optimize_fn, theta_shard: torch.Tensor, total_sequences: int, group=None):

@@ -18,14 +18,64 @@ def lib():
     return engine.load_library()
 
 
+def _declared(header):
+    return set(re.findall(r"\b(pndf_[a-z0-9_]+)\s*\(", open(os.path.join(REPO, "include", header)).read()))
+
+
 def test_exports_match_header(lib):
-    hdr = open(os.path.join(REPO, "include", "posendf_amd.h")).read()
-    declared = set(re.findall(r"\b(pndf_[a-z0-9_]+)\s*\(", hdr))
+    declared = _declared("posendf_amd.h")
     assert declared, "no declarations found"
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     from posendf_amd import engine
     assert set(engine.EXPORTS) == declared
+
+
+def test_debug_entry_points_live_in_their_own_header(lib):
+    """the drop-in boundary carries no bring-up / profiling entry point -- those are declared in
+    include/posendf_amd_debug.h, which a maintainer binding the library never includes."""
+    from posendf_amd import engine
+    public = open(os.path.join(REPO, "include", "posendf_amd.h")).read()
+    assert "debug" not in public.lower()
+    dbg = _declared("posendf_amd_debug.h")
+    assert dbg == set(engine.DEBUG_EXPORTS) and all(n.startswith("pndf_debug_") for n in dbg)
+    assert not (dbg & set(engine.EXPORTS))
+    for name in dbg:
+        assert hasattr(lib, name), f"{name} declared in the debug header but not exported"
+
+
+def test_product_library_carries_no_experiment(lib, tmp_path):
+    """The lab is quarantined from the product (csrc/pndf_experiment.h): every translation unit of the library exports one
+    word with a bit per tuning / ablation macro that differed from its product default at build time; all of them are 0 in
+    the library the package loads, pndf_version() says so, and an experiment macro without the umbrella does not compile."""
+    import subprocess
+    from posendf_amd import engine
+    for name in engine.EXPERIMENT_WORDS:
+        assert ctypes.c_uint.in_dll(lib, name).value == 0, name
+    assert engine.experiment_word(lib) == 0 and lib.pndf_experiment_word() == 0
+    assert b"experiments=0x00000000" in lib.pndf_version()
+    hdr = os.path.join(REPO, "posendf_amd", "csrc", "pndf_experiment.h")
+    cc = ["gcc", "-x", "c", "-fsyntax-only", hdr]
+    assert subprocess.run(cc, capture_output=True).returncode == 0
+    for macro in ("PNDF_ABLATE=2", "PNDF_SP_DIAG=4", "PNDF_RING_ALIAS_F", "PNDF_NT_MODE=1", "PNDF_RING_SLOTS=4", "PNDF_DMA_EARLY=0",
+                  "PNDF_LBS_DIAG=1", "PNDF_EXP_LO_BITS=4", "PNDF_RING_PIECES=2", "PNDF_RING_STAMPS=1"):
+        bad = subprocess.run(cc + ["-D" + macro], capture_output=True, text=True)
+        assert bad.returncode != 0 and "PNDF_EXPERIMENT" in bad.stderr, macro
+        assert subprocess.run(cc + ["-D" + macro, "-DPNDF_EXPERIMENT=1"], capture_output=True).returncode == 0, macro
+    # the word itself: a probe translation unit built with an arm set reports the arm's bit and the umbrella's
+    src = tmp_path / "word.c"
+    src.write_text('#include "pndf_experiment.h"\n#include <stdio.h>\nint main(void) { printf("%08x\\n", PNDF_EXPERIMENT_WORD); return 0; }\n')
+    exe = tmp_path / "word"
+    inc = ["-I", os.path.dirname(hdr)]
+    for flags, want in (([], "00000000"), (["-DPNDF_EXPERIMENT=1", "-DPNDF_ABLATE=1024"], "80000001"),
+                        (["-DPNDF_EXPERIMENT=1", "-DPNDF_SP_DIAG=32", "-DPNDF_DMA_EARLY=0"], "80000202"),
+                        (["-DPNDF_TU_RING_PIECES=2", "-DPNDF_TU_RING_STAMPS=1"], "00000000")):      # a wrapper unit's structural values
+        subprocess.run(["gcc", *inc, *flags, str(src), "-o", str(exe)], check=True)
+        assert subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip() == want, flags
+    # and the build entry refuses flags for the product path
+    import __graft_entry__ as ge
+    with pytest.raises(ValueError, match="product library takes no compile flags"):
+        ge.build_library(ge.LIB, flags=["-DPNDF_ABLATE=2"])
 
 
 def test_default_config(lib):
@@ -186,8 +236,8 @@ def test_header_is_plain_c(tmp_path):
     if gcc is None:
         pytest.skip("no gcc")
     src = tmp_path / "use_header.c"
-    refs = "\n".join(f"    (void)&{name};" for name in engine.EXPORTS)
-    src.write_text('#include "posendf_amd.h"\nint main(void) {\n' + refs + "\n    return sizeof(pndf_config) > 0 ? 0 : 1;\n}\n")
+    refs = "\n".join(f"    (void)&{name};" for name in engine.EXPORTS + engine.DEBUG_EXPORTS)
+    src.write_text('#include "posendf_amd.h"\n#include "posendf_amd_debug.h"\nint main(void) {\n' + refs + "\n    return sizeof(pndf_config) > 0 ? 0 : 1;\n}\n")
     r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(REPO, "include"),
                         str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr

@@ -60,3 +60,32 @@ def test_power_window_rates(monkeypatch):
     assert r["socket_thermal_limited_frac"] == 0.0 and r["prochot_frac"] == 0.0 and launches
     monkeypatch.setattr(subprocess, "run", lambda *a, **k: (_ for _ in ()).throw(OSError("no such tool")))
     assert "error" in bench.power_window(lambda: None, lambda: None, kernel_ms=88.0, min_s=0.01, max_s=1.0)
+
+
+def test_readings_follow_the_pci_address(monkeypatch):
+    """on a multi-GPU node amd-smi lists every GPU whatever HIP_VISIBLE_DEVICES says; the readings must come
+    from the device the kernel runs on (matched by PCI address), and an unknown address is an error block, never entry 0."""
+    listing = [{"gpu": 0, "bdf": "0000:05:00.0"}, {"gpu": 3, "bdf": "0000:72:00.0"}]
+    other = json.loads(json.dumps(READING))
+    other["gpu_data"][0]["gpu"] = 3
+    other["gpu_data"][0]["power"]["socket_power"]["value"] = 777
+    calls = []
+
+    class R:
+        def __init__(self, out):
+            self.stdout = out
+
+    def run(cmd, *a, **k):
+        calls.append(cmd)
+        if cmd[1] == "list":
+            return R(json.dumps(listing))
+        assert cmd[1:4] == ["metric", "-g", "3"], cmd
+        return R(json.dumps(other))
+    monkeypatch.setattr(subprocess, "run", run)
+    bench._AMDSMI_INDEX.clear()
+    assert bench._amdsmi_gpu_index("0000:72:00.0") == 3
+    assert bench._amdsmi_metric("0000:72:00.0")["socket_power_w"] == 777.0
+    assert bench._amdsmi_metric("0000:99:00.0") is None
+    r = bench.power_window(lambda: None, lambda: None, kernel_ms=88.0, min_s=0.01, max_s=1.0, bdf="0000:99:00.0")
+    assert "error" in r and "0000:99:00.0" in r["error"]
+    bench._AMDSMI_INDEX.clear()

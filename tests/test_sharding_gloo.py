@@ -29,6 +29,7 @@ def _worker(rank, world, port, total, steps, outdir):
     import torch.distributed as dist
     from oracle import posendf_np as onp
     from posendf_amd import synth
+    from posendf_amd import sharding
     from posendf_amd.sharding import project_sharded, shard_bounds
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -41,18 +42,22 @@ def _worker(rank, world, port, total, steps, outdir):
         qo, d = onp.project(q.numpy(), sd, steps=steps)
         return torch.from_numpy(qo), torch.from_numpy(d)
 
+    before = sharding.COLLECTIVES["all_gather_into_tensor"]
     q, d = project_sharded(project_fn, torch.from_numpy(q_all[lo:hi]), steps, total)
+    # ONE collective per projection pass -- poses and distances travel together, 85 floats per pose
+    assert sharding.COLLECTIVES["all_gather_into_tensor"] - before == 1
+    assert q.shape == (total, 21, 4) and d.shape == (total, 1) and q.stride() == (85, 4, 1)      # views into the one receive buffer
     np.save(os.path.join(outdir, f"q_{rank}.npy"), q.numpy())
     np.save(os.path.join(outdir, f"d_{rank}.npy"), d.numpy())
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [64, 37])
-def test_two_rank_gloo_matches_unsharded(tmp_path, total):
+@pytest.mark.parametrize("total,world", [(64, 2), (37, 2), (64, 4), (43, 4)])
+def test_gloo_ranks_match_unsharded(tmp_path, total, world):
     from oracle import posendf_np as onp
     from posendf_amd import synth
-    world, steps = 2, 3
-    port = 29500 + (os.getpid() % 2000) + total
+    steps = 3
+    port = 29500 + (os.getpid() % 2000) + total + 100 * world
     mp.spawn(_worker, args=(world, port, total, steps, str(tmp_path)), nprocs=world, join=True)
     q_ref, d_ref = onp.project(synth.make_poses(total, seed=77), golden_weights("live"), steps=steps)
     for r in range(world):

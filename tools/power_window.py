@@ -41,7 +41,7 @@ def main():
         passes = 1000
         assert lib.pndf_debug_ring_stream(0, passes, ctypes.byref(sec)) == 0
         idle = bench._amdsmi_metric()
-        r = bench.power_window(lambda: lib.pndf_debug_ring_stream(0, passes, ctypes.byref(sec)), lambda: None, sec.value * passes * 1e3)
+        r = bench.power_window(lambda: lib.pndf_debug_ring_stream(0, passes, ctypes.byref(sec)), lambda: None, sec.value * passes * 1e3, bdf=bench.device_bdf(0))
         r.pop("what", None)
         cus = torch.cuda.get_device_properties(0).multi_processor_count
         bytes_per_call = passes * 670 * 16384 * cus
@@ -70,7 +70,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 5
-            r = bench.power_window(lambda: bm.terms_grad(theta, j0, 2, out=out), torch.cuda.synchronize, ms)
+            r = bench.power_window(lambda: bm.terms_grad(theta, j0, 2, out=out), torch.cuda.synchronize, ms, bdf=bench.device_bdf(0))
             r.pop("what", None)
             print(json.dumps({"load": f"pndf_lbs_terms_grad {S} x {T} frames, {prec}", "kernel_ms": ms, **r}), flush=True)
         return
@@ -96,7 +96,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
-        r = bench.power_window(lambda: net.project(q, steps=100), torch.cuda.synchronize, ms)
+        r = bench.power_window(lambda: net.project(q, steps=100), torch.cuda.synchronize, ms, bdf=bench.device_bdf(0))
         r.pop("what", None)
         print(json.dumps({"kernel": net._engine_for(q.device).kernel_name(), "kernel_ms": ms, **r}), flush=True)
 
