@@ -31,6 +31,38 @@ static_assert(offsetof(PndfKernelArgs, stream) == 32 && offsetof(PndfKernelArgs,
               offsetof(PndfKernelArgs, steps) == 64 && offsetof(PndfKernelArgs, slope) == 72 &&
               offsetof(PndfKernelArgs, scratch) == 80 && offsetof(PndfKernelArgs, noenc) == 92, "PndfKernelArgs layout");
 
+// ---- runtime-planned DFNet (pndf_generic.hip): any depth / width the reference's `dims` list can describe
+constexpr int PNDF_GEN_MAXLIN = 8;         // linear layers (n_dims 3 .. 9)
+constexpr int PNDF_GEN_NTB = 4;            // output tiles of one register block
+constexpr int PNDF_GEN_XTILES = 64;        // tiles of the widest activation (1024 rows)
+struct PndfGenericArgs {
+    const float* q_in;      // [B,84]
+    float* q_out;           // [B,84]
+    float* d_out;           // [B]
+    const float* grad_out;  // [B] or null
+    const char* enc_stream; // encoder forward section | backward section (PNDF_GEN_ENC_SECTION_TILES KiB each), null without encoder
+    const float* bias;      // BIAS_FLOATS block (the encoder's biases)
+    const float* wfwd;      // forward weight tiles of all layers, [block][k tile][tile of the block] per layer
+    const float* wbwd;      // the same for the transposed matrices
+    const float* lbias;     // biases, each layer padded to whole blocks of tiles
+    float* scratch;         // gridDim.x * wg_tiles tile slots of 4 KiB: activations (ping, pong), derivative factors per layer
+    long long B;
+    int steps, mode;
+    float slope, beta;
+    int noenc, nlayers;
+    int kt[PNDF_GEN_MAXLIN];     // contraction tiles of the forward pass = ceil(in / 16)
+    int nt[PNDF_GEN_MAXLIN];     // contraction tiles of the backward pass = ceil(out / 16)
+    int ktp[PNDF_GEN_MAXLIN];    // kt, nt rounded up to whole blocks: output tiles of the backward / forward pass
+    int ntp[PNDF_GEN_MAXLIN];
+    int wf_off[PNDF_GEN_MAXLIN]; // first tile of the layer in wfwd / wbwd
+    int wb_off[PNDF_GEN_MAXLIN];
+    int b_off[PNDF_GEN_MAXLIN];  // first float of the layer in lbias
+    int d_off[PNDF_GEN_MAXLIN];  // first tile slot of the layer's derivative factors in the workgroup's scratch
+    int enc_d_off;               // softplus: first tile slot of the encoder's 42 derivative tiles
+    int wg_tiles;                // tile slots per workgroup
+};
+constexpr int PNDF_GEN_ENC_SECTION_TILES = 48 + 4 * 16;      // the encoder's 3 slots + what the ring fetches ahead (4 slots)
+
 struct PndfDenoiseArgs {
     const float* theta_in; // [S,T,69] current poses (read: a frame's neighbours belong to other threads / workgroups)
     float* theta_out;      // [S,T,69] updated poses (the caller swaps the two buffers every step)

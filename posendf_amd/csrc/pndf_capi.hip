@@ -15,6 +15,8 @@
 #include "pndf_layout.h"
 #include "pndf_args.h"
 #include "pndf_host.h"
+#include "pndf_pack.h"
+#include "pndf_generic.h"
 
 using namespace pndf;
 
@@ -54,6 +56,8 @@ struct pndf_engine {
     hipEvent_t sp_done = nullptr;
     void* sp_stream = nullptr;
     bool sp_pending = false;
+    // any DFNet that is not shaped like configs/amass.yaml (another depth, wider layers): the runtime-planned path, pndf_generic.hip
+    PndfGeneric* generic = nullptr;
     std::string err;
 };
 
@@ -78,11 +82,11 @@ static int fail(pndf_engine* h, int code, const std::string& msg) {
 PNDF_EXPORT_EXPERIMENT_WORD(capi)
 extern "C" {
 extern const unsigned pndf_experiment_word_fp32, pndf_experiment_word_fp32_timing, pndf_experiment_word_split,
-    pndf_experiment_word_split_x2, pndf_experiment_word_split_timing, pndf_experiment_word_lbs;
+    pndf_experiment_word_split_x2, pndf_experiment_word_split_timing, pndf_experiment_word_lbs, pndf_experiment_word_generic;
 }
 extern "C" unsigned pndf_experiment_word(void) {
     return pndf_experiment_word_capi | pndf_experiment_word_fp32 | pndf_experiment_word_fp32_timing | pndf_experiment_word_split |
-           pndf_experiment_word_split_x2 | pndf_experiment_word_split_timing | pndf_experiment_word_lbs;
+           pndf_experiment_word_split_x2 | pndf_experiment_word_split_timing | pndf_experiment_word_lbs | pndf_experiment_word_generic;
 }
 extern "C" const char* pndf_version(void) {
     static const std::string v = [] {
@@ -108,16 +112,20 @@ extern "C" void pndf_default_config(pndf_config* cfg, int32_t act, float beta) {
 
 static int check_config(pndf_engine* h, const pndf_config* cfg) {
     if (!cfg) return fail(h, PNDF_ERR_BAD_ARG, "cfg is null");
-    if (cfg->num_joints != NJ || cfg->n_dims != NLIN + 1)
-        return fail(h, PNDF_ERR_UNSUPPORTED, "only the 21-joint, 7-layer configs/amass.yaml architecture is implemented");
-    // The kernels are laid out for configs/amass.yaml (126 | 84, 256, 512, 1024, 512, 256, 64, 1).  A DFNet of the same
+    if (cfg->num_joints != NJ)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "only the 21-joint structure of get_parent_mapping('smpl') is implemented");
+    // The fused kernels are laid out for configs/amass.yaml (126 | 84, 256, 512, 1024, 512, 256, 64, 1).  A DFNet of the same
     // depth whose hidden layers are NARROWER runs on them zero-padded (padded units have zero outgoing weights, so they
-    // reach neither the distance nor its gradient, whatever the activation); anything wider or of another depth is refused.
-    if ((cfg->dims[0] != DIMS[0] && cfg->dims[0] != NOENC_IN) || cfg->dims[NLIN] != 1)
+    // reach neither the distance nor its gradient, whatever the activation); any other `dims` list the reference can build
+    // (net_modules.py:14-28) -- 2 .. 8 linear layers, hidden widths up to 1024 -- runs on the runtime-planned kernels of
+    // pndf_generic.hip (exact fp32 whatever precision was asked for).  Only beyond that is a configuration refused.
+    if (cfg->n_dims < 3 || cfg->n_dims > MAXLIN + 1)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "DFNet depth: n_dims must be 3 .. 9 (1 .. 7 hidden layers + the output layer)");
+    if ((cfg->dims[0] != DIMS[0] && cfg->dims[0] != NOENC_IN) || cfg->dims[cfg->n_dims - 1] != 1)
         return fail(h, PNDF_ERR_UNSUPPORTED, "DFNet in_dim must be 126 (StrEnc.use=True) or 84 (False), its output 1");
-    for (int i = 1; i < NLIN; ++i)
-        if (cfg->dims[i] < 1 || cfg->dims[i] > DIMS[i])
-            return fail(h, PNDF_ERR_UNSUPPORTED, "DFNet hidden widths must not exceed 256,512,1024,512,256,64 (configs/amass.yaml)");
+    for (int i = 1; i < cfg->n_dims - 1; ++i)
+        if (cfg->dims[i] < 1 || cfg->dims[i] > MAX_WIDTH)
+            return fail(h, PNDF_ERR_UNSUPPORTED, "DFNet hidden widths must be 1 .. 1024");
     for (int i = 0; i < NJ; ++i)
         if (cfg->parent[i] != PARENT[i]) return fail(h, PNDF_ERR_UNSUPPORTED, "parent table must be get_parent_mapping('smpl')");
     if (cfg->act != PNDF_ACT_RELU && cfg->act != PNDF_ACT_LRELU && cfg->act != PNDF_ACT_SOFTPLUS)
@@ -153,6 +161,16 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
         return fail(nullptr, PNDF_ERR_HIP, "the device reports no compute units (multiProcessorCount <= 0)");
     }
     h->resident_wgs = prop.multiProcessorCount;
+    if (pndf_generic_needed(*cfg)) {
+        std::string why;
+        rc = pndf_generic_create(&h->generic, *cfg, h->resident_wgs, why);
+        if (rc != PNDF_OK) {
+            delete h;
+            return fail(nullptr, rc, why);
+        }
+        *out = h;
+        return PNDF_OK;
+    }
     hipError_t e = hipMalloc((void**)&h->d_stream, (size_t)(STEP_TILES + STREAM_PAD_SLOTS * SLOT_TILES) * TILE_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_bias, BIAS_FLOATS * sizeof(float));
     if (e == hipSuccess && cfg->act == PNDF_ACT_SOFTPLUS) {
@@ -200,6 +218,7 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
 extern "C" int pndf_destroy(pndf_handle h) {
     if (!h) return PNDF_OK;
     DeviceGuard guard(h->device);
+    pndf_generic_destroy(h->generic);
     if (h->sp_done) (void)hipEventDestroy(h->sp_done);
     if (h->d_stream) (void)hipFree(h->d_stream);
     if (h->d_bias) (void)hipFree(h->d_bias);
@@ -209,53 +228,16 @@ extern "C" int pndf_destroy(pndf_handle h) {
 }
 
 // ------------------------------------------------------------------------------------------ packing
-namespace {
-
-struct Mat {          // logical matrix view M[r][c] of dfnet.lin{l}.weight, optionally transposed, zero padded
-    const float* w;   // (out, in) row-major
-    int out, in;
-    bool transposed;
-    float at(int r, int c) const {
-        const int o = transposed ? c : r, i = transposed ? r : c;
-        return (o < out && i < in) ? w[(size_t)o * in + i] : 0.f;
-    }
-};
-
-// tile(M, nt, kt)[lane*4 + s] = M[16 nt + (lane & 15)][16 kt + 4 (lane >> 4) + s]   (pndf_layout.h)
-void emit_tile(const Mat& m, int nt, int kt, float* dst) {
-    for (int lane = 0; lane < 64; ++lane)
-        for (int s = 0; s < 4; ++s) dst[lane * 4 + s] = m.at(16 * nt + (lane & 15), 16 * kt + 4 * (lane >> 4) + s);
-}
-
-}  // namespace
+// (Mat / emit_tile / EncMat / emit_enc_tile: pndf_pack.h, shared with pndf_generic.hip)
+using pndf_pack::Mat;
+using pndf_pack::emit_tile;
+using pndf_pack::EncMat;
+using pndf_pack::emit_enc_tile;
 
 extern "C" void pndf_packed_sizes(int64_t* stream_floats, int64_t* bias_floats) {
     if (stream_floats) *stream_floats = (int64_t)STEP_TILES * TILE_FLOATS;
     if (bias_floats) *bias_floats = BIAS_FLOATS;
 }
-
-namespace {
-// 16x16 logical matrices of one encoder joint (zero padded), see pndf_layout.h "encoder on the MFMA pipe"
-struct EncMat {
-    const float* w1;   // [10][in]
-    const float* w2;   // [6][10]
-    int in;
-    int kind;          // 0: W1 (rows = hidden, k = input)   1: W2 (rows 4..9 = feature, k = hidden)
-                       // 2: W2^T (rows = hidden, k = feature row 4..9)   3: W1^T (rows = input, k = hidden)
-    float at(int r, int c) const {
-        switch (kind) {
-            case 0: return (r < HID && c < in) ? w1[r * in + c] : 0.f;
-            case 1: return (r >= ENC_FEAT_ROW && r < ENC_FEAT_ROW + FEAT && c < HID) ? w2[(r - ENC_FEAT_ROW) * HID + c] : 0.f;
-            case 2: return (r < HID && c >= ENC_FEAT_ROW && c < ENC_FEAT_ROW + FEAT) ? w2[(c - ENC_FEAT_ROW) * HID + r] : 0.f;
-            default: return (r < in && c < HID) ? w1[c * in + r] : 0.f;
-        }
-    }
-};
-void emit_enc_tile(const EncMat& m, float* dst) {
-    for (int lane = 0; lane < 64; ++lane)
-        for (int s = 0; s < 4; ++s) dst[lane * 4 + s] = m.at(lane & 15, 4 * (lane >> 4) + s);
-}
-}  // namespace
 
 // in_dim of the trunk: 126 with the structure encoder, 84 = 21 x 4 without it (model.StrEnc.use = False, reference
 // model/posendf.py:40-42,73-74: DFNet sees the normalised quaternions, `p.reshape(len(p), -1)` net_modules.py:49)
@@ -457,6 +439,15 @@ static int pack_host_split(const float* const* tensors, const int64_t* numel, in
 
 extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, const int64_t* numel, int n_tensors) {
     if (!h) return PNDF_ERR_BAD_ARG;
+    if (h->generic) {
+        DeviceGuard guard(h->device);
+        if (!guard.ok) return fail(h, PNDF_ERR_HIP, "hipSetDevice failed");
+        std::string why;
+        const int grc = pndf_generic_load(h->generic, tensors, numel, n_tensors, why);
+        if (grc != PNDF_OK) return fail(h, grc, why);
+        h->have_weights = true;
+        return PNDF_OK;
+    }
     NetDims nd;
     if (const char* why = check_tensors(tensors, numel, n_tensors, &nd)) return fail(h, PNDF_ERR_BAD_SHAPE, why);
     if (table_has_encoder(n_tensors) != (h->cfg.dims[0] == DIMS[0]))
@@ -499,6 +490,7 @@ extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, con
 // name of the kernel the compute calls of this handle launch (after pndf_load_weights), for logs, benches and tests
 extern "C" const char* pndf_kernel_name(pndf_handle h) {
     if (!h) return "";
+    if (h->generic) return pndf_generic_kernel_name(h->generic);
     const bool sp = h->cfg.act == PNDF_ACT_SOFTPLUS;
     switch (h->cfg.precision) {
         case PNDF_PREC_F16X3:
@@ -521,6 +513,19 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
     if (((uintptr_t)q | (uintptr_t)qo) & 15) return fail(h, PNDF_ERR_BAD_ARG, "pose buffers must be 16-byte aligned");
     if (((uintptr_t)d | (uintptr_t)gout) & 3) return fail(h, PNDF_ERR_BAD_ARG, "misaligned distance buffer");
     PndfKernelArgs a;
+    if (h->generic) {
+        if (dbg || timing) return fail(h, PNDF_ERR_UNSUPPORTED, "stage dumps and region timing exist for the amass.yaml-shaped kernels only");
+        DeviceGuard gguard(h->device);
+        if (!gguard.ok) return fail(h, PNDF_ERR_HIP, "hipSetDevice failed");
+        if (mode == MODE_PROJECT && steps == 0) {      // zero iterations: the loop body never runs (sample_poses.py:70)
+            if (qo != q) HIP_TRY(h, hipMemcpyAsync(qo, q, (size_t)B * NQ * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            if (d) HIP_TRY(h, hipMemsetAsync(d, 0, (size_t)B * sizeof(float), (hipStream_t)stream));
+            return PNDF_OK;
+        }
+        std::string why;
+        const int grc = pndf_generic_launch(h->generic, mode, q, gout, qo, d, B, steps, stream, why);
+        return grc == PNDF_OK ? PNDF_OK : fail(h, grc, why);
+    }
     a.q_in = q; a.q_out = qo; a.d_out = d; a.grad_out = gout;
     a.stream = h->d_stream; a.bias = h->d_bias; a.dbg = dbg;
     a.B = B; a.steps = steps; a.mode = mode;

@@ -45,8 +45,9 @@ struct pndf_cpu_engine {
     bool encoder = true;
     bool have_weights = false;
     Layer enc[NJ][2];
-    Layer lin[NLIN];
-    int dims[NLIN + 1];
+    Layer lin[MAXLIN];      // any DFNet depth the reference can build (net_modules.py:14-28: `dims` is a free list): 2 .. 8 linear layers
+    int dims[MAXLIN + 1];
+    int nlin = NLIN;
     std::string err;
 };
 
@@ -122,7 +123,7 @@ void activate(const Act& a, float* z, float* der, int n, bool output_layer) {
 }
 
 struct Scratch {      // per thread
-    std::vector<float> n, x[NLIN + 1], dx[NLIN + 1], g, g2, eh[NJ], ehd[NJ], ef[NJ], efd[NJ], ein[NJ], gf, gh, gin;
+    std::vector<float> n, x[MAXLIN + 1], dx[MAXLIN + 1], g, g2, eh[NJ], ehd[NJ], ef[NJ], efd[NJ], ein[NJ], gf, gh, gin;
     float inv[4][PB], nrm[4][PB];
 };
 
@@ -164,19 +165,20 @@ void forward_grad_block(const pndf_cpu_engine& E, const float* q /*[nb][84]*/, i
         memcpy(S.x[0].data(), S.n.data(), sizeof(float) * NQ * PB);
     }
     // ---- DFNet (net_modules.py:46-72)
-    for (int l = 0; l < NLIN; ++l) {
+    const int NL = E.nlin;
+    for (int l = 0; l < NL; ++l) {
         const Layer& L = E.lin[l];
         S.x[l + 1].resize((size_t)L.out * PB);
         S.dx[l + 1].resize((size_t)L.out * PB);
         dense(L.w.data(), L.b.data(), L.out, L.in, S.x[l].data(), S.x[l + 1].data());
-        activate(act, S.x[l + 1].data(), S.dx[l + 1].data(), L.out * PB, l == NLIN - 1);
+        activate(act, S.x[l + 1].data(), S.dx[l + 1].data(), L.out * PB, l == NL - 1);
     }
-    for (int p = 0; p < nb; ++p) d[p] = S.x[NLIN][p];
+    for (int p = 0; p < nb; ++p) d[p] = S.x[NL][p];
     if (!want_grad) return;
     // ---- d (sum_b grad_out_b d_b) / d q: reverse pass
     S.g.assign((size_t)PB, 0.f);
-    for (int p = 0; p < nb; ++p) S.g[p] = (gout ? gout[p] : 1.0f) * S.dx[NLIN][p];
-    for (int l = NLIN - 1; l >= 0; --l) {
+    for (int p = 0; p < nb; ++p) S.g[p] = (gout ? gout[p] : 1.0f) * S.dx[NL][p];
+    for (int l = NL - 1; l >= 0; --l) {
         const Layer& L = E.lin[l];
         S.g2.resize((size_t)L.in * PB);
         dense(L.wt.data(), nullptr, L.in, L.out, S.g.data(), S.g2.data());
@@ -285,20 +287,23 @@ extern "C" int pndf_cpu_create(pndf_cpu_handle* out, const pndf_config* cfg) {
     if (!out || !cfg) return cpu_fail(nullptr, PNDF_ERR_BAD_ARG, "null argument");
     *out = nullptr;
     if (cfg->act < PNDF_ACT_RELU || cfg->act > PNDF_ACT_SOFTPLUS) return cpu_fail(nullptr, PNDF_ERR_UNSUPPORTED, "unknown activation");
-    if (cfg->num_joints != NJ || cfg->n_dims != NLIN + 1) return cpu_fail(nullptr, PNDF_ERR_UNSUPPORTED, "21 joints and 7 DFNet layers (configs/amass.yaml)");
+    if (cfg->num_joints != NJ || cfg->n_dims < 3 || cfg->n_dims > MAXLIN + 1)
+        return cpu_fail(nullptr, PNDF_ERR_UNSUPPORTED, "21 joints and a DFNet of 2 .. 8 linear layers (n_dims 3 .. 9)");
+    const int nlin = cfg->n_dims - 1;
     for (int j = 0; j < NJ; ++j)
         if (cfg->parent[j] != PARENT[j]) return cpu_fail(nullptr, PNDF_ERR_UNSUPPORTED, "parent table other than net_utils.py:46");
     if (cfg->dims[0] != NFEAT && cfg->dims[0] != NOENC_IN) return cpu_fail(nullptr, PNDF_ERR_UNSUPPORTED, "DFNet in_dim must be 126 (encoder) or 84");
-    if (cfg->dims[NLIN] != 1) return cpu_fail(nullptr, PNDF_ERR_UNSUPPORTED, "DFNet must end in one output");
-    for (int l = 1; l < NLIN; ++l)
-        if (cfg->dims[l] < 1 || cfg->dims[l] > DIMS[l])      // the same architectures the device engine accepts
-            return cpu_fail(nullptr, PNDF_ERR_UNSUPPORTED, "hidden widths up to configs/amass.yaml's");
+    if (cfg->dims[nlin] != 1) return cpu_fail(nullptr, PNDF_ERR_UNSUPPORTED, "DFNet must end in one output");
+    for (int l = 1; l < nlin; ++l)
+        if (cfg->dims[l] < 1 || cfg->dims[l] > MAX_WIDTH)      // the same architectures the device engine accepts
+            return cpu_fail(nullptr, PNDF_ERR_UNSUPPORTED, "hidden widths 1 .. 1024");
     if (cfg->act == PNDF_ACT_SOFTPLUS && !(cfg->beta > 0.f)) return cpu_fail(nullptr, PNDF_ERR_BAD_ARG, "Softplus beta must be positive");
     return guarded(nullptr, [&] {
         pndf_cpu_engine* h = new pndf_cpu_engine();
         h->cfg = *cfg;
         h->encoder = cfg->dims[0] == NFEAT;
-        for (int l = 0; l <= NLIN; ++l) h->dims[l] = cfg->dims[l];
+        h->nlin = nlin;
+        for (int l = 0; l <= nlin; ++l) h->dims[l] = cfg->dims[l];
         *out = h;
     });
 }
@@ -312,7 +317,7 @@ extern "C" const char* pndf_cpu_last_error(pndf_cpu_handle h) { return h ? h->er
 
 extern "C" int pndf_cpu_load_weights(pndf_cpu_handle h, const float* const* tensors, const int64_t* numel, int n_tensors) {
     if (!h || !tensors || !numel) return PNDF_ERR_BAD_ARG;
-    const int want = (h->encoder ? 4 * NJ : 0) + 2 * NLIN;
+    const int want = (h->encoder ? 4 * NJ : 0) + 2 * h->nlin;
     if (n_tensors != want) return cpu_fail(h, PNDF_ERR_BAD_SHAPE, "tensor count: " + std::to_string(n_tensors) + ", expected " + std::to_string(want));
     h->have_weights = false;      // a failed load leaves no half-loaded engine behind
     int rc = PNDF_OK;
@@ -333,7 +338,7 @@ extern "C" int pndf_cpu_load_weights(pndf_cpu_handle h, const float* const* tens
             for (int j = 0; j < NJ && rc == PNDF_OK; ++j)
                 if (!take(h->enc[j][0], HID, enc_in(j)) || !take(h->enc[j][1], FEAT, HID))
                     rc = cpu_fail(h, PNDF_ERR_BAD_SHAPE, "encoder tensor " + std::to_string(t) + " has the wrong size");
-        for (int l = 0; l < NLIN && rc == PNDF_OK; ++l)
+        for (int l = 0; l < h->nlin && rc == PNDF_OK; ++l)
             if (!take(h->lin[l], h->dims[l + 1], h->dims[l]))
                 rc = cpu_fail(h, PNDF_ERR_BAD_SHAPE, "dfnet.lin" + std::to_string(l) + " has the wrong size");
     });

@@ -150,6 +150,7 @@ __device__ __forceinline__ void ring_wait_dma() { asm volatile("s_waitcnt vmcnt(
 // never read them, so their half of the stream need not be delivered at all (round 5: the delivery of the weight stream into LDS
 // is a fifth of a launch's energy and what pushes the kernel over the power cap).  Encoder slots and the ring's start always fetch all four.
 static_assert(PNDF_RING_PIECES == 4 || PNDF_RING_PIECES == 2, "pieces per trunk slot");
+static_assert(PAIR_HI_TILE == 0 && PAIR_LO_TILE == 1, "PNDF_RING_PIECES == 2 skips the ODD pieces of a wave's window: they must be the lo tiles (pndf_layout.h)");
 // the counted wait before the mid-slot barrier: at most this many of the wave's fetch operations may still be in flight -- the
 // pieces of the slots after the next one, counted with the SMALLEST number a slot can issue (a slot that issued more only makes
 // the wait stricter)
@@ -406,19 +407,31 @@ __device__ __forceinline__ void act_softplus4(f32x4& z, const SpK& k, f32x4& der
 // + a 32-bit per-lane byte offset: `global_load/store v_off, .., s[base:base+1]`.  As per-lane 64-bit pointers (round 1)
 // the ~200 slot addresses were computed ahead, hoisted and spilled -- and every spill reload is a VMEM load whose
 // vmcnt(0) drains the ring's DMA.
+// bytes of a derivative tile per lane: 16 = four fp32 values.  PNDF_SP_DIAG & 256 (timing arm, WRONG results): 12 -- what a
+// 3-byte storage format of the derivative could buy at most (its bytes without its pack / unpack instructions; the fourth value
+// of a tile is then not stored at all); profiles/r06/small_arms.txt
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+constexpr uint32_t SP_LANE_BYTES = (PNDF_SP_DIAG & 256) ? 12u : 16u;
 struct SpRef {
     const char* base;   // uniform: this workgroup's block of the scratch
-    uint32_t off;       // per lane: tid * 16
-    __device__ __forceinline__ f32x4* slot(int s) const { return (f32x4*)(const_cast<char*>(base) + (uint32_t)(off + (uint32_t)s * (WG_THREADS * 16u))); }
+    uint32_t off;       // per lane: tid * SP_LANE_BYTES
+    __device__ __forceinline__ f32x4* slot(int s) const {
+        if constexpr (PNDF_SP_WRAP != 0) s %= PNDF_SP_WRAP;      // (footprint experiment, pndf_experiment.h: WRONG results)
+        return (f32x4*)(const_cast<char*>(base) + (uint32_t)(off + (uint32_t)s * (WG_THREADS * SP_LANE_BYTES)));
+    }
     // the parked derivatives are written once and read once, 843 KB per workgroup and step: PNDF_SP_NT marks these accesses
     // non-temporal (1 = the chunk layers' stores, 2 = every store, 4 = the loads) so that they do not push the weight stream out of L2
     template <int KIND>
     __device__ __forceinline__ void put(int s, const f32x4& v) const {
-        if constexpr ((PNDF_SP_NT & KIND) != 0) __builtin_nontemporal_store(v, slot(s));
+        if constexpr (SP_LANE_BYTES == 12) *(f32x3*)slot(s) = f32x3{v[0], v[1], v[2]};
+        else if constexpr ((PNDF_SP_NT & KIND) != 0) __builtin_nontemporal_store(v, slot(s));
         else *slot(s) = v;
     }
     __device__ __forceinline__ f32x4 get(int s) const {
-        if constexpr ((PNDF_SP_NT & 4) != 0) return __builtin_nontemporal_load(slot(s));
+        if constexpr (SP_LANE_BYTES == 12) {
+            const f32x3 v = *(const f32x3*)slot(s);
+            return f32x4{v[0], v[1], v[2], v[2]};
+        } else if constexpr ((PNDF_SP_NT & 4) != 0) return __builtin_nontemporal_load(slot(s));
         else return *slot(s);
     }
 };
@@ -437,11 +450,23 @@ struct ActP {
 __device__ __forceinline__ void stage_derivative_tile(const SpRef& sp, int slot, char* stage_tile) {
     // wave-uniform by construction (the wave's window); readfirstlane keeps it in an SGPR whatever hipcc infers
     const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(PNDF_LDS char*)stage_tile);
-    const uint32_t off = sp.off + (uint32_t)slot * (WG_THREADS * 16u);
-    if constexpr ((PNDF_SP_NT & 4) != 0)
+    if constexpr (PNDF_SP_WRAP != 0) slot %= PNDF_SP_WRAP;
+    const uint32_t off = sp.off + (uint32_t)slot * (WG_THREADS * SP_LANE_BYTES);
+    if constexpr (SP_LANE_BYTES == 12)      // (timing arm: 12 bytes per lane land at dst + lane * 12)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %0, %1" : : "v"(off), "s"(sp.base), "s"(dst) : "memory", "m0");
+    else if constexpr ((PNDF_SP_NT & 4) != 0)
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(off), "s"(sp.base), "s"(dst) : "memory", "m0");
     else
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(sp.base), "s"(dst) : "memory", "m0");
+}
+// this lane's values of staged tile `ci` of the wave's window
+__device__ __forceinline__ f32x4 staged_derivative_tile(const char* stage, int ci, int lane) {
+    if constexpr (SP_LANE_BYTES == 12) {
+        const float* p = (const float*)(stage + ci * 1024 + lane * 12);
+        return f32x4{p[0], p[1], p[2], p[2]};
+    } else {
+        return *(const f32x4*)(stage + ci * 1024 + lane * 16);
+    }
 }
 template <int YOUNGER>
 __device__ __forceinline__ void wait_staged_derivatives() {

@@ -23,7 +23,8 @@
     defined(PNDF_RING_PIECES) || defined(PNDF_RING_STAMPS) || defined(PNDF_GROUP_STAMPS) || defined(PNDF_NT_MODE) || defined(PNDF_DMA_EARLY) || \
     defined(PNDF_MFMA_ORDER) || defined(PNDF_BIG_CT) || defined(PNDF_SPLIT_FOUR) || defined(PNDF_SP_FORM) || defined(PNDF_SP_FORM_OUT) || \
     defined(PNDF_SP_FORM_ENC) || defined(PNDF_SP_FORM_TILES) || defined(PNDF_SP_FORM_CHUNK) || defined(PNDF_SP_NT) || defined(PNDF_EXP_LO_BITS) || \
-    defined(PNDF_LBS_DIAG) || defined(PNDF_LBS_FLA) || defined(PNDF_LBS_RLA) || defined(PNDF_LBS_PAIR_READS)
+    defined(PNDF_LBS_DIAG) || defined(PNDF_LBS_FLA) || defined(PNDF_LBS_RLA) || defined(PNDF_LBS_PAIR_READS) || defined(PNDF_STAGGER) || \
+    defined(PNDF_SP_WRAP)
 #error "an experiment macro is set without -DPNDF_EXPERIMENT=1: the product library takes no tuning / ablation macros (pndf_experiment.h)"
 #endif
 #endif
@@ -113,6 +114,12 @@
 #ifndef PNDF_LBS_PAIR_READS
 #define PNDF_LBS_PAIR_READS 0
 #endif
+#ifndef PNDF_SP_WRAP
+#define PNDF_SP_WRAP 0           // pndf_device.h: softplus derivative slots wrap after this many (same bytes, smaller footprint: does the
+#endif                           // scratch cost what it costs because 216 MB + the rest overflow the 256 MB Infinity Cache?), WRONG results
+#ifndef PNDF_STAGGER
+#define PNDF_STAGGER 0           // pndf_kernel_split.hip: workgroups of XCD x start x * PNDF_STAGGER sleeps (~4 us each) late (round 6:
+#endif                           // does a chip whose XCDs are in different phases of a step sit closer to the power cap?)
 
 // one bit per macro that differs from the product default of THIS translation unit
 #define PNDF_EXPERIMENT_WORD                                                                                                        \
@@ -123,7 +130,7 @@
      ((PNDF_BIG_CT) != 2 ? 1u << 11 : 0u) | ((PNDF_SPLIT_FOUR) != 0 ? 1u << 12 : 0u) |                                              \
      (((PNDF_SP_FORM) != 1 || (PNDF_SP_FORM_OUT) != 1 || (PNDF_SP_FORM_ENC) != 1 || (PNDF_SP_FORM_TILES) != 1 || (PNDF_SP_FORM_CHUNK) != 1) ? 1u << 13 : 0u) | \
      ((PNDF_SP_NT) != 0 ? 1u << 14 : 0u) | (PNDF_X_EXP_LO_BITS ? 1u << 15 : 0u) | ((PNDF_LBS_DIAG) != 0 ? 1u << 16 : 0u) |          \
-     (((PNDF_LBS_FLA) != 2 || (PNDF_LBS_RLA) != 1 || (PNDF_LBS_PAIR_READS) != 0) ? 1u << 17 : 0u) | ((PNDF_EXPERIMENT) != 0 ? 1u << 31 : 0u))
+     (((PNDF_LBS_FLA) != 2 || (PNDF_LBS_RLA) != 1 || (PNDF_LBS_PAIR_READS) != 0) ? 1u << 17 : 0u) | ((PNDF_STAGGER) != 0 ? 1u << 18 : 0u) | ((PNDF_SP_WRAP) != 0 ? 1u << 19 : 0u) | ((PNDF_EXPERIMENT) != 0 ? 1u << 31 : 0u))
 
 // `PNDF_EXPORT_EXPERIMENT_WORD(tag)` in a translation unit: its word as an exported constant of the shared library
 #define PNDF_EXPORT_EXPERIMENT_WORD_(tag)                                                                  \

@@ -1,0 +1,482 @@
+// Runtime-planned Pose-NDF kernel for gfx950: any DFNet the reference can build.
+//
+// reference model/network/net_modules.py:14-28 takes the hidden widths of DFNet as a free list (`dims`), and the README points
+// users at checkpoints of configs other than configs/amass.yaml.  The fused kernels of pndf_kernel*.hip are compile-time plans of
+// that one architecture (pair-fused phases, register-resident activations); everything else -- 2 .. 8 linear layers, hidden widths
+// 1 .. 1024 -- runs here, with the same ownership (a workgroup = 4 waves = 64 poses for the whole call, one persistent launch for
+// all projection steps), the same MFMA encoder, normalisation and update code (pndf_device.h), and the trunk LAYER BY LAYER from a
+// plan that travels in the kernel arguments:
+//   * arithmetic: exact fp32 (v_mfma_f32_16x16x4_f32, fp32 accumulate from the bias), the same operation order as
+//     pndf_fused_relu_kernel -- whatever `precision` the handle asked for (a request for speed, not for less accuracy);
+//   * transposed like the fused kernels: D tile = 16 rows x the wave's 16 poses, and a D tile is the B operand of the next
+//     layer as it stands (pndf_layout.h), so activations are never transposed;
+//   * what does not fit the register file at run-time widths lives in a per-workgroup global scratch that only ITS OWN lane ever
+//     touches (every lane stores and re-loads exactly its 16 bytes of a tile: private memory with a coalesced layout -- no
+//     barrier, no fence): activations ping / pong (64 tiles each) and the activation derivative of every hidden unit (fp32
+//     factor: 1 | slope, or softplus' e / (1 + e)) for the backward pass;
+//   * weights: fp32 tiles `tile(M, nt, kt)` in consumption order [block of 4 output tiles][k tile][tile of the block], read
+//     straight from global memory (every wave of every workgroup reads the same 1-KiB tiles: L1 / L2 hits), one block of four
+//     accumulators per pass so that an activation tile is loaded once per sixteen MFMAs; the next k step's five loads are issued
+//     before the current step's MFMAs (an fp32 MFMA occupies the pipe for 32 cycles: the loads hide behind them).
+// Roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic work per pose-step 4 x sum_l in_l out_l FLOP.  Not the benchmark path
+// (BASELINE.json names amass.yaml); measured in profiles/r06/generic_arch.txt.
+#include "pndf_device.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "pndf_generic.h"
+#include "pndf_host.h"
+#include "pndf_pack.h"
+
+namespace {
+
+constexpr int NTB = PNDF_GEN_NTB;
+constexpr int TILE_F4 = 64;              // f32x4 elements of a weight tile (one per lane)
+constexpr int SLOT_F4 = WG_THREADS;      // f32x4 elements of a scratch tile slot (one per thread of the workgroup)
+
+// acc[j] += sum_k W(block, k, j) X[k]: `w` = this lane's element of the block's first tile, `x` = this thread's element of the
+// operand's tile 0.  Software-pipelined one k step deep; the last trip re-reads its own tiles instead of branching.
+__device__ __forceinline__ void gen_gemm(const f32x4* __restrict__ w, const f32x4* x, int nk, f32x4 (&acc)[NTB]) {
+    f32x4 wc[NTB], xc = x[0];
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) wc[j] = w[j * TILE_F4];
+    for (int k = 0; k < nk; ++k) {
+        const int kn = (k + 1 < nk) ? k + 1 : k;
+        f32x4 wn[NTB];
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) wn[j] = w[(size_t)(kn * NTB + j) * TILE_F4];
+        const f32x4 xn = x[(size_t)kn * SLOT_F4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) acc[j] = mfma4(wc[j][s], xc[s], acc[j]);      // four independent chains
+        }
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) wc[j] = wn[j];
+        xc = xn;
+    }
+}
+
+// hidden activation of one D tile (reference net_modules.py:30-41,64-65) and its derivative factor
+template <bool SP>
+__device__ __forceinline__ void gen_act(f32x4& z, f32x4& dfac, float slope, const SpK& k) {
+    if constexpr (SP) {
+        act_softplus4<PNDF_SP_FORM, false>(z, k, dfac);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool pos = z[r] > 0.0f;             // PyTorch: relu'(0) = 0, lrelu'(0) = slope
+            dfac[r] = pos ? 1.0f : slope;
+            z[r] = pos ? z[r] : z[r] * slope;
+        }
+    }
+}
+
+template <bool SP>
+__device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4;
+    const int p = lane & 15;
+    const int wp = wave * 16 + p;
+    const int L = args.nlayers;
+
+    // this workgroup's scratch: [0, 64) activations ping, [64, 128) pong, then the derivative factors (args.d_off)
+    f32x4* const wg = (f32x4*)args.scratch + (size_t)blockIdx.x * args.wg_tiles * SLOT_F4 + tid;
+    f32x4* const xbuf[2] = {wg, wg + (size_t)PNDF_GEN_XTILES * SLOT_F4};
+
+    ActP ap;
+    ap.slope = args.slope;
+    ap.k = sp_consts(args.beta);
+    // the encoder parks its 42 derivative tiles at slots SP_SLOT_ENC + i of `ap.sp` (pndf_device.h): point slot SP_SLOT_ENC at enc_d_off
+    ap.sp = SpRef{SP ? (const char*)((f32x4*)args.scratch + ((size_t)blockIdx.x * args.wg_tiles + args.enc_d_off) * SLOT_F4)
+                           - (size_t)SP_SLOT_ENC * WG_THREADS * SP_LANE_BYTES
+                     : nullptr,
+                  (uint32_t)tid * SP_LANE_BYTES};
+    ap.stage = nullptr;
+    ap.lane = lane;
+
+    float* const lds_bias = (float*)(smem + LDS_BIAS);
+    float* const lds_q = (float*)(smem + LDS_Q);
+    float* const my_q = lds_q + wp * NQ;
+    float* const my_f = (float*)(smem + LDS_F) + wp * FSTRIDE;
+    float* const my_gn = (float*)(smem + LDS_GN) + wp * FSTRIDE;   // aliases the feature row of the pose
+
+    Ring ring;
+    ring.smem = smem;
+    ring.lane = lane;
+    ring.st_wait = ring.st_bar = 0;
+    ring.st_n = 0;
+    for (int i = tid; i < BIAS_FLOATS / 4; i += WG_THREADS) ((f32x4*)lds_bias)[i] = ((const f32x4*)args.bias)[i];
+
+    const long long nblocks = (args.B + WG_POSES - 1) / WG_POSES;
+    for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const long long pose0 = blk * WG_POSES;
+        {
+            long long nvalid = args.B - pose0;
+            if (nvalid > WG_POSES) nvalid = WG_POSES;
+            const f32x4* src = (const f32x4*)(args.q_in + pose0 * NQ);
+            const int nvec = (int)nvalid * (NQ / 4);
+            for (int i = tid; i < WG_POSES * (NQ / 4); i += WG_THREADS) {
+                const int src_i = i < nvec ? i : (nvec - (NQ / 4) + (i % (NQ / 4)));
+                ((f32x4*)lds_q)[i] = src[src_i];
+            }
+        }
+        __syncthreads();
+
+        const int nsteps = (args.mode == MODE_PROJECT) ? args.steps : 1;
+        float dval = 0.f;
+        for (int step = 0; step < nsteps; ++step) {
+            // ---------------- encoder (or the normalised pose itself) -> x0, 128 rows in the pose's feature row
+            uint32_t eb[6] = {0, 0, 0, 0, 0, 0};
+            float poison;
+            if (args.noenc) {
+                poison = noenc_forward<SP>(my_q, my_f, g);
+            } else {
+                // the encoder's tiles come through the weight ring like in the fused kernels: forward section of the stream
+                ring.gstream = args.enc_stream;
+                ring_start(ring, wave);
+                ring_wait_dma();
+                __syncthreads();
+                poison = encoder_forward<SP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ap, g);
+                ring_wait_dma();      // (the ring fetched ahead into the section's padding: drain before the next restart)
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) xbuf[0][(size_t)t * SLOT_F4] = *(const f32x4*)(my_f + 16 * t + 4 * g);
+
+            // ---------------- trunk forward, layer by layer (net_modules.py:51-69)
+            f32x4 zlast = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int l = 0; l < L; ++l) {
+                const int nk = args.kt[l], nb = args.ntp[l] / NTB;
+                const f32x4* w = (const f32x4*)args.wfwd + (size_t)args.wf_off[l] * TILE_F4 + lane;
+                const float* bias = args.lbias + args.b_off[l];
+                const f32x4* xin = xbuf[l & 1];
+                f32x4* xout = xbuf[(l + 1) & 1];
+                f32x4* dl = wg + (size_t)args.d_off[l] * SLOT_F4;
+                for (int b = 0; b < nb; ++b) {
+                    f32x4 acc[NTB];
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) acc[j] = *(const f32x4*)(bias + 16 * (b * NTB + j) + 4 * g);
+                    gen_gemm(w + (size_t)b * nk * NTB * TILE_F4, xin, nk, acc);
+                    if (l == L - 1) {          // the output layer: one unit, row 0 of tile 0; its activation follows below
+                        if (b == 0) zlast = acc[0];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NTB; ++j) {
+                            f32x4 df;
+                            gen_act<SP>(acc[j], df, args.slope, ap.k);
+                            xout[(size_t)(b * NTB + j) * SLOT_F4] = acc[j];
+                            dl[(size_t)(b * NTB + j) * SLOT_F4] = df;
+                        }
+                    }
+                }
+            }
+            // row 0 of the output tile lives in register 0 of lane group 0: every lane of the pose reads it from there
+            const float z7 = __shfl(zlast[0], p);
+            float gz7;
+            if constexpr (SP) {
+                dval = act_softplus<PNDF_SP_FORM_OUT>(z7, ap.k, gz7) + poison;      // output Softplus, net_modules.py:39-41,69
+                gz7 += poison;
+            } else {
+                dval = (z7 != z7) ? z7 : fmaxf(z7, 0.f);      // output ReLU for relu AND lrelu, net_modules.py:30-37 (relu(NaN) = NaN)
+                gz7 = (z7 > 0.f) ? 1.f : 0.f;
+            }
+            if (args.mode == MODE_FORWARD) break;
+            float gscale = gz7;
+            if (args.mode == MODE_FORWARD_GRAD && args.grad_out) {
+                long long pidx = pose0 + wp;
+                if (pidx >= args.B) pidx = args.B - 1;
+                gscale = gz7 * args.grad_out[pidx];
+            }
+
+            // ---------------- trunk backward: the seed is d z_out / d z_out = 1 in row 0 (the output activation's derivative
+            // and grad_outputs scale the result, as in the fused kernels)
+            int cur = 0;
+            xbuf[0][0] = (g == 0) ? f32x4{1.f, 0.f, 0.f, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int l = L - 1; l >= 0; --l) {
+                const int nk = args.nt[l], nb = args.ktp[l] / NTB;
+                const f32x4* w = (const f32x4*)args.wbwd + (size_t)args.wb_off[l] * TILE_F4 + lane;
+                const f32x4* gin = xbuf[cur];
+                f32x4* gout = xbuf[cur ^ 1];
+                const f32x4* dprev = (l > 0) ? wg + (size_t)args.d_off[l - 1] * SLOT_F4 : nullptr;
+                for (int b = 0; b < nb; ++b) {
+                    f32x4 acc[NTB];
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    gen_gemm(w + (size_t)b * nk * NTB * TILE_F4, gin, nk, acc);
+#pragma unroll
+                    for (int j = 0; j < NTB; ++j) {
+                        const int t = b * NTB + j;
+                        if (l > 0) gout[(size_t)t * SLOT_F4] = acc[j] * dprev[(size_t)t * SLOT_F4];      // x act'(z_{l-1})
+                        else if (t < 8) *(f32x4*)(my_f + 16 * t + 4 * g) = acc[j];                       // d z_out / d x0
+                    }
+                }
+                cur ^= 1;
+            }
+            __syncthreads();
+
+            // ---------------- encoder backward + normalise backward + update (fp32, as the fused kernels)
+            if (!args.noenc) {
+                ring.gstream = args.enc_stream + (size_t)PNDF_GEN_ENC_SECTION_TILES * TILE_BYTES;
+                ring_start(ring, wave);
+                ring_wait_dma();
+                __syncthreads();
+                encoder_backward<SP>(my_f, my_gn, eb, ring, ap, g);
+                ring_wait_dma();
+            }
+            {
+                float ss[4], dot[4], denom[4], kk[4];
+                ss[0] = ss[1] = ss[2] = ss[3] = 0.f;
+                dot[0] = dot[1] = dot[2] = dot[3] = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const f32x4 qv = *(const f32x4*)(my_q + 4 * j);
+                    const f32x4 gv = *(const f32x4*)(my_gn + 4 * j);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        ss[c] = fmaf(qv[c], qv[c], ss[c]);
+                        dot[c] = fmaf(gv[c], qv[c], dot[c]);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float norm = sqrtf(ss[c]);
+                    denom[c] = fmaxf(norm, 1e-12f);
+                    kk[c] = (norm > 1e-12f) ? dot[c] / (denom[c] * denom[c] * norm) : 0.f;
+                }
+                for (int j = g; j < NJ; j += 4) {
+                    const f32x4 qv = *(const f32x4*)(my_q + 4 * j);
+                    const f32x4 gv = *(const f32x4*)(my_gn + 4 * j);
+                    f32x4 o;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float dq = gv[c] / denom[c] - qv[c] * kk[c];
+                        const float dqs = dq * gscale;
+                        o[c] = (args.mode == MODE_PROJECT) ? project_update(qv[c], dval, dqs) : dqs;
+                    }
+                    *(f32x4*)(my_q + 4 * j) = o;
+                }
+            }
+            __syncthreads();
+        }
+
+        {
+            long long pidx = pose0 + wp;
+            if (g == 0 && pidx < args.B && args.d_out) args.d_out[pidx] = dval;
+        }
+        if (args.mode != MODE_FORWARD) {
+            __syncthreads();
+            long long nvalid = args.B - pose0;
+            if (nvalid > WG_POSES) nvalid = WG_POSES;
+            f32x4* dst = (f32x4*)(args.q_out + pose0 * NQ);
+            const int nvec = (int)nvalid * (NQ / 4);
+            for (int i = tid; i < nvec; i += WG_THREADS) dst[i] = ((const f32x4*)lds_q)[i];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_generic_relu_kernel(PndfGenericArgs args) {
+    pndf_generic_body<false>(args);
+}
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_generic_softplus_kernel(PndfGenericArgs args) {
+    pndf_generic_body<true>(args);
+}
+
+// ------------------------------------------------------------------------------------------ host side
+using namespace pndf;
+
+struct PndfGeneric {
+    pndf_config cfg;
+    int L = 0;
+    bool enc = true;
+    int resident = 0;
+    PndfGenericArgs plan;            // tile counts and offsets (pointers filled per launch)
+    size_t wf_tiles = 0, wb_tiles = 0, lbias_floats = 0;
+    char* d_enc = nullptr;
+    float *d_bias = nullptr, *d_wf = nullptr, *d_wb = nullptr, *d_lb = nullptr, *d_scratch = nullptr;
+    bool have_weights = false;
+    // the scratch is shared by all launches of the handle: a launch on another stream than the previous one first waits
+    // (on the device) for that one's completion event, as the softplus engines do
+    hipEvent_t done = nullptr;
+    void* last_stream = nullptr;
+    bool pending = false;
+};
+
+bool pndf_generic_needed(const pndf_config& cfg) {
+    // PNDF_FORCE_GENERIC=1: also configs/amass.yaml itself takes this path (tools/bench_generic.py: what the runtime plan costs
+    // against the compile-time one, same network, same box)
+    const char* force = getenv("PNDF_FORCE_GENERIC");
+    if (force && force[0] == '1') return true;
+    if (cfg.n_dims != NLIN + 1) return true;
+    for (int i = 1; i < NLIN; ++i)
+        if (cfg.dims[i] > DIMS[i]) return true;
+    return false;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+int pndf_generic_create(PndfGeneric** out, const pndf_config& cfg, int resident_wgs, std::string& err) {
+    *out = nullptr;
+    const int L = cfg.n_dims - 1;
+    if (L < 2 || L > PNDF_GEN_MAXLIN) { err = "DFNet depth: 2 .. 8 linear layers (n_dims 3 .. 9)"; return PNDF_ERR_UNSUPPORTED; }
+    PndfGeneric* g = new PndfGeneric();
+    g->cfg = cfg;
+    g->L = L;
+    g->enc = cfg.dims[0] == DIMS[0];
+    g->resident = resident_wgs;
+    PndfGenericArgs& P = g->plan;
+    memset(&P, 0, sizeof(P));
+    P.nlayers = L;
+    P.noenc = g->enc ? 0 : 1;
+    int wf = 0, wb = 0, bo = 0, slot = 2 * PNDF_GEN_XTILES;
+    for (int l = 0; l < L; ++l) {
+        const int in = (l == 0) ? 128 : cfg.dims[l];      // x0 is the pose's 128-row feature buffer (126 | 84 rows used, the rest zero)
+        const int outw = cfg.dims[l + 1];
+        P.kt[l] = ceil_div(in, 16);
+        P.nt[l] = ceil_div(outw, 16);
+        P.ktp[l] = round_up(P.kt[l], NTB);
+        P.ntp[l] = round_up(P.nt[l], NTB);
+        P.wf_off[l] = wf;
+        P.wb_off[l] = wb;
+        P.b_off[l] = bo;
+        P.d_off[l] = slot;
+        wf += P.ntp[l] * P.kt[l];
+        wb += P.ktp[l] * P.nt[l];
+        bo += 16 * P.ntp[l];
+        if (l < L - 1) slot += P.ntp[l];
+    }
+    P.enc_d_off = slot;
+    if (cfg.act == PNDF_ACT_SOFTPLUS && g->enc) slot += 2 * NJ;
+    P.wg_tiles = slot;
+    g->wf_tiles = wf;
+    g->wb_tiles = wb;
+    g->lbias_floats = bo;
+    hipError_t e = hipMalloc((void**)&g->d_bias, BIAS_FLOATS * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->d_enc, (size_t)2 * PNDF_GEN_ENC_SECTION_TILES * TILE_BYTES);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->d_wf, g->wf_tiles * TILE_BYTES);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->d_wb, g->wb_tiles * TILE_BYTES);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->d_lb, g->lbias_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->d_scratch, (size_t)resident_wgs * P.wg_tiles * SLOT_F4 * sizeof(f32x4));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pndf_generic_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pndf_generic_softplus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (e != hipSuccess) {
+        err = std::string("pndf_create (runtime-planned DFNet): ") + hipGetErrorString(e);
+        pndf_generic_destroy(g);
+        return PNDF_ERR_HIP;
+    }
+    *out = g;
+    return PNDF_OK;
+}
+
+void pndf_generic_destroy(PndfGeneric* g) {
+    if (!g) return;
+    if (g->done) (void)hipEventDestroy(g->done);
+    for (void* p : {(void*)g->d_enc, (void*)g->d_bias, (void*)g->d_wf, (void*)g->d_wb, (void*)g->d_lb, (void*)g->d_scratch})
+        if (p) (void)hipFree(p);
+    delete g;
+}
+
+int pndf_generic_load(PndfGeneric* g, const float* const* tensors, const int64_t* numel, int n_tensors, std::string& err) {
+    const int L = g->L;
+    const int want = (g->enc ? 4 * NJ : 0) + 2 * L;
+    if (!tensors || !numel || n_tensors != want) {
+        err = "expected " + std::to_string(want) + " tensors in state-dict order (encoder: 84, then weight and bias of every dfnet.lin)";
+        return PNDF_ERR_BAD_SHAPE;
+    }
+    int t = 0;
+    for (int j = 0; g->enc && j < NJ; ++j) {
+        const int64_t sz[4] = {HID * enc_in(j), HID, FEAT * HID, FEAT};
+        for (int k = 0; k < 4; ++k, ++t)
+            if (!tensors[t] || numel[t] != sz[k]) { err = "encoder tensor missing or of the wrong size"; return PNDF_ERR_BAD_SHAPE; }
+    }
+    const float* const* lin = tensors + t;
+    const int64_t* ln = numel + t;
+    for (int l = 0; l < L; ++l) {
+        const int64_t in = g->cfg.dims[l], outw = g->cfg.dims[l + 1];
+        if (!lin[2 * l] || !lin[2 * l + 1] || ln[2 * l] != in * outw || ln[2 * l + 1] != outw) {
+            err = "dfnet.lin" + std::to_string(l) + " does not match the configured dims";
+            return PNDF_ERR_BAD_SHAPE;
+        }
+    }
+    const PndfGenericArgs& P = g->plan;
+    std::vector<float> wf(g->wf_tiles * TILE_FLOATS), wb(g->wb_tiles * TILE_FLOATS), lb(g->lbias_floats, 0.f), bias(BIAS_FLOATS, 0.f),
+        enc((size_t)2 * PNDF_GEN_ENC_SECTION_TILES * TILE_FLOATS, 0.f);
+    for (int l = 0; l < L; ++l) {
+        const int in = g->cfg.dims[l], outw = g->cfg.dims[l + 1];
+        const pndf_pack::Mat F{lin[2 * l], outw, in, false}, T{lin[2 * l], outw, in, true};
+        float* dst = wf.data() + (size_t)P.wf_off[l] * TILE_FLOATS;
+        for (int b = 0; b < P.ntp[l] / NTB; ++b)
+            for (int k = 0; k < P.kt[l]; ++k)
+                for (int j = 0; j < NTB; ++j, dst += TILE_FLOATS) pndf_pack::emit_tile(F, b * NTB + j, k, dst);
+        dst = wb.data() + (size_t)P.wb_off[l] * TILE_FLOATS;
+        for (int b = 0; b < P.ktp[l] / NTB; ++b)
+            for (int k = 0; k < P.nt[l]; ++k)
+                for (int j = 0; j < NTB; ++j, dst += TILE_FLOATS) pndf_pack::emit_tile(T, b * NTB + j, k, dst);
+        memcpy(lb.data() + P.b_off[l], lin[2 * l + 1], sizeof(float) * outw);
+    }
+    for (int l = 0; l < 8; ++l) bias[SCALE_OFF + l] = 1.0f;
+    if (g->enc) {
+        for (int j = 0; j < NJ; ++j) {
+            memcpy(bias.data() + ENCB_OFF + 32 * j, tensors[4 * j + 1], sizeof(float) * HID);
+            memcpy(bias.data() + ENCB_OFF + 32 * j + 16 + ENC_FEAT_ROW, tensors[4 * j + 3], sizeof(float) * FEAT);
+        }
+        pndf_pack::emit_encoder_sections(tensors, enc.data(), enc.data() + (size_t)PNDF_GEN_ENC_SECTION_TILES * TILE_FLOATS);
+    }
+    hipError_t e = hipDeviceSynchronize();      // no launch may still be reading the old weights
+    if (e == hipSuccess) e = hipMemcpy(g->d_wf, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->d_wb, wb.data(), wb.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->d_lb, lb.data(), lb.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->d_enc, enc.data(), enc.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { err = std::string("pndf_load_weights (runtime-planned DFNet): ") + hipGetErrorString(e); return PNDF_ERR_HIP; }
+    g->have_weights = true;
+    return PNDF_OK;
+}
+
+const char* pndf_generic_kernel_name(const PndfGeneric* g) {
+    return g->cfg.act == PNDF_ACT_SOFTPLUS ? "pndf_generic_softplus_kernel" : "pndf_generic_relu_kernel";
+}
+
+int pndf_generic_launch(PndfGeneric* g, int mode, const float* q, const float* gout, float* qo, float* d, int64_t B, int steps,
+                        void* stream, std::string& err) {
+    if (!g->have_weights) { err = "pndf_load_weights has not been called"; return PNDF_ERR_NO_WEIGHTS; }
+    PndfGenericArgs a = g->plan;
+    a.q_in = q; a.q_out = qo; a.d_out = d; a.grad_out = gout;
+    a.enc_stream = g->d_enc; a.bias = g->d_bias; a.wfwd = g->d_wf; a.wbwd = g->d_wb; a.lbias = g->d_lb; a.scratch = g->d_scratch;
+    a.B = B; a.steps = steps; a.mode = mode;
+    a.slope = (g->cfg.act == PNDF_ACT_LRELU) ? 0.01f : 0.0f;      // nn.LeakyReLU() default slope, net_modules.py:31
+    a.beta = g->cfg.beta;
+    const int64_t nblocks = (B + WG_POSES - 1) / WG_POSES;
+    const dim3 grid((unsigned)(nblocks < g->resident ? nblocks : g->resident)), block(WG_THREADS);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    hipError_t e = hipSuccess;
+    if (g->pending && g->last_stream != stream && !capturing) e = hipStreamWaitEvent((hipStream_t)stream, g->done, 0);
+    if (e == hipSuccess) {
+        if (g->cfg.act == PNDF_ACT_SOFTPLUS) hipLaunchKernelGGL(pndf_generic_softplus_kernel, grid, block, LDS_TOTAL, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(pndf_generic_relu_kernel, grid, block, LDS_TOTAL, (hipStream_t)stream, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && !capturing) {
+        e = hipEventRecord(g->done, (hipStream_t)stream);
+        g->last_stream = stream;
+        g->pending = true;
+    }
+    if (e != hipSuccess) { err = std::string("runtime-planned DFNet launch: ") + hipGetErrorString(e); return PNDF_ERR_HIP; }
+    return PNDF_OK;
+}
+
+PNDF_EXPORT_EXPERIMENT_WORD(generic)

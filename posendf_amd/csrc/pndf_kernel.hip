@@ -93,7 +93,7 @@ struct PhaseBody {
                                 ap.sp.put<1>(spslot + c * CT + ci, dv);
                             } else {
                                 if (ci == 0) wait_staged_derivatives<(KA * CT / 4 < 12) ? KA * CT / 4 : 12>();
-                                ch[ci] = ch[ci] * *(const f32x4*)(ap.stage + ci * 1024 + ap.lane * 16);
+                                ch[ci] = ch[ci] * staged_derivative_tile(ap.stage, ci, ap.lane);
                             }
                         }
                     } else if (!BWD) {
@@ -240,7 +240,7 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     ActP ap;
     ap.slope = args.slope;
     ap.k = sp_consts(args.beta);
-    ap.sp = SpRef{SP ? (const char*)(args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS) : nullptr, (uint32_t)tid * 16u};
+    ap.sp = SpRef{SP ? (const char*)(args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS) : nullptr, (uint32_t)tid * SP_LANE_BYTES};
     ap.stage = (char*)(smem + LDS_F) + wave * (16 * FSTRIDE * 4);
     ap.lane = lane;
     float* const lds_bias = (float*)(smem + LDS_BIAS);

@@ -322,6 +322,9 @@ struct SplitPhase {
     static constexpr int PARTIALS = 1;                // accumulators per chunk tile (3 = one per term)
     static constexpr int BIG = (NC >= 32) ? (BWD ? 2 : 1) : 0;      // the two 4 MiB phases: 1 = (lin2,lin3), 2 = (lin3^T,lin2^T)
     static_assert(AP % 4 == 0 && BP % 4 == 0 && A_TILES % SLOT_TILES == 0, "group / slot alignment");
+    // Both parts of a chunk are whole 16-tile slots (AG, BG even): STAGE_YOUNGER counts AG / 2 slots per part A, and the hi-only
+    // fetch of the two-term kernels (PNDF_RING_PIECES == 2) relies on every part starting on a slot boundary.
+    static_assert(AG % 2 == 0 && BG % 2 == 0, "part A and part B of a chunk must each be a whole number of ring slots");
     static_assert(!SP || PARTIALS == 1, "the softplus epilogue reads one accumulator per chunk tile");
 
     // ---- part A: chunk rows of layer A.  Three partial accumulators per chunk tile (hh, hl, lh terms) keep
@@ -333,6 +336,7 @@ struct SplitPhase {
             constexpr int term = mfma_term(M, NT), i = mfma_pair(M, NT, CT == 2), pi = 4 * GA + i, kb = pi / CT, ci = pi % CT;
             constexpr int TN = (8 * (GA + 1)) % SLOT_TILES;
             if constexpr (M == 8 && PNDF_MFMA_ORDER != 3) __builtin_amdgcn_s_waitcnt(0xC87F);     // lgkmcnt(8): this group's lo tiles
+            static_assert(NT == 3 || term != 2, "a two-term instantiation never reads a lo tile (they are not even fetched: PNDF_RING_PIECES == 2)");
             const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
             const f16x8 x = (term == 1) ? xin[kb].l : xin[kb].h;
             if (!((PNDF_ABLATE & 8) && term == 2))      // (energy-model experiment: no third term)
@@ -503,7 +507,7 @@ struct SplitPhase {
                         if constexpr (r == 3) act.sp.template put<1>(act.spslot + c * CT + ci, bt[ci]);
                     }
                 } else if constexpr (SP && BWD) {
-                    if constexpr (r == 0) bt[ci] = *(const f32x4*)(act.stage + ci * 1024 + act.lane * 16);
+                    if constexpr (r == 0) bt[ci] = staged_derivative_tile(act.stage, ci, act.lane);
                     y[ci][r] = (a * cf) * bt[ci][r];
                 } else if constexpr (!BWD) {
                     y[ci][r] = lrelu_bit(fmaf(a, cf, bt[ci][r]), act.slope, bits);
@@ -593,6 +597,7 @@ struct SplitPhase {
                 if constexpr (LOADED) __builtin_amdgcn_s_waitcnt(0xC87F);   // lgkmcnt(8)
                 else __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0)
             }
+            static_assert(NT == 3 || term != 2, "a two-term instantiation never reads a lo tile");
             const f16x8 w = (term == 2) ? cur[i].l : cur[i].h;
             const f16x8 x = (term == 1) ? chb[b].l : chb[b].h;
             if (!((PNDF_ABLATE & 8) && term == 2)) acc[nb] = mf16(w, x, acc[nb]);
@@ -883,7 +888,7 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
     ActP ap;
     ap.slope = args.slope;
     ap.k = sp_consts(args.beta);
-    ap.sp = SpRef{SP ? (const char*)(args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS) : nullptr, (uint32_t)tid * 16u};
+    ap.sp = SpRef{SP ? (const char*)(args.scratch + (size_t)blockIdx.x * SP_WG_FLOATS) : nullptr, (uint32_t)tid * SP_LANE_BYTES};
     // uniform constants of the packer: 1 / weight scale of lin0..lin5 (powers of two) and the norms behind the a-priori
     // bounds of the chunked layers (pndf_layout.h NORM_OFF)
     auto uni = [&](int i) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, args.bias[i]))); };
@@ -921,6 +926,9 @@ __device__ __forceinline__ void pndf_fused_split_body(const PndfKernelArgs& args
     // is bounded by the resident workgroups (pndf_capi.hip).  Every block restarts the ring (the forward-only mode leaves
     // it in the middle of the stream); the drain + barrier at the end of a block make that safe.
     const long long nblocks = (args.B + WG_POSES - 1) / WG_POSES;
+    if constexpr (PNDF_STAGGER != 0) {      // (experiment, pndf_experiment.h: the XCDs -- workgroup id mod 8 -- start out of phase)
+        for (int i = 0; i < (int)(blockIdx.x & 7u) * PNDF_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const long long pose0 = blk * WG_POSES;
     ring_start(ring, wave);   // slots 0..3 in flight; the __syncthreads() below makes them visible

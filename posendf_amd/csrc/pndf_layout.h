@@ -27,6 +27,10 @@ constexpr int FEAT = 6;
 constexpr int HID = 10;
 constexpr int NLIN = 7;
 constexpr int DIMS[NLIN + 1] = {126, 256, 512, 1024, 512, 256, 64, 1};
+// Any other DFNet the reference can build (net_modules.py:14-28: `dims` is a free list of hidden widths) runs on the
+// runtime-planned kernels of pndf_generic.hip: 2 .. 8 linear layers (n_dims 3 .. 9), hidden widths 1 .. 1024.
+constexpr int MAXLIN = 8;
+constexpr int MAX_WIDTH = 1024;
 
 constexpr int TILE_FLOATS = 256;
 constexpr int TILE_BYTES = 1024;
@@ -86,6 +90,11 @@ static_assert(ENC_TILES_PADDED % SLOT_TILES == 0 && ENC_TILES <= ENC_TILES_PADDE
 // registers of two consecutive C/D tiles).  Same tile count and slot structure as the fp32 stream; inside a
 // phase the order is software-pipelined:  A(0) | A(1) B(0) | A(2) B(1) | ... | B(NC-1)
 //   A(c): (kb, ci) pairs        B(c): (nb, b) pairs, b = k-block inside the chunk (CT / 2 of them)
+// Tile parity (relied on by the two-term kernels, which fetch and read the hi tiles only): a pair occupies two consecutive stream
+// tiles, hi first; every part of a chunk is an even number of tiles and starts on a slot boundary, so within a slot -- and within
+// the four-tile window one wave fetches of it -- EVEN tiles are hi tiles and ODD tiles are lo tiles.
+constexpr int PAIR_HI_TILE = 0, PAIR_LO_TILE = 1;
+static_assert(SLOT_TILES % 2 == 0 && (SLOT_TILES / 4) % 2 == 0, "a wave's window of a slot holds whole pairs");
 constexpr int phase_a_pairs(const Phase& p) { return (p.KA / 2) * p.CT; }
 constexpr int phase_b_pairs(const Phase& p) { return p.NB * (p.CT / 2); }
 static_assert(2 * (phase_a_pairs(PHASES[1]) + phase_b_pairs(PHASES[1])) == phase_chunk_tiles(PHASES[1]), "same tile count");

@@ -126,6 +126,7 @@ extern "C" int pndf_debug_mem_probe(int device, double* out, int n_out) {
         for (int pass = 0; pass < 2; ++pass)
             hipLaunchKernelGGL(probe_stream, dim3(1024), dim3(256), 0, 0, (const f4*)buf, foot[f] / 16, (float*)sink);
         hipLaunchKernelGGL(probe_chase, dim3(1), dim3(64), 0, 0, buf, hops, ticks, sink);
+        if (hipGetLastError() != hipSuccess) { rc = -3; break; }
         unsigned long long t = 0;
         if (hipMemcpy(&t, ticks, sizeof(t), hipMemcpyDeviceToHost) != hipSuccess) { rc = -3; break; }
         out[f] = (double)t / hops * 1e6 / rate_khz;      // ticks per hop -> ns
@@ -140,7 +141,7 @@ extern "C" int pndf_debug_mem_probe(int device, double* out, int n_out) {
             hipLaunchKernelGGL(probe_stream, dim3(2048), dim3(256), 0, 0, (const f4*)buf, bytes / 16, (float*)sink);
         (void)hipEventRecord(e1, 0);
         float ms = 0.f;
-        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) rc = -3;
+        if (hipGetLastError() != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0.f) rc = -3;
         else out[3] = 3.0 * (double)bytes / (ms * 1e-3) / 1e9;
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
@@ -161,7 +162,8 @@ extern "C" int pndf_debug_mem_probe(int device, double* out, int n_out) {
             hipLaunchKernelGGL(probe_ring, dim3(cus), dim3(256), PR_SLOTS * PR_SLOT, 0, (const char*)buf, 1, tk);      // warm
             hipLaunchKernelGGL(probe_ring, dim3(cus), dim3(256), PR_SLOTS * PR_SLOT, 0, (const char*)buf, passes, tk);
             std::vector<unsigned long long> h(cus);
-            if (hipMemcpy(h.data(), tk, (size_t)cus * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = -3;
+            if (hipGetLastError() != hipSuccess) rc = -3;
+            else if (hipMemcpy(h.data(), tk, (size_t)cus * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = -3;
             else {
                 double sum = 0;
                 for (int i = 0; i < cus; ++i) sum += (double)h[i];
@@ -190,19 +192,27 @@ extern "C" int pndf_debug_ring_stream(int device, int passes, double* sec_per_pa
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    static char* buf = nullptr;               // (a debugging aid: the 12 MB are kept for the life of the process)
-    static unsigned long long* tk = nullptr;
-    if (!buf) {
-        const size_t bytes = (size_t)(PR_STREAM_SLOTS + PR_SLOTS) * PR_SLOT;
-        if (hipMalloc((void**)&buf, bytes) != hipSuccess) return -3;
-        hipLaunchKernelGGL(probe_fill_random, dim3(1024), dim3(256), 0, 0, (uint32_t*)buf, bytes / 4);
-    }
-    if (!tk && hipMalloc((void**)&tk, 1024 * sizeof(unsigned long long)) != hipSuccess) return -3;
+    // allocated and freed per call, on `device` (function-local statics were tied to the first device passed in, never
+    // freed and not thread-safe); every launch is checked -- a failed launch must not come back as rc 0 with garbage timings
+    char* buf = nullptr;
+    unsigned long long* tk = nullptr;
+    const size_t bytes = (size_t)(PR_STREAM_SLOTS + PR_SLOTS) * PR_SLOT;
     if (cus > 1024) cus = 1024;
-    if (hipFuncSetAttribute((const void*)probe_ring, hipFuncAttributeMaxDynamicSharedMemorySize, PR_SLOTS * PR_SLOT) != hipSuccess) return -3;
-    hipLaunchKernelGGL(probe_ring, dim3(cus), dim3(256), PR_SLOTS * PR_SLOT, 0, (const char*)buf, passes, tk);
+    int rc = 0;
+    if (hipMalloc((void**)&buf, bytes) != hipSuccess || hipMalloc((void**)&tk, 1024 * sizeof(unsigned long long)) != hipSuccess) rc = -3;
+    if (rc == 0) {
+        hipLaunchKernelGGL(probe_fill_random, dim3(1024), dim3(256), 0, 0, (uint32_t*)buf, bytes / 4);
+        if (hipGetLastError() != hipSuccess) rc = -3;
+    }
+    if (rc == 0 && hipFuncSetAttribute((const void*)probe_ring, hipFuncAttributeMaxDynamicSharedMemorySize, PR_SLOTS * PR_SLOT) != hipSuccess) rc = -3;
+    if (rc == 0) {
+        hipLaunchKernelGGL(probe_ring, dim3(cus), dim3(256), PR_SLOTS * PR_SLOT, 0, (const char*)buf, passes, tk);
+        if (hipGetLastError() != hipSuccess) rc = -3;
+    }
     unsigned long long t = 0;
-    if (hipMemcpy(&t, tk, sizeof(t), hipMemcpyDeviceToHost) != hipSuccess) return -3;
-    if (sec_per_pass) *sec_per_pass = (double)t / (rate_khz * 1e3) / passes;
-    return 0;
+    if (rc == 0 && hipMemcpy(&t, tk, sizeof(t), hipMemcpyDeviceToHost) != hipSuccess) rc = -3;      // (synchronises: the kernel's own errors surface here)
+    if (rc == 0 && sec_per_pass) *sec_per_pass = (double)t / (rate_khz * 1e3) / passes;
+    if (tk) (void)hipFree(tk);
+    if (buf) (void)hipFree(buf);
+    return rc;
 }

@@ -142,7 +142,7 @@ DEBUG_EXPORTS = ("pndf_debug_forward_grad", "pndf_debug_floats", "pndf_debug_pro
                  "pndf_debug_timing_layout", "pndf_debug_mem_probe", "pndf_debug_ring_stream")
 # per-translation-unit experiment words (csrc/pndf_experiment.h): data symbols, all zero in a product build
 EXPERIMENT_WORDS = ("pndf_experiment_word_capi", "pndf_experiment_word_fp32", "pndf_experiment_word_fp32_timing", "pndf_experiment_word_split",
-                    "pndf_experiment_word_split_x2", "pndf_experiment_word_split_timing", "pndf_experiment_word_lbs")
+                    "pndf_experiment_word_split_x2", "pndf_experiment_word_split_timing", "pndf_experiment_word_lbs", "pndf_experiment_word_generic")
 
 
 def experiment_word(lib=None) -> int:
@@ -166,15 +166,18 @@ EXPORTS = ("pndf_default_config", "pndf_create", "pndf_destroy", "pndf_load_weig
            "pndf_cpu_last_error")
 
 
-def state_dict_order(encoder: bool = True):
-    """Keys in the order pndf_load_weights expects (== reference state_dict order): 98 tensors with the structure
-    encoder, the 14 dfnet.* tensors without it (model.StrEnc.use = False, in_dim 84)."""
+def state_dict_order(encoder: bool = True, n_lin: int = 7):
+    """Keys in the order pndf_load_weights expects (== reference state_dict order): the 84 encoder tensors (with the
+    structure encoder; without it -- model.StrEnc.use = False, in_dim 84 -- none), then weight and bias of every
+    dfnet.lin{l}: 98 / 14 tensors for configs/amass.yaml's seven linear layers."""
     from .synth import DFNET_DIMS, DFNET_DIMS_NOENC, state_dict_shapes
-    return list(state_dict_shapes(DFNET_DIMS if encoder else DFNET_DIMS_NOENC).keys())
+    first = (DFNET_DIMS if encoder else DFNET_DIMS_NOENC)[0]
+    return list(state_dict_shapes((first,) + (1,) * n_lin).keys())
 
 
 def _tensor_table(sd_np):
-    keys = state_dict_order(encoder=any(k.startswith("enc.") for k in sd_np))
+    n_lin = sum(1 for k in sd_np if k.startswith("dfnet.lin") and k.endswith(".weight"))
+    keys = state_dict_order(encoder=any(k.startswith("enc.") for k in sd_np), n_lin=n_lin)
     arrs = [np.ascontiguousarray(np.asarray(sd_np[k], dtype=np.float32)) for k in keys]
     ptrs = (c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
     numel = (c_int64 * len(arrs))(*[a.size for a in arrs])
@@ -212,12 +215,19 @@ class Engine:
         cfg.precision = PRECISION_CODES[precision]
         if not encoder:
             cfg.dims[0] = 84          # model.StrEnc.use = False: DFNet on the 21 x 4 normalised quaternions
-        if hidden is not None:        # model.DFNet.dims: hidden widths narrower than configs/amass.yaml run zero padded
+        if hidden is not None:
+            # model.DFNet.dims (reference net_modules.py:14-28: a free list).  Six hidden widths within configs/amass.yaml's run on
+            # the fused kernels (narrower ones zero padded); any other list of 1 .. 7 widths up to 1024 on the runtime-planned
+            # kernels (csrc/pndf_generic.hip, exact fp32); pndf_create refuses the rest
             hidden = [int(w) for w in hidden]
-            if len(hidden) != 6:
-                raise PndfError(f"DFNet with {len(hidden)} hidden layers: the kernels implement the 6 of configs/amass.yaml")
+            if not 1 <= len(hidden) <= 7:
+                raise PndfError(f"DFNet with {len(hidden)} hidden layers: 1 .. 7 are implemented")
+            cfg.n_dims = len(hidden) + 2
+            for i in range(1, len(cfg.dims)):
+                cfg.dims[i] = 0
             for i, w in enumerate(hidden):
                 cfg.dims[i + 1] = w
+            cfg.dims[len(hidden) + 1] = 1
         self.precision = precision
         self.handle = c_void_p()
         rc = self.lib.pndf_create(ctypes.byref(self.handle), ctypes.byref(cfg), int(device))
@@ -325,10 +335,14 @@ class CpuEngine:
             cfg.dims[0] = 84
         if hidden is not None:
             hidden = [int(w) for w in hidden]
-            if len(hidden) != 6:
-                raise PndfError(f"DFNet with {len(hidden)} hidden layers: 6 as in configs/amass.yaml")
+            if not 1 <= len(hidden) <= 7:
+                raise PndfError(f"DFNet with {len(hidden)} hidden layers: 1 .. 7 are implemented")
+            cfg.n_dims = len(hidden) + 2
+            for i in range(1, len(cfg.dims)):
+                cfg.dims[i] = 0
             for i, w in enumerate(hidden):
                 cfg.dims[i + 1] = w
+            cfg.dims[len(hidden) + 1] = 1
         self.precision = "fp32"
         self.handle = c_void_p()
         rc = self.lib.pndf_cpu_create(ctypes.byref(self.handle), ctypes.byref(cfg))

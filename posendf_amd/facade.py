@@ -88,6 +88,7 @@ class PoseNDF(nn.Module):
         self._act = opt["model"]["DFNet"]["act"]
         self._beta = float(opt["model"]["DFNet"].get("beta", 100.0))
         if self.enc is not None and opt["model"]["StrEnc"]["act"] != self._act:
+            # (net_modules.py:128 vs :30 would allow it; no config of the reference does it: configs/amass.yaml:31,42)
             raise PndfError("StrEnc.act and DFNet.act differ; the fused kernel uses one activation family")
         if (self.enc is not None and self._act == "softplus"
                 and float(opt["model"]["StrEnc"].get("beta", self._beta)) != self._beta):
@@ -151,7 +152,7 @@ class PoseNDF(nn.Module):
                     "opt['engine'] = {'precision': 'fp32'} or PNDF_PRECISION=fp32 selects the exact fp32 MFMA kernel", idx)
         if entry[1] != fp:          # first use, load_state_dict, optimiser step, .to(): re-pack the weights
             sd = self.state_dict()
-            weights = {k: sd[k].detach().float().cpu().numpy() for k in state_dict_order(self.enc is not None)}
+            weights = {k: sd[k].detach().float().cpu().numpy() for k in state_dict_order(self.enc is not None, len(self._hidden) + 1)}
             try:
                 entry[0].load_weights(weights)
             except PndfError as e:

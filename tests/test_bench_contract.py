@@ -48,8 +48,10 @@ def test_bench_json_line_default_precision():
     # B = 4,096 on ALL physical cores; the calibration of smaller thread counts sits beside the figure, it does
     # not choose it
     assert cb["batch"] == 4096 and "B=4096" in cb["sample"] and str(cb["cores"]) in cb["thread_calibration_pose_steps_per_s"]
-    assert f"{cb['cores']} threads = all physical cores" in cb["sample"] and len(cb["runs_s"]) == 3
+    assert f"{cb['cores']} threads = all physical cores" in cb["sample"] and len(cb["runs_s"]) in (1, 3)      # (1: a host too contended for three)
     assert cb["cores"] == max(int(k) for k in cb["thread_calibration_pose_steps_per_s"])
+    if cb["cgroup_cpu_quota"]:              # the container's CFS quota caps the thread count (threads beyond it are throttled, not run)
+        assert cb["cores"] <= cb["cgroup_cpu_quota"]
     assert cb["pinned_to"].startswith(f"{cb['cores']} distinct physical cores") and len(cb["host_loadavg_before_after"]) == 2
     assert {"sclk_mhz", "package_w", "telemetry_source"} <= set(d["roofline"])      # clock / power beside the time
     if d["roofline"]["sclk_mhz"] is not None:

@@ -136,7 +136,7 @@ def test_host_twin_configurations_and_refusals():
     lib = load_library()
     assert lib.pndf_forward_cpu(eng.handle, None, out.ctypes.data, 2) == -1
     with pytest.raises(PndfError):
-        CpuEngine("lrelu", hidden=[256, 512, 2048, 512, 256, 64])       # wider than configs/amass.yaml: refused like pndf_create
+        CpuEngine("lrelu", hidden=[256, 512, 2048, 512, 256, 64])       # wider than 1024: refused like pndf_create
 
 
 def test_reference_projection_loop_runs_unchanged_on_cpu():

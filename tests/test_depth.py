@@ -1,0 +1,203 @@
+"""DFNets of other depths and widths than configs/amass.yaml.
+
+reference model/network/net_modules.py:14-28 builds DFNet from a free list of hidden widths; tests/golden/make_golden_depth.py
+runs the REAL reference on seven such networks (one to seven hidden layers, widths up to 1024, with and without the structure
+encoder, all three activations) and records inputs and outputs.  Here:
+  * CPU: the numpy oracle is pinned on those vectors (so it is a valid checker at these depths too), and the library's host twins
+    (`train.device: cpu`) reproduce them;
+  * GPU: `posendf_amd.PoseNDF` built from the same config runs on the runtime-planned HIP kernels (csrc/pndf_generic.hip) through
+    the C ABI and is held to the same per-pose gates as the fused kernels; what the engine still refuses is asserted too.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, d_rows, fp32_noise, outlier_gate, pose_gate, rel_err_rows, traj_envelope, traj_margin
+
+CASES = ["d1_lrelu", "d4_lrelu", "d4_softplus", "d7_lrelu", "d7_softplus", "wide_relu", "noenc_d3_lrelu"]
+TOL = 1e-4
+
+
+def load_case(name):
+    g = dict(np.load(os.path.join(GOLDEN, f"depth_{name}.npz")))
+    hidden = [int(w) for w in g["hidden"]]
+    act, enc = str(g["act"]), bool(g["encoder"])
+    seed, gain, ob = (float(x) for x in g["weights"])
+    from posendf_amd import synth
+    sd = synth.make_weights(int(seed), gain, ob, dims=(126 if enc else 84, *hidden, 1))
+    return g, hidden, act, enc, sd
+
+
+def config_for(hidden, act, enc, device):
+    from posendf_amd import amass_config
+    cfg = amass_config(act, device)
+    cfg["model"]["DFNet"]["dims"] = list(hidden)
+    cfg["model"]["StrEnc"]["use"] = enc
+    if not enc:
+        cfg["model"]["DFNet"]["in_dim"] = 84
+    return cfg
+
+
+def kink_exempt(q, sd, act):
+    from oracle import posendf_np as onp
+    return None if act == "softplus" else onp.kink_margin(q, sd, act) < 1e-5
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_is_pinned_at_other_depths(name):
+    """fp64: the oracle IS the reference to rounding; fp32: within the reference arithmetic's own fp32 noise."""
+    from oracle import posendf_np as onp
+    g, hidden, act, enc, sd = load_case(name)
+    d64, g64 = onp.forward_grad(g["q"], sd, act, dtype=np.float64)
+    assert np.abs(d64 - g["d_f64"]).max() <= 1e-11 * max(np.abs(g["d_f64"]).max(), 1.0)
+    assert rel_err_rows(g64, g["dq_f64"]).max() <= 1e-9
+    q10, _ = onp.project(g["q"], sd, steps=10, act=act, dtype=np.float64)
+    live = np.isfinite(g["q10_f64"]).all(axis=(1, 2))
+    assert live.sum() >= len(live) - 1 and rel_err_rows(q10[live], g["q10_f64"][live]).max() <= 1e-7
+    d32, g32 = onp.forward_grad(g["q"], sd, act)
+    sig_d, sig_g, _, _ = fp32_noise(g["q"], sd, act)
+    pose_gate(d_rows(g["d_f32"], g["d_f64"]), np.maximum(sig_d, d_rows(d32, g["d_f64"])), f"{name} reference fp32 d")
+    pose_gate(rel_err_rows(g["dq_f32"], g["dq_f64"]), np.maximum(sig_g, rel_err_rows(g32, g["dq_f64"])), f"{name} reference fp32 dq",
+              exempt=kink_exempt(g["q"], sd, act))
+
+
+def _check_network(net, torch, g, act, sd, name, device):
+    """single step (d, d d/d q), the autograd contract with an arbitrary grad_output, and the 1 / 10-step projections of a
+    PoseNDF built from the case's config, against the reference's vectors through the gates of the fused kernels"""
+    q = torch.from_numpy(g["q"]).to(device).requires_grad_(True)
+    d = net(q, train=False)["dist_pred"]
+    assert d.shape == (len(g["q"]), 1)
+    (dq,) = torch.autograd.grad(d, q, grad_outputs=torch.ones_like(d))
+    d_np, dq_np = d.detach().cpu().numpy(), dq.cpu().numpy()
+    ref_d, ref_g = d_rows(g["d_f32"], g["d_f64"]), rel_err_rows(g["dq_f32"], g["dq_f64"])
+    sig_d, sig_g, _, _ = fp32_noise(g["q"], sd, act, extra_d=[ref_d], extra_g=[ref_g])
+    ex = kink_exempt(g["q"], sd, act)
+    e_d, e_g = d_rows(d_np, g["d_f64"]), rel_err_rows(dq_np, g["dq_f64"])
+    pose_gate(e_d, sig_d, f"{name} d")
+    pose_gate(e_g, sig_g, f"{name} dq", exempt=ex)
+    outlier_gate(e_g, ref_g, TOL, f"{name} dq", margin=traj_margin(g["q"], sd, act), sigma=sig_g)
+    assert np.isfinite(d_np).all() and np.isfinite(dq_np).all()
+    if act != "softplus":      # clipped poses: exactly zero distance and gradient where the reference's two runs agree on it
+        z = (g["d_f32"][:, 0] == 0) & (g["d_f64"][:, 0] == 0)
+        assert np.all(d_np[z, 0] == 0) and np.all(dq_np[z] == 0)
+    # autograd contract (motion_denoise.py:82-83,97-98)
+    q2 = torch.from_numpy(g["q"]).to(device).requires_grad_(True)
+    (net(q2, train=False)["dist_pred"] * torch.from_numpy(g["grad_out"]).to(device)).sum().backward()
+    truth = g["dq_f64"] * g["grad_out"].reshape(-1, 1, 1)
+    ref_rows = rel_err_rows(g["grad_pose_f32"], truth)
+    _, sig_go, _, _ = fp32_noise(g["q"], sd, act, extra_g=[ref_rows])
+    outlier_gate(rel_err_rows(q2.grad.cpu().numpy(), truth), ref_rows, TOL, f"{name} grad_out", margin=traj_margin(g["q"], sd, act), sigma=sig_go)
+    # projection loop (sample_poses.py:67-74): 1 and 10 steps, free running
+    for steps in (1, 10):
+        qp, dl = net.project(torch.from_numpy(g["q"]).to(device), steps=steps)
+        truth_q = g[f"q{steps}_f64"]
+        live = np.isfinite(truth_q).all(axis=(1, 2)) & np.isfinite(g[f"q{steps}_f32"]).all(axis=(1, 2))      # (the eps-clamp edge pose may overflow in both runs)
+        env = traj_envelope(g["q"], sd, act, steps, truth_q)
+        outlier_gate(rel_err_rows(qp.cpu().numpy()[live], truth_q[live]), rel_err_rows(g[f"q{steps}_f32"][live], truth_q[live]), TOL,
+                     f"{name} project {steps}", margin=None if env["margin"] is None else env["margin"][live], sigma=env["sigma"][live])
+        assert np.isfinite(dl.cpu().numpy()[live]).all()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_host_twins_at_other_depths(name):
+    """`train.device: cpu`: the library's plain-C++ host twins (csrc/pndf_cpu.cpp) take the same configurations."""
+    import torch
+    from posendf_amd import PoseNDF
+    g, hidden, act, enc, sd = load_case(name)
+    net = PoseNDF(config_for(hidden, act, enc, "cpu"))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    _check_network(net, torch, g, act, sd, name + " host twin", "cpu")
+    assert net._engine_for(torch.device("cpu")).kernel_name() == "pndf_cpu (host twin)"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+@pytest.mark.parametrize("name", CASES)
+def test_runtime_planned_kernels(name, precision):
+    """The HIP path: every depth / width runs on pndf_generic_{relu,softplus}_kernel through the C ABI -- exact fp32 whatever
+    `precision` the config asks for -- and meets the gates of the fused kernels."""
+    import torch
+    from posendf_amd import PoseNDF
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X (no CPU fallback exists)"
+    g, hidden, act, enc, sd = load_case(name)
+    cfg = config_for(hidden, act, enc, "cuda:0")
+    cfg["engine"] = {"precision": precision}
+    net = PoseNDF(cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    _check_network(net, torch, g, act, sd, f"{name} {precision}", "cuda:0")
+    want = "pndf_generic_softplus_kernel" if act == "softplus" else "pndf_generic_relu_kernel"
+    assert net._engine_for(torch.device("cuda:0")).kernel_name() == want
+
+
+@pytest.mark.gpu
+def test_runtime_planned_kernels_full_size_properties():
+    """B = 16,411 (ragged: 256 whole blocks + 27 poses, more blocks than compute units: the persistent grid walks them) on the
+    four-hidden-layer network: bit-exact permutation equivariance and determinism, step composition (10 = 4 + 6 steps,
+    bit-exact), in-place operation, a sample against the oracle's fp64 trajectory, steps = 0 identity."""
+    import torch
+    from oracle import posendf_np as onp
+    from posendf_amd import PoseNDF, synth
+    g, hidden, act, enc, sd = load_case("d4_lrelu")
+    net = PoseNDF(config_for(hidden, act, enc, "cuda:0"))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    B = 16411
+    q_np = synth.make_poses(B, seed=91)
+    q = torch.from_numpy(q_np).cuda()
+    a, da = net.project(q, steps=10)
+    b, db = net.project(q, steps=10)
+    assert torch.equal(a, b) and torch.equal(da, db)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).cuda()
+    c, dc = net.project(q[perm], steps=10)
+    assert torch.equal(c, a[perm]) and torch.equal(dc, da[perm])
+    m, _ = net.project(q, steps=4)
+    e, de = net.project(m, steps=6)
+    assert torch.equal(e, a) and torch.equal(de, da)
+    z, dz = net.project(q, steps=0)
+    assert torch.equal(z, q) and float(dz.abs().max()) == 0.0
+    idx = np.random.default_rng(0).choice(B, 64, replace=False)
+    q64, _ = onp.project(q_np[idx], sd, steps=10, act=act, dtype=np.float64)
+    q32, _ = onp.project(q_np[idx], sd, steps=10, act=act)
+    env = traj_envelope(q_np[idx], sd, act, 10, q64)
+    outlier_gate(rel_err_rows(a[idx].cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, "generic full size", margin=env["margin"], sigma=env["sigma"])
+    # forward + gradient with grad_outputs at the same size, against the forward-only launch
+    qg = q.clone().requires_grad_(True)
+    d = net(qg, train=False)["dist_pred"]
+    go = torch.from_numpy(np.random.default_rng(1).normal(size=(B, 1)).astype(np.float32)).cuda()
+    (gq,) = torch.autograd.grad(d, qg, grad_outputs=go)
+    (g1,) = torch.autograd.grad(net(qg, train=False)["dist_pred"].sum(), qg)
+    assert torch.allclose(gq, go.view(-1, 1, 1) * g1, rtol=2e-6, atol=0)
+    with torch.no_grad():
+        assert torch.equal(net(q, train=False)["dist_pred"], d.detach())
+
+
+def test_what_the_engine_still_refuses():
+    """pndf_create accepts n_dims 3 .. 9 with hidden widths 1 .. 1024; beyond that it fails loudly (no silent truncation)."""
+    import ctypes
+    from posendf_amd import engine
+    lib = engine.load_library()
+    h = ctypes.c_void_p()
+    cfg = engine.PndfConfig()
+    for n_dims, dims, why in ((2, [126, 1], b"depth"), (10, [126] + [64] * 8 + [1], b"depth"), (5, [126, 64, 1025, 64, 1], b"widths"),
+                              (5, [126, 64, 0, 64, 1], b"widths"), (5, [100, 64, 64, 64, 1], b"in_dim"), (5, [126, 64, 64, 64, 2], b"in_dim")):
+        lib.pndf_default_config(ctypes.byref(cfg), 1, 100.0)
+        cfg.n_dims = n_dims
+        for i in range(16):
+            cfg.dims[i] = dims[i] if i < len(dims) else 0
+        assert lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0) == -4, (n_dims, dims)
+        assert why in lib.pndf_last_error(None), (why, lib.pndf_last_error(None))
+    for hidden in ([], [8] * 8):
+        with pytest.raises(engine.PndfError, match="hidden layers"):
+            engine.CpuEngine("lrelu", hidden=hidden)
+    # accepted shapes get as far as the device (no HIP device here -> -6, on a GPU box 0)
+    lib.pndf_default_config(ctypes.byref(cfg), 2, 100.0)
+    cfg.n_dims = 4
+    for i, w in enumerate([84, 1024, 1, 1]):
+        cfg.dims[i] = w
+    rc = lib.pndf_create(ctypes.byref(h), ctypes.byref(cfg), 0)
+    assert rc in (0, -6), (rc, lib.pndf_last_error(None))
+    if h.value:
+        lib.pndf_destroy(h)

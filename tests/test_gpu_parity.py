@@ -296,12 +296,15 @@ def test_weight_reload_and_errors(torch_cuda):
     d_c = net(q, train=False)["dist_pred"]
     assert torch.allclose(d_c, d_b + 1.0, atol=1e-5)
     cfg = amass_config("lrelu", "cuda:0")
-    cfg["model"]["DFNet"]["dims"] = [256, 512, 2048, 512, 256, 64]     # wider than the kernels' layout: loud failure
+    cfg["model"]["DFNet"]["dims"] = [256, 512, 2048, 512, 256, 64]     # wider than 1024: loud failure
     with pytest.raises(PndfError):
         PoseNDF(cfg)(q, train=False)
-    cfg["model"]["DFNet"]["dims"] = [256, 512, 1024, 512, 256]         # another depth: loud failure
+    cfg["model"]["DFNet"]["dims"] = [64] * 8                           # deeper than seven hidden layers: loud failure
     with pytest.raises(PndfError):
         PoseNDF(cfg)(q, train=False)
+    cfg["model"]["DFNet"]["dims"] = [256, 512, 1024, 512, 256]         # another depth RUNS (runtime-planned kernels, tests/test_depth.py)
+    other = PoseNDF(cfg)
+    assert other(q, train=False)["dist_pred"].shape == (64, 1) and other._engine_for(q.device).kernel_name() == "pndf_generic_relu_kernel"
     with pytest.raises(RuntimeError):                      # no double backward on the engine path
         qq = q.clone().requires_grad_(True)
         dd = net(qq, train=False)["dist_pred"]

@@ -33,20 +33,30 @@ def quant(kind):
             u=((u+0x80)&0xFFFFFF00).astype(np.uint32)
             return u.view(np.float32).astype(dt)
         if kind=="u24": return (np.round(d.astype(np.float64)*(2**24))/2**24).astype(dt)
+        if kind=="e7m17":   # round 6: 0 < d <= 1, so bits 31 (sign) and 30 (top exponent bit) of the fp32 are ALWAYS zero: bits 29..6 are a
+            u=d.astype(np.float32).view(np.uint32).astype(np.uint64)      # 3-byte format with fp32's full range below 2 and 18 significant bits
+            u=np.minimum((u+0x20)&0xFFFFFFC0, 0x3F800000).astype(np.uint32)      # rne to 17 explicit mantissa bits (a carry into 1.0 stays 1.0)
+            return u.view(np.float32).astype(dt)
         return d
     return f
 print("# softplus derivative storage formats against the per-pose gradient gate (tools/sp_derivative_formats.py; 256 poses per weight set)")
+print("# round 6: e7m17 = bits 29..6 of the fp32 (sign and top exponent bit are always 0 for 0 < d <= 1), rne (3 B); within1e-4 = fraction of poses inside the north_star bar (1e-4, or 2 x the fp32 arithmetic's own error where that is larger)")
 print("# fp32 = product (4 B); u16 = unsigned fixed point round(d 65535) (2 B); f16 = fp16 rne (2 B); f16+8 = fp16 hi + 8-bit lo in 1/256 ulp (3 B); fp24 = the top three bytes of the fp32, rne (3 B); u24 = 24-bit fixed point (3 B)")
 sets=[(0,2.0,0.1),(0,2.5,0.1),(1,1.0,0.1),(3,0.5,0.1),(4,2.5,0.05),(2,3.0,0.1),(11,1.5,0.1),(14,2.8,0.1),(17,3.6,0.1)]
 for ws in sets:
     sd=synth.make_weights(*ws); q=synth.make_poses(256, seed=77)
     sig_d,sig_g,d64,g64=fp32_noise(q,sd,"softplus")
     row=f"s{ws[0]}g{ws[1]}"
-    for kind in ("fp32","u16","f16","f16+8","fp24","u24"):
+    ref32=None
+    for kind in ("fp32","u16","f16","f16+8","fp24","u24","e7m17"):
         onp._dact=quant(kind)
         d,g=onp.forward_grad(q,sd,"softplus",dtype=np.float32)
         onp._dact=orig
         eg=rel_err_rows(g,g64)
+        if kind=="fp32": ref32=eg
         ratio=(eg/(8*sig_g+8e-6)).max()
-        row+=f" | {kind}: dq med {np.median(eg):.1e} p95 {np.percentile(eg,95):.1e} max {eg.max():.1e} gate {ratio:.2f}"
+        # north_star's contract: 1e-4 relative on the outputs -- wherever the reference's own fp32 arithmetic meets it (a pose on which
+        # the fp32 run is itself > 1e-4 from the fp64 run is judged against 2 x the fp32 run's error instead)
+        ok=(eg<=np.maximum(1e-4,2*ref32)).mean()
+        row+=f" | {kind}: dq med {np.median(eg):.1e} p95 {np.percentile(eg,95):.1e} max {eg.max():.1e} gate {ratio:.2f} within1e-4 {ok:.3f}"
     print(row,flush=True)
