@@ -33,7 +33,7 @@ static_assert(offsetof(PndfKernelArgs, stream) == 32 && offsetof(PndfKernelArgs,
 
 // ---- runtime-planned DFNet (pndf_generic.hip): any depth / width the reference's `dims` list can describe
 constexpr int PNDF_GEN_MAXLIN = 8;         // linear layers (n_dims 3 .. 9)
-constexpr int PNDF_GEN_NTB = 4;            // output tiles of one register block
+constexpr int PNDF_GEN_NTB = 8;            // output tiles of one group: its 32 MFMAs hide the fetch of the next group's weights
 constexpr int PNDF_GEN_XTILES = 64;        // tiles of the widest activation (1024 rows)
 struct PndfGenericArgs {
     const float* q_in;      // [B,84]

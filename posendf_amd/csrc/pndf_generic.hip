@@ -14,10 +14,14 @@
 //     touches (every lane stores and re-loads exactly its 16 bytes of a tile: private memory with a coalesced layout -- no
 //     barrier, no fence): activations ping / pong (64 tiles each) and the activation derivative of every hidden unit (fp32
 //     factor: 1 | slope, or softplus' e / (1 + e)) for the backward pass;
-//   * weights: fp32 tiles `tile(M, nt, kt)` in consumption order [block of 4 output tiles][k tile][tile of the block], read
-//     straight from global memory (every wave of every workgroup reads the same 1-KiB tiles: L1 / L2 hits), one block of four
-//     accumulators per pass so that an activation tile is loaded once per sixteen MFMAs; the next k step's five loads are issued
-//     before the current step's MFMAs (an fp32 MFMA occupies the pipe for 32 cycles: the loads hide behind them).
+//   * the accumulators of up to 32 output tiles (512 rows: 128 registers) stay resident, so an operand tile is loaded once per
+//     layer (twice for layers wider than 512) and prefetched a whole k step (up to 128 MFMAs) ahead -- it comes back from L2 /
+//     Infinity Cache;
+//     the first form of this kernel (one block of four output tiles per pass: the operand re-read once per block, prefetched
+//     16 MFMAs ahead) ran at 0.22 of the fp32 MFMA peak, waiting for those loads (profiles/r06/generic_arch_v1.jsonl);
+//   * weights: fp32 tiles `tile(M, nt, kt)` in consumption order [k tile][output tile], read straight from global memory (every
+//     wave of every workgroup reads the same 1-KiB tiles: L1 / L2 hits), a group of four prefetched while the previous group's
+//     sixteen MFMAs issue (an fp32 MFMA occupies the pipe for 32 cycles).
 // Roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic work per pose-step 4 x sum_l in_l out_l FLOP.  Not the benchmark path
 // (BASELINE.json names amass.yaml); measured in profiles/r06/generic_arch.txt.
 #include "pndf_device.h"
@@ -38,25 +42,44 @@ constexpr int NTB = PNDF_GEN_NTB;
 constexpr int TILE_F4 = 64;              // f32x4 elements of a weight tile (one per lane)
 constexpr int SLOT_F4 = WG_THREADS;      // f32x4 elements of a scratch tile slot (one per thread of the workgroup)
 
-// acc[j] += sum_k W(block, k, j) X[k]: `w` = this lane's element of the block's first tile, `x` = this thread's element of the
-// operand's tile 0.  Software-pipelined one k step deep; the last trip re-reads its own tiles instead of branching.
-__device__ __forceinline__ void gen_gemm(const f32x4* __restrict__ w, const f32x4* x, int nk, f32x4 (&acc)[NTB]) {
+// acc[t] += sum_k W(t, k) X[k] for `NG * NTB` output tiles (one pass over a layer) at once: every operand tile X[k] is loaded
+// ONCE per pass (the operand lives in the workgroup's global scratch -- L2 / Infinity Cache latency -- and is prefetched a whole
+// k step, up to 128 MFMAs, ahead); the weights stream through in the order they are packed, [k][group][tile of the group], one group
+// (four 1-KiB tiles, the same for every wave of every workgroup: L1 / L2 hits) prefetched while the previous one is multiplied.
+// `w` = this lane's element of the layer's first weight tile, `x` = this thread's element of the operand's tile 0.
+// Register indices must be compile-time, so the number of groups is a template parameter: the plan rounds a layer's output
+// tiles up to whole groups of NTB (host side: gen_round_tiles) and the layer code is instantiated per group count of a pass.  (A
+// first form kept 64 accumulators under run-time guards `if (group < ng)`: hipcc answered with 700 spilled registers.)
+template <int NG>
+__device__ __forceinline__ void gen_layer(const f32x4* __restrict__ w, const f32x4* x, int nk, f32x4 (&acc)[NG * NTB]) {
+    // One group (NTB = 8 tiles = 32 MFMAs = 1,024 cycles of matrix pipe) of weights is in flight ahead of the MFMAs that use it, and
+    // the operand tile of the next k step.  The distance is what matters: an L2 hit is ~480 cycles and 3 % of the weight stream
+    // misses the L2.  With groups of four tiles (512 cycles ahead) this loop ran at 0.45 of the fp32 MFMA peak; the first form of
+    // the kernel (operand re-read per block of four tiles) at 0.22 (profiles/r06/generic_arch_v1.jsonl, _v2.jsonl).  A deeper
+    // pipeline through registers does not work: rotating three buffers by copies makes hipcc wait for the YOUNGEST load at the end
+    // of every group (`s_waitcnt vmcnt(0)` at the loop head); the buffers would have to rotate by name, i.e. by unrolling.
+    const f32x4* const wlast = w + (size_t)(nk * NG - 1) * NTB * TILE_F4;      // (the last group is re-read instead of branching)
     f32x4 wc[NTB], xc = x[0];
 #pragma unroll
     for (int j = 0; j < NTB; ++j) wc[j] = w[j * TILE_F4];
+    const f32x4* wnext = w + NTB * TILE_F4;                    // the group after the current one, in stream order
     for (int k = 0; k < nk; ++k) {
-        const int kn = (k + 1 < nk) ? k + 1 : k;
-        f32x4 wn[NTB];
+        const f32x4 xn = x[(size_t)((k + 1 < nk) ? k + 1 : k) * SLOT_F4];
 #pragma unroll
-        for (int j = 0; j < NTB; ++j) wn[j] = w[(size_t)(kn * NTB + j) * TILE_F4];
-        const f32x4 xn = x[(size_t)kn * SLOT_F4];
+        for (int gi = 0; gi < NG; ++gi) {
+            f32x4 wn[NTB];
+            const f32x4* src = (wnext <= wlast) ? wnext : wlast;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+            for (int j = 0; j < NTB; ++j) wn[j] = src[j * TILE_F4];
+            wnext += NTB * TILE_F4;
 #pragma unroll
-            for (int j = 0; j < NTB; ++j) acc[j] = mfma4(wc[j][s], xc[s], acc[j]);      // four independent chains
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) acc[gi * NTB + j] = mfma4(wc[j][s], xc[s], acc[gi * NTB + j]);      // eight independent chains
+            }
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) wc[j] = wn[j];
         }
-#pragma unroll
-        for (int j = 0; j < NTB; ++j) wc[j] = wn[j];
         xc = xn;
     }
 }
@@ -75,6 +98,51 @@ __device__ __forceinline__ void gen_act(f32x4& z, f32x4& dfac, float slope, cons
         }
     }
 }
+
+// one forward layer with NG groups of output tiles: bias -> accumulate -> (hidden layers) activation, derivative factor
+template <int NG, bool SP>
+__device__ __forceinline__ void gen_forward(const f32x4* w, const float* bias, const f32x4* xin, f32x4* xout, f32x4* dl, int nk, bool last,
+                                            float slope, const SpK& k, int g, f32x4& zlast) {
+    f32x4 acc[NG * NTB];
+#pragma unroll
+    for (int t = 0; t < NG * NTB; ++t) acc[t] = *(const f32x4*)(bias + 16 * t + 4 * g);
+    gen_layer<NG>(w, xin, nk, acc);
+    if (last) {                    // the output layer: one unit, row 0 of tile 0; its activation is the caller's
+        zlast = acc[0];
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < NG * NTB; ++t) {
+        f32x4 df;
+        gen_act<SP>(acc[t], df, slope, k);
+        xout[(size_t)t * SLOT_F4] = acc[t];
+        dl[(size_t)t * SLOT_F4] = df;
+        if (t % NTB == NTB - 1) __builtin_amdgcn_sched_barrier(0);      // a group at a time: the accumulators fill up to half the register file
+    }
+}
+
+// one backward layer: G_in = W^T G_out, times the derivative factors of the layer below (l > 0) or into the pose's feature row
+template <int NG>
+__device__ __forceinline__ void gen_backward(const f32x4* w, const f32x4* gin, f32x4* gout, const f32x4* dprev, float* my_f, int nk, int g, int t0) {
+    f32x4 acc[NG * NTB];
+#pragma unroll
+    for (int t = 0; t < NG * NTB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gen_layer<NG>(w, gin, nk, acc);
+#pragma unroll
+    for (int t = 0; t < NG * NTB; ++t) {
+        if (dprev) gout[(size_t)t * SLOT_F4] = acc[t] * dprev[(size_t)t * SLOT_F4];      // x act'(z_{l-1})
+        else if (t0 + t < 8) *(f32x4*)(my_f + 16 * (t0 + t) + 4 * g) = acc[t];           // d z_out / d x0 (t0 = 0: one pass)
+        // (without it hipcc hoists all derivative loads above the first multiply: up to 256 more live registers)
+        if (t % NTB == NTB - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the group counts the layer code is instantiated for (the plan rounds up to the next one: at most a third of a layer is padding)
+// A pass keeps at most 4 groups = 32 tiles = 128 accumulator registers (a whole 1024-wide layer at once -- 256 -- left hipcc 150 - 220
+// spilled registers: everything that is not an MFMA accumulator has to fit the 256 architectural VGPRs); wider layers take two
+// passes, each of which reads the operand tiles once.
+#define PNDF_GEN_GROUP_CASES(X) X(1) X(2) X(3) X(4)
+constexpr int GEN_PASS_GROUPS = 4;
 
 template <bool SP>
 __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
@@ -153,27 +221,18 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
             // ---------------- trunk forward, layer by layer (net_modules.py:51-69)
             f32x4 zlast = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int l = 0; l < L; ++l) {
-                const int nk = args.kt[l], nb = args.ntp[l] / NTB;
+                const int nk = args.kt[l], ng = args.ntp[l] / NTB;
                 const f32x4* w = (const f32x4*)args.wfwd + (size_t)args.wf_off[l] * TILE_F4 + lane;
                 const float* bias = args.lbias + args.b_off[l];
-                const f32x4* xin = xbuf[l & 1];
-                f32x4* xout = xbuf[(l + 1) & 1];
                 f32x4* dl = wg + (size_t)args.d_off[l] * SLOT_F4;
-                for (int b = 0; b < nb; ++b) {
-                    f32x4 acc[NTB];
-#pragma unroll
-                    for (int j = 0; j < NTB; ++j) acc[j] = *(const f32x4*)(bias + 16 * (b * NTB + j) + 4 * g);
-                    gen_gemm(w + (size_t)b * nk * NTB * TILE_F4, xin, nk, acc);
-                    if (l == L - 1) {          // the output layer: one unit, row 0 of tile 0; its activation follows below
-                        if (b == 0) zlast = acc[0];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < NTB; ++j) {
-                            f32x4 df;
-                            gen_act<SP>(acc[j], df, args.slope, ap.k);
-                            xout[(size_t)(b * NTB + j) * SLOT_F4] = acc[j];
-                            dl[(size_t)(b * NTB + j) * SLOT_F4] = df;
-                        }
+                for (int g0 = 0; g0 < ng; g0 += GEN_PASS_GROUPS) {      // passes of at most 8 groups of output tiles
+                    const int n = (ng - g0 < GEN_PASS_GROUPS) ? ng - g0 : GEN_PASS_GROUPS, t0 = g0 * NTB;
+                    const f32x4* wp = w + (size_t)g0 * nk * NTB * TILE_F4;      // stream order: [pass][k tile][tile of the pass]
+                    switch (n) {
+#define PNDF_GEN_FWD(N) case N: gen_forward<N, SP>(wp, bias + 16 * t0, xbuf[l & 1], xbuf[(l + 1) & 1] + (size_t)t0 * SLOT_F4, dl + (size_t)t0 * SLOT_F4, nk, l == L - 1, args.slope, ap.k, g, zlast); break;
+                        PNDF_GEN_GROUP_CASES(PNDF_GEN_FWD)
+#undef PNDF_GEN_FWD
+                        default: break;      // (pndf_generic_create plans no other group count)
                     }
                 }
             }
@@ -200,21 +259,17 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
             int cur = 0;
             xbuf[0][0] = (g == 0) ? f32x4{1.f, 0.f, 0.f, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
             for (int l = L - 1; l >= 0; --l) {
-                const int nk = args.nt[l], nb = args.ktp[l] / NTB;
+                const int nk = args.nt[l], ng = args.ktp[l] / NTB;
                 const f32x4* w = (const f32x4*)args.wbwd + (size_t)args.wb_off[l] * TILE_F4 + lane;
-                const f32x4* gin = xbuf[cur];
-                f32x4* gout = xbuf[cur ^ 1];
                 const f32x4* dprev = (l > 0) ? wg + (size_t)args.d_off[l - 1] * SLOT_F4 : nullptr;
-                for (int b = 0; b < nb; ++b) {
-                    f32x4 acc[NTB];
-#pragma unroll
-                    for (int j = 0; j < NTB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    gen_gemm(w + (size_t)b * nk * NTB * TILE_F4, gin, nk, acc);
-#pragma unroll
-                    for (int j = 0; j < NTB; ++j) {
-                        const int t = b * NTB + j;
-                        if (l > 0) gout[(size_t)t * SLOT_F4] = acc[j] * dprev[(size_t)t * SLOT_F4];      // x act'(z_{l-1})
-                        else if (t < 8) *(f32x4*)(my_f + 16 * t + 4 * g) = acc[j];                       // d z_out / d x0
+                for (int g0 = 0; g0 < ng; g0 += GEN_PASS_GROUPS) {
+                    const int n = (ng - g0 < GEN_PASS_GROUPS) ? ng - g0 : GEN_PASS_GROUPS, t0 = g0 * NTB;
+                    const f32x4* wp = w + (size_t)g0 * nk * NTB * TILE_F4;
+                    switch (n) {
+#define PNDF_GEN_BWD(N) case N: gen_backward<N>(wp, xbuf[cur], xbuf[cur ^ 1] + (size_t)t0 * SLOT_F4, dprev ? dprev + (size_t)t0 * SLOT_F4 : nullptr, my_f, nk, g, t0); break;
+                        PNDF_GEN_GROUP_CASES(PNDF_GEN_BWD)
+#undef PNDF_GEN_BWD
+                        default: break;
                     }
                 }
                 cur ^= 1;
@@ -324,7 +379,12 @@ bool pndf_generic_needed(const pndf_config& cfg) {
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
-static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+// tiles -> tiles rounded up to a group count the layer code exists for (PNDF_GEN_GROUP_CASES)
+static inline int gen_round_tiles(int tiles) {
+    const int groups = ceil_div(tiles, NTB);
+    const int full = (groups - 1) / GEN_PASS_GROUPS * GEN_PASS_GROUPS, rest = groups - full;      // whole passes of 8 groups + a last one
+    return (full + rest) * NTB;      // (every 1 .. GEN_PASS_GROUPS groups of a last pass have their instantiation: PNDF_GEN_GROUP_CASES)
+}
 
 int pndf_generic_create(PndfGeneric** out, const pndf_config& cfg, int resident_wgs, std::string& err) {
     *out = nullptr;
@@ -345,8 +405,8 @@ int pndf_generic_create(PndfGeneric** out, const pndf_config& cfg, int resident_
         const int outw = cfg.dims[l + 1];
         P.kt[l] = ceil_div(in, 16);
         P.nt[l] = ceil_div(outw, 16);
-        P.ktp[l] = round_up(P.kt[l], NTB);
-        P.ntp[l] = round_up(P.nt[l], NTB);
+        P.ktp[l] = gen_round_tiles(P.kt[l]);
+        P.ntp[l] = gen_round_tiles(P.nt[l]);
         P.wf_off[l] = wf;
         P.wb_off[l] = wb;
         P.b_off[l] = bo;
@@ -417,13 +477,14 @@ int pndf_generic_load(PndfGeneric* g, const float* const* tensors, const int64_t
         const int in = g->cfg.dims[l], outw = g->cfg.dims[l + 1];
         const pndf_pack::Mat F{lin[2 * l], outw, in, false}, T{lin[2 * l], outw, in, true};
         float* dst = wf.data() + (size_t)P.wf_off[l] * TILE_FLOATS;
-        for (int b = 0; b < P.ntp[l] / NTB; ++b)
+        const int PT = GEN_PASS_GROUPS * NTB;                  // consumption order: [pass of <= 32 output tiles][k tile][tile of the pass]
+        for (int t0 = 0; t0 < P.ntp[l]; t0 += PT)
             for (int k = 0; k < P.kt[l]; ++k)
-                for (int j = 0; j < NTB; ++j, dst += TILE_FLOATS) pndf_pack::emit_tile(F, b * NTB + j, k, dst);
+                for (int t = t0; t < P.ntp[l] && t < t0 + PT; ++t, dst += TILE_FLOATS) pndf_pack::emit_tile(F, t, k, dst);
         dst = wb.data() + (size_t)P.wb_off[l] * TILE_FLOATS;
-        for (int b = 0; b < P.ktp[l] / NTB; ++b)
+        for (int t0 = 0; t0 < P.ktp[l]; t0 += PT)
             for (int k = 0; k < P.nt[l]; ++k)
-                for (int j = 0; j < NTB; ++j, dst += TILE_FLOATS) pndf_pack::emit_tile(T, b * NTB + j, k, dst);
+                for (int t = t0; t < P.ktp[l] && t < t0 + PT; ++t, dst += TILE_FLOATS) pndf_pack::emit_tile(T, t, k, dst);
         memcpy(lb.data() + P.b_off[l], lin[2 * l + 1], sizeof(float) * outw);
     }
     for (int l = 0; l < 8; ++l) bias[SCALE_OFF + l] = 1.0f;
