@@ -22,7 +22,9 @@ SWEEP_WEIGHTS = ((0, 2.0, 0.1), (0, 2.5, 0.05), (1, 1.0, 0.2), (2, 3.0, 0.05), (
 _HELDOUT = {"1": ((5, 0.7, 0.3), (6, 1.5, 0.1), (7, 2.0, 0.0), (8, 3.5, 0.02), (9, 4.0, 0.1), (10, 2.2, -0.05)),
             "2": ((11, 0.6, 0.25), (12, 1.2, 0.15), (13, 1.8, 0.0), (14, 2.8, 0.03), (15, 3.2, 0.08), (16, 2.4, -0.03)),
             # =3: six more, first run in round 4 after the softplus activation was rewritten (packed fp32, clamp instead of selects)
-            "3": ((21, 0.8, 0.2), (22, 1.4, 0.1), (23, 2.1, 0.0), (24, 3.0, 0.04), (25, 3.6, 0.06), (26, 1.7, -0.02))}
+            "3": ((21, 0.8, 0.2), (22, 1.4, 0.1), (23, 2.1, 0.0), (24, 3.0, 0.04), (25, 3.6, 0.06), (26, 1.7, -0.02)),
+            # =4: six more, first run at the end of round 6 (no gate changed in round 6: a pure re-check on weights never seen)
+            "4": ((31, 0.9, 0.15), (32, 1.6, 0.05), (33, 2.3, 0.0), (34, 2.7, 0.07), (35, 3.3, 0.03), (36, 1.1, -0.04))}
 SWEEP_WEIGHTS = _HELDOUT.get(os.environ.get("PNDF_SWEEP_HELDOUT", ""), SWEEP_WEIGHTS)
 
 

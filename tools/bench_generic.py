@@ -49,7 +49,10 @@ ARMS = [("amass.yaml, fused fp32 kernel", AMASS, "lrelu", True, {}),
         ("one hidden layer", [300], "lrelu", True, {}),
         ("no encoder, three hidden layers", [200, 100, 50], "lrelu", False, {})]
 
-for name, hidden, act, enc, env in ARMS:
+only = [int(a) for a in sys.argv[1:] if a.isdigit()]      # arm indices (default: all)
+for i, (name, hidden, act, enc, env) in enumerate(ARMS):
+    if only and i not in only:
+        continue
     code = CHILD % dict(repo=REPO, hidden=hidden, act=act, enc=enc, B=65536, steps=10)
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     if p.returncode != 0:

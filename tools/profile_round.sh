@@ -18,8 +18,12 @@ bash tools/collect_profiles.sh "$OUT/prof_f16x3_lrelu" "$OUT/collected/f16x3" pn
 bash tools/collect_profiles.sh "$OUT/prof_f16x3_softplus" "$OUT/collected/f16x3_softplus" pndf_fused_split_softplus_kernel "bench.py --precision f16x3 --act softplus $W" > /dev/null
 bash tools/collect_profiles.sh "$OUT/prof_fp32_lrelu" "$OUT/collected/fp32" pndf_fused_relu_kernel "bench.py --precision fp32 --act lrelu $W" > /dev/null
 cp profiles/traffic.json "$OUT/traffic.json"
-python bench.py --steps 5 --warmup 1 > "$OUT/bench_head.json" 2> "$OUT/bench_head.err"
-echo "bench rc=$?"
+# the driver's own command (the default, slim line) with its wall time, then the same with every analysis block
+( time python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_cmd.json" 2> "$OUT/bench_driver_cmd.err" ) 2> "$OUT/bench_driver_cmd.time"
+echo "bench (driver command) rc=$?"
+python bench.py --steps 20 --warmup 5 --diagnostics > "$OUT/bench_head.json" 2> "$OUT/bench_head.err"
+echo "bench --diagnostics rc=$?"
+python tools/bench_generic.py > "$OUT/generic_arch.jsonl" 2> "$OUT/generic_arch.err"
 python tools/gpu_region_timing.py 3 f16x3 lrelu > "$OUT/regions_f16x3_lrelu.txt" 2>&1
 python tools/gpu_region_timing.py 3 f16x3 softplus > "$OUT/regions_f16x3_softplus.txt" 2>&1
 python tools/gpu_region_timing.py 3 fp32 lrelu > "$OUT/regions_fp32_lrelu.txt" 2>&1
