@@ -49,16 +49,20 @@ typedef enum { PNDF_ACT_RELU = 0, PNDF_ACT_LRELU = 1, PNDF_ACT_SOFTPLUS = 2 } pn
 /* Mirrors the keys PoseNDF.__init__ actually reads (reference model/posendf.py:35-55,
  * model/network/net_modules.py:14-41,116-128; configs/amass.yaml:22-43). */
 typedef struct {
-    int32_t act;            /* pndf_act: model.DFNet.act == model.StrEnc.act */
+    int32_t act;            /* pndf_act: model.DFNet.act (and model.StrEnc.act unless enc_act says otherwise) */
     float beta;             /* Softplus beta (amass.yaml:32,43); ignored for relu / lrelu */
     int32_t num_joints;     /* 21 */
     int32_t n_dims;         /* 8: in_dim, dims..., 1 */
     int32_t dims[16];       /* 126,256,512,1024,512,256,64,1 (amass.yaml:26,30); dims[0] = 84 selects the
-                               encoder-less model (model.StrEnc.use = False, model/posendf.py:40-42,73-74); hidden
-                               widths dims[1..6] may be SMALLER (the network runs zero padded on the same kernels),
-                               wider layers or another depth are refused with PNDF_ERR_UNSUPPORTED */
+                               encoder-less model (model.StrEnc.use = False, model/posendf.py:40-42,73-74).  `dims` is the
+                               reference's free list (net_modules.py:14-28): six hidden widths within amass.yaml's run on the
+                               fused kernels (narrower ones zero padded); any other n_dims 3 .. 9 with hidden widths 1 .. 1024
+                               runs on the runtime-planned kernels (exact fp32); beyond that PNDF_ERR_UNSUPPORTED */
     int32_t parent[32];     /* net_utils.py:46 */
     int32_t precision;      /* pndf_precision: arithmetic of the trunk (engine knob, no reference counterpart) */
+    int32_t enc_act;        /* model.StrEnc.act when it differs from model.DFNet.act (net_modules.py:128 reads its own key);
+                               -1 (pndf_default_config) = the same as `act`.  A mixed pair runs on the runtime-planned kernels */
+    float enc_beta;         /* model.StrEnc.beta for a softplus encoder; <= 0 = the same as `beta` */
 } pndf_config;
 
 /* PNDF_PREC_FP32 : exact fp32 MFMA (v_mfma_f32_16x16x4_f32), bit-comparable to an fmaf chain.

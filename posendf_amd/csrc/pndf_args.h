@@ -48,7 +48,8 @@ struct PndfGenericArgs {
     float* scratch;         // gridDim.x * wg_tiles tile slots of 4 KiB: activations (ping, pong), derivative factors per layer
     long long B;
     int steps, mode;
-    float slope, beta;
+    float slope, beta;           // trunk: 0 | 0.01 (relu | lrelu), Softplus beta
+    float enc_slope, enc_beta;   // the encoder's own (model.StrEnc.act / beta; equal to the trunk's in every config of the reference)
     int noenc, nlayers;
     int kt[PNDF_GEN_MAXLIN];     // contraction tiles of the forward pass = ceil(in / 16)
     int nt[PNDF_GEN_MAXLIN];     // contraction tiles of the backward pass = ceil(out / 16)

@@ -108,6 +108,8 @@ extern "C" void pndf_default_config(pndf_config* cfg, int32_t act, float beta) {
     for (int i = 0; i <= NLIN; ++i) cfg->dims[i] = DIMS[i];
     for (int i = 0; i < NJ; ++i) cfg->parent[i] = PARENT[i];
     cfg->precision = PNDF_PREC_FP32;
+    cfg->enc_act = -1;      // the same activation as the trunk (every config of the reference)
+    cfg->enc_beta = 0.f;
 }
 
 static int check_config(pndf_engine* h, const pndf_config* cfg) {
@@ -132,6 +134,10 @@ static int check_config(pndf_engine* h, const pndf_config* cfg) {
         return fail(h, PNDF_ERR_UNSUPPORTED, "unknown activation (relu, lrelu and softplus are implemented)");
     if (cfg->act == PNDF_ACT_SOFTPLUS && !(cfg->beta > 0.f))
         return fail(h, PNDF_ERR_BAD_ARG, "softplus beta must be positive");
+    if (cfg->enc_act != -1 && cfg->enc_act != PNDF_ACT_RELU && cfg->enc_act != PNDF_ACT_LRELU && cfg->enc_act != PNDF_ACT_SOFTPLUS)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "unknown encoder activation (relu, lrelu and softplus are implemented; -1 = the trunk's)");
+    if (cfg->enc_act == PNDF_ACT_SOFTPLUS && !(cfg->enc_beta > 0.f) && !(cfg->beta > 0.f))
+        return fail(h, PNDF_ERR_BAD_ARG, "softplus beta of the encoder must be positive");
     if (cfg->precision != PNDF_PREC_FP32 && cfg->precision != PNDF_PREC_F16X3 && cfg->precision != PNDF_PREC_F16)
         return fail(h, PNDF_ERR_UNSUPPORTED, "unknown precision (fp32, f16x3 and f16 are implemented)");
     if (cfg->precision == PNDF_PREC_F16 && cfg->act == PNDF_ACT_SOFTPLUS)

@@ -130,6 +130,8 @@ struct Scratch {      // per thread
 void forward_grad_block(const pndf_cpu_engine& E, const float* q /*[nb][84]*/, int nb, const float* gout, float* d, float* dq,
                         bool want_grad, Scratch& S) {
     const Act act{E.cfg.act, E.cfg.beta};
+    // model.StrEnc.act / beta are read on their own (net_modules.py:128); -1 / <= 0: the trunk's
+    const Act eact{E.cfg.enc_act == -1 ? E.cfg.act : E.cfg.enc_act, E.cfg.enc_beta > 0.f ? E.cfg.enc_beta : E.cfg.beta};
     // ---- normalise over joints per component (posendf.py:71), poses of the block as the inner index
     S.n.assign((size_t)NQ * PB, 0.f);
     for (int c = 0; c < 4; ++c)
@@ -156,9 +158,9 @@ void forward_grad_block(const pndf_cpu_engine& E, const float* q /*[nb][84]*/, i
             S.eh[j].resize((size_t)HID * PB); S.ehd[j].resize((size_t)HID * PB);
             S.ef[j].resize((size_t)FEAT * PB); S.efd[j].resize((size_t)FEAT * PB);
             dense(E.enc[j][0].w.data(), E.enc[j][0].b.data(), HID, in, S.ein[j].data(), S.eh[j].data());
-            activate(act, S.eh[j].data(), S.ehd[j].data(), HID * PB, false);
+            activate(eact, S.eh[j].data(), S.ehd[j].data(), HID * PB, false);
             dense(E.enc[j][1].w.data(), E.enc[j][1].b.data(), FEAT, HID, S.eh[j].data(), S.ef[j].data());
-            activate(act, S.ef[j].data(), S.efd[j].data(), FEAT * PB, false);
+            activate(eact, S.ef[j].data(), S.efd[j].data(), FEAT * PB, false);
             memcpy(&S.x[0][(size_t)FEAT * j * PB], S.ef[j].data(), sizeof(float) * FEAT * PB);      // cat(f_0 .. f_20), :169
         }
     } else {
@@ -298,6 +300,8 @@ extern "C" int pndf_cpu_create(pndf_cpu_handle* out, const pndf_config* cfg) {
         if (cfg->dims[l] < 1 || cfg->dims[l] > MAX_WIDTH)      // the same architectures the device engine accepts
             return cpu_fail(nullptr, PNDF_ERR_UNSUPPORTED, "hidden widths 1 .. 1024");
     if (cfg->act == PNDF_ACT_SOFTPLUS && !(cfg->beta > 0.f)) return cpu_fail(nullptr, PNDF_ERR_BAD_ARG, "Softplus beta must be positive");
+    if (cfg->enc_act < -1 || cfg->enc_act > PNDF_ACT_SOFTPLUS) return cpu_fail(nullptr, PNDF_ERR_UNSUPPORTED, "unknown encoder activation");
+    if (cfg->enc_act == PNDF_ACT_SOFTPLUS && !(cfg->enc_beta > 0.f) && !(cfg->beta > 0.f)) return cpu_fail(nullptr, PNDF_ERR_BAD_ARG, "Softplus beta of the encoder must be positive");
     return guarded(nullptr, [&] {
         pndf_cpu_engine* h = new pndf_cpu_engine();
         h->cfg = *cfg;

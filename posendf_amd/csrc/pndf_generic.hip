@@ -144,7 +144,9 @@ __device__ __forceinline__ void gen_backward(const f32x4* w, const f32x4* gin, f
 #define PNDF_GEN_GROUP_CASES(X) X(1) X(2) X(3) X(4)
 constexpr int GEN_PASS_GROUPS = 4;
 
-template <bool SP>
+// SP: the trunk's activation is Softplus (else relu / lrelu); ESP: the encoder's.  Every config of the reference has ESP == SP;
+// net_modules.py:128 reads model.StrEnc.act on its own, so the other two combinations exist as well.
+template <bool SP, bool ESP = SP>
 __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -159,16 +161,20 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
     f32x4* const wg = (f32x4*)args.scratch + (size_t)blockIdx.x * args.wg_tiles * SLOT_F4 + tid;
     f32x4* const xbuf[2] = {wg, wg + (size_t)PNDF_GEN_XTILES * SLOT_F4};
 
-    ActP ap;
+    ActP ap;                         // the TRUNK's activation parameters ...
     ap.slope = args.slope;
     ap.k = sp_consts(args.beta);
-    // the encoder parks its 42 derivative tiles at slots SP_SLOT_ENC + i of `ap.sp` (pndf_device.h): point slot SP_SLOT_ENC at enc_d_off
-    ap.sp = SpRef{SP ? (const char*)((f32x4*)args.scratch + ((size_t)blockIdx.x * args.wg_tiles + args.enc_d_off) * SLOT_F4)
-                           - (size_t)SP_SLOT_ENC * WG_THREADS * SP_LANE_BYTES
-                     : nullptr,
-                  (uint32_t)tid * SP_LANE_BYTES};
+    ap.sp = SpRef{nullptr, 0u};
     ap.stage = nullptr;
     ap.lane = lane;
+    ActP ape = ap;                   // ... and the encoder's
+    ape.slope = args.enc_slope;
+    ape.k = sp_consts(args.enc_beta);
+    // the encoder parks its 42 derivative tiles at slots SP_SLOT_ENC + i of `ape.sp` (pndf_device.h): point slot SP_SLOT_ENC at enc_d_off
+    ape.sp = SpRef{ESP ? (const char*)((f32x4*)args.scratch + ((size_t)blockIdx.x * args.wg_tiles + args.enc_d_off) * SLOT_F4)
+                           - (size_t)SP_SLOT_ENC * WG_THREADS * SP_LANE_BYTES
+                     : nullptr,
+                   (uint32_t)tid * SP_LANE_BYTES};
 
     float* const lds_bias = (float*)(smem + LDS_BIAS);
     float* const lds_q = (float*)(smem + LDS_Q);
@@ -203,16 +209,21 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
         for (int step = 0; step < nsteps; ++step) {
             // ---------------- encoder (or the normalised pose itself) -> x0, 128 rows in the pose's feature row
             uint32_t eb[6] = {0, 0, 0, 0, 0, 0};
-            float poison;
+            float poison = 0.f;
             if (args.noenc) {
                 poison = noenc_forward<SP>(my_q, my_f, g);
             } else {
+                if constexpr (SP && !ESP) {      // a Softplus trunk behind a relu-family encoder: the NaN / inf poison of the pose (joint_axis_norms)
+                    float ss[4];
+                    poison = joint_axis_norms<true>(my_q, ss);
+                }
                 // the encoder's tiles come through the weight ring like in the fused kernels: forward section of the stream
                 ring.gstream = args.enc_stream;
                 ring_start(ring, wave);
                 ring_wait_dma();
                 __syncthreads();
-                poison = encoder_forward<SP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ap, g);
+                const float pe = encoder_forward<ESP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ape, g);
+                if constexpr (ESP) poison = pe;
                 ring_wait_dma();      // (the ring fetched ahead into the section's padding: drain before the next restart)
             }
 #pragma unroll
@@ -245,6 +256,10 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
             } else {
                 dval = (z7 != z7) ? z7 : fmaxf(z7, 0.f);      // output ReLU for relu AND lrelu, net_modules.py:30-37 (relu(NaN) = NaN)
                 gz7 = (z7 > 0.f) ? 1.f : 0.f;
+                if constexpr (ESP) {                         // (a Softplus encoder swallows a NaN pose: v_min / v_max; see joint_axis_norms)
+                    dval += poison;
+                    gz7 += poison;
+                }
             }
             if (args.mode == MODE_FORWARD) break;
             float gscale = gz7;
@@ -282,7 +297,7 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                 ring_start(ring, wave);
                 ring_wait_dma();
                 __syncthreads();
-                encoder_backward<SP>(my_f, my_gn, eb, ring, ap, g);
+                encoder_backward<ESP>(my_f, my_gn, eb, ring, ape, g);
                 ring_wait_dma();
             }
             {
@@ -346,6 +361,13 @@ extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_generic_relu_ke
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_generic_softplus_kernel(PndfGenericArgs args) {
     pndf_generic_body<true>(args);
 }
+// model.StrEnc.act and model.DFNet.act of different families (net_modules.py:128 vs :30)
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_generic_relu_spenc_kernel(PndfGenericArgs args) {
+    pndf_generic_body<false, true>(args);
+}
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_generic_softplus_reluenc_kernel(PndfGenericArgs args) {
+    pndf_generic_body<true, false>(args);
+}
 
 // ------------------------------------------------------------------------------------------ host side
 using namespace pndf;
@@ -372,6 +394,9 @@ bool pndf_generic_needed(const pndf_config& cfg) {
     // against the compile-time one, same network, same box)
     const char* force = getenv("PNDF_FORCE_GENERIC");
     if (force && force[0] == '1') return true;
+    if (cfg.dims[0] == DIMS[0] && cfg.enc_act != -1 &&
+        (cfg.enc_act != cfg.act || (cfg.act == PNDF_ACT_SOFTPLUS && cfg.enc_beta > 0.f && cfg.enc_beta != cfg.beta)))
+        return true;      // StrEnc.act / beta differ from DFNet's (net_modules.py:128 vs :30): the fused kernels have one activation family
     if (cfg.n_dims != NLIN + 1) return true;
     for (int i = 1; i < NLIN; ++i)
         if (cfg.dims[i] > DIMS[i]) return true;
@@ -379,6 +404,17 @@ bool pndf_generic_needed(const pndf_config& cfg) {
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int gen_enc_act(const pndf_config& cfg) { return cfg.enc_act == -1 ? cfg.act : cfg.enc_act; }
+static inline float gen_enc_beta(const pndf_config& cfg) { return cfg.enc_beta > 0.f ? cfg.enc_beta : cfg.beta; }
+typedef void (*gen_kernel_t)(PndfGenericArgs);
+static gen_kernel_t gen_kernel(const pndf_config& cfg, const char** name) {
+    const bool sp = cfg.act == PNDF_ACT_SOFTPLUS, esp = (cfg.dims[0] == DIMS[0]) ? gen_enc_act(cfg) == PNDF_ACT_SOFTPLUS : sp;
+    if (sp && esp) { *name = "pndf_generic_softplus_kernel"; return pndf_generic_softplus_kernel; }
+    if (!sp && !esp) { *name = "pndf_generic_relu_kernel"; return pndf_generic_relu_kernel; }
+    if (sp) { *name = "pndf_generic_softplus_reluenc_kernel"; return pndf_generic_softplus_reluenc_kernel; }
+    *name = "pndf_generic_relu_spenc_kernel";
+    return pndf_generic_relu_spenc_kernel;
+}
 // tiles -> tiles rounded up to a group count the layer code exists for (PNDF_GEN_GROUP_CASES)
 static inline int gen_round_tiles(int tiles) {
     const int groups = ceil_div(tiles, NTB);
@@ -417,7 +453,7 @@ int pndf_generic_create(PndfGeneric** out, const pndf_config& cfg, int resident_
         if (l < L - 1) slot += P.ntp[l];
     }
     P.enc_d_off = slot;
-    if (cfg.act == PNDF_ACT_SOFTPLUS && g->enc) slot += 2 * NJ;
+    if (gen_enc_act(cfg) == PNDF_ACT_SOFTPLUS && g->enc) slot += 2 * NJ;
     P.wg_tiles = slot;
     g->wf_tiles = wf;
     g->wb_tiles = wb;
@@ -429,8 +465,9 @@ int pndf_generic_create(PndfGeneric** out, const pndf_config& cfg, int resident_
     if (e == hipSuccess) e = hipMalloc((void**)&g->d_lb, g->lbias_floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&g->d_scratch, (size_t)resident_wgs * P.wg_tiles * SLOT_F4 * sizeof(f32x4));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->done, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pndf_generic_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)pndf_generic_softplus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    for (const void* kfn : {(const void*)pndf_generic_relu_kernel, (const void*)pndf_generic_softplus_kernel,
+                            (const void*)pndf_generic_relu_spenc_kernel, (const void*)pndf_generic_softplus_reluenc_kernel})
+        if (e == hipSuccess) e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     if (e != hipSuccess) {
         err = std::string("pndf_create (runtime-planned DFNet): ") + hipGetErrorString(e);
         pndf_generic_destroy(g);
@@ -507,7 +544,9 @@ int pndf_generic_load(PndfGeneric* g, const float* const* tensors, const int64_t
 }
 
 const char* pndf_generic_kernel_name(const PndfGeneric* g) {
-    return g->cfg.act == PNDF_ACT_SOFTPLUS ? "pndf_generic_softplus_kernel" : "pndf_generic_relu_kernel";
+    const char* name = "";
+    (void)gen_kernel(g->cfg, &name);
+    return name;
 }
 
 int pndf_generic_launch(PndfGeneric* g, int mode, const float* q, const float* gout, float* qo, float* d, int64_t B, int steps,
@@ -519,6 +558,8 @@ int pndf_generic_launch(PndfGeneric* g, int mode, const float* q, const float* g
     a.B = B; a.steps = steps; a.mode = mode;
     a.slope = (g->cfg.act == PNDF_ACT_LRELU) ? 0.01f : 0.0f;      // nn.LeakyReLU() default slope, net_modules.py:31
     a.beta = g->cfg.beta;
+    a.enc_slope = (gen_enc_act(g->cfg) == PNDF_ACT_LRELU) ? 0.01f : 0.0f;
+    a.enc_beta = gen_enc_beta(g->cfg);
     const int64_t nblocks = (B + WG_POSES - 1) / WG_POSES;
     const dim3 grid((unsigned)(nblocks < g->resident ? nblocks : g->resident)), block(WG_THREADS);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -527,8 +568,8 @@ int pndf_generic_launch(PndfGeneric* g, int mode, const float* q, const float* g
     hipError_t e = hipSuccess;
     if (g->pending && g->last_stream != stream && !capturing) e = hipStreamWaitEvent((hipStream_t)stream, g->done, 0);
     if (e == hipSuccess) {
-        if (g->cfg.act == PNDF_ACT_SOFTPLUS) hipLaunchKernelGGL(pndf_generic_softplus_kernel, grid, block, LDS_TOTAL, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(pndf_generic_relu_kernel, grid, block, LDS_TOTAL, (hipStream_t)stream, a);
+        const char* name = "";
+        hipLaunchKernelGGL(gen_kernel(g->cfg, &name), grid, block, LDS_TOTAL, (hipStream_t)stream, a);
         e = hipGetLastError();
     }
     if (e == hipSuccess && !capturing) {

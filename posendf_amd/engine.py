@@ -20,7 +20,7 @@ PRECISION_CODES = {"fp32": 0, "f16x3": 1, "f16": 2}
 
 class PndfConfig(ctypes.Structure):
     _fields_ = [("act", c_int32), ("beta", c_float), ("num_joints", c_int32), ("n_dims", c_int32),
-                ("dims", c_int32 * 16), ("parent", c_int32 * 32), ("precision", c_int32)]
+                ("dims", c_int32 * 16), ("parent", c_int32 * 32), ("precision", c_int32), ("enc_act", c_int32), ("enc_beta", c_float)]
 
 
 class DenoiseWeights(ctypes.Structure):
@@ -200,11 +200,21 @@ def pack_host(sd_np, lib=None, split=False):
     return stream, bias
 
 
+def _set_encoder_act(cfg, act, beta, enc_act, enc_beta):
+    """model.StrEnc.act / beta when they differ from model.DFNet's (reference net_modules.py:128 reads its own keys; every config
+    of the reference sets them equal): a mixed pair runs on the runtime-planned kernels."""
+    if enc_act is not None and enc_act not in ACT_CODES:
+        raise PndfError(f"unknown encoder activation {enc_act!r}")
+    if enc_act is not None and (enc_act != act or (enc_act == "softplus" and enc_beta is not None and float(enc_beta) != float(beta))):
+        cfg.enc_act = ACT_CODES[enc_act]
+        cfg.enc_beta = float(enc_beta if enc_beta is not None else beta)
+
+
 class Engine:
     """One engine per device.  All compute methods take raw device pointers and a stream handle."""
 
     def __init__(self, act: str = "lrelu", beta: float = 100.0, device: int = 0, lib=None, precision: str = "fp32",
-                 encoder: bool = True, hidden=None):
+                 encoder: bool = True, hidden=None, enc_act: str | None = None, enc_beta: float | None = None):
         self.lib = lib or load_library()
         if act not in ACT_CODES:
             raise PndfError(f"unknown activation {act!r}")
@@ -213,6 +223,7 @@ class Engine:
         cfg = PndfConfig()
         self.lib.pndf_default_config(ctypes.byref(cfg), ACT_CODES[act], float(beta))
         cfg.precision = PRECISION_CODES[precision]
+        _set_encoder_act(cfg, act, beta, enc_act, enc_beta)
         if not encoder:
             cfg.dims[0] = 84          # model.StrEnc.use = False: DFNet on the 21 x 4 normalised quaternions
         if hidden is not None:
@@ -325,12 +336,14 @@ class CpuEngine:
     what `PoseNDF` runs on when its config says `train.device: cpu`, as the reference's class does (model/posendf.py:35,64).
     Plain C++ on the host cores -- not the oracle, and never a fallback of the device engine."""
 
-    def __init__(self, act: str = "lrelu", beta: float = 100.0, lib=None, encoder: bool = True, hidden=None):
+    def __init__(self, act: str = "lrelu", beta: float = 100.0, lib=None, encoder: bool = True, hidden=None,
+                 enc_act: str | None = None, enc_beta: float | None = None):
         self.lib = lib or load_library()
         if act not in ACT_CODES:
             raise PndfError(f"unknown activation {act!r}")
         cfg = PndfConfig()
         self.lib.pndf_default_config(ctypes.byref(cfg), ACT_CODES[act], float(beta))
+        _set_encoder_act(cfg, act, beta, enc_act, enc_beta)
         if not encoder:
             cfg.dims[0] = 84
         if hidden is not None:

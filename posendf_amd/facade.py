@@ -87,12 +87,10 @@ class PoseNDF(nn.Module):
         self._precision = (opt.get("engine") or {}).get("precision") or os.environ.get("PNDF_PRECISION", "auto")
         self._act = opt["model"]["DFNet"]["act"]
         self._beta = float(opt["model"]["DFNet"].get("beta", 100.0))
-        if self.enc is not None and opt["model"]["StrEnc"]["act"] != self._act:
-            # (net_modules.py:128 vs :30 would allow it; no config of the reference does it: configs/amass.yaml:31,42)
-            raise PndfError("StrEnc.act and DFNet.act differ; the fused kernel uses one activation family")
-        if (self.enc is not None and self._act == "softplus"
-                and float(opt["model"]["StrEnc"].get("beta", self._beta)) != self._beta):
-            raise PndfError("StrEnc.beta and DFNet.beta differ; the fused kernel uses one Softplus beta")
+        # model.StrEnc.act / beta are read on their own (net_modules.py:128, :116-128); every config of the reference sets them equal
+        # to DFNet's.  A mixed pair runs on the runtime-planned kernels (csrc/pndf_generic.hip).
+        self._enc_act = opt["model"]["StrEnc"]["act"] if self.enc is not None else None
+        self._enc_beta = float(opt["model"]["StrEnc"].get("beta", self._beta)) if self.enc is not None else None
         self._hidden = list(opt["model"]["DFNet"]["dims"])       # net_modules.py:14-28; narrower than amass.yaml: zero padded
         self._engines = {}          # device index -> (Engine, weight fingerprint)
         self._param_list = None     # cached list(self.parameters()): walking the module tree costs 0.15 ms per call
@@ -138,12 +136,13 @@ class PoseNDF(nn.Module):
         fp = self._fingerprint()
         entry = self._engines.get(idx)
         if entry is None and host:
-            entry = self._engines[idx] = [CpuEngine(self._act, self._beta, encoder=self.enc is not None, hidden=self._hidden), None]
+            entry = self._engines[idx] = [CpuEngine(self._act, self._beta, encoder=self.enc is not None, hidden=self._hidden,
+                                                    enc_act=self._enc_act, enc_beta=self._enc_beta), None]
         if entry is None:
             # the plain-f16 comparison kernel is relu-family only; fp32 and f16x3 implement all three activations
             prec = "fp32" if (self._act == "softplus" and self._precision == "f16") else self._precision
             entry = [Engine(self._act, self._beta, idx, precision="f16x3" if prec == "auto" else prec,
-                            encoder=self.enc is not None, hidden=self._hidden), None]
+                            encoder=self.enc is not None, hidden=self._hidden, enc_act=self._enc_act, enc_beta=self._enc_beta), None]
             self._engines[idx] = entry
             if prec == "auto":      # a drop-in of an fp32 model picks an arithmetic on the caller's behalf: say so, once per engine
                 logging.getLogger("posendf_amd").info(
@@ -161,7 +160,7 @@ class PoseNDF(nn.Module):
                 # both are HIP kernels: this is a choice of arithmetic, not a fallback off the engine
                 warnings.warn(f"posendf_amd: {e}; precision 'auto' selects the exact fp32 kernel for this network")
                 entry[0] = Engine(self._act, self._beta, idx, precision="fp32", encoder=self.enc is not None,
-                                  hidden=self._hidden)
+                                  hidden=self._hidden, enc_act=self._enc_act, enc_beta=self._enc_beta)
                 entry[0].load_weights(weights)
             entry[1] = fp
         return entry[0]

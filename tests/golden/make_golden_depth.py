@@ -30,6 +30,9 @@ CASES = {
     "d7_softplus": ([128, 256, 512, 1024, 512, 256, 64], "softplus", True, (41, 2.2, 0.2)),
     "wide_relu": ([512, 1024, 1024, 640, 256, 128], "relu", True, (26, 2.0, 0.1)),           # amass.yaml's depth, wider layers
     "noenc_d3_lrelu": ([200, 100, 50], "lrelu", False, (27, 2.0, 0.1)),                      # StrEnc.use = False, in_dim 84
+    # model.StrEnc.act differs from model.DFNet.act (net_modules.py:128 reads its own key): "trunk/encoder"
+    "mix_softplus_lreluenc": ([256, 512, 1024, 512, 256, 64], "softplus/lrelu", True, (28, 2.0, 0.1)),      # amass.yaml's dims
+    "mix_relu_softplusenc": ([192, 320, 160, 48], "relu/softplus", True, (43, 2.0, 0.3)),
 }
 NPOSE = 24
 
@@ -48,9 +51,10 @@ def ref_model(name, dtype):
     hidden, act, use_enc, (seed, gain, ob) = CASES[name]
     opt = mg.load_config(os.path.join(mg.REF, "configs", "amass.yaml"))
     opt["train"]["device"] = "cpu"
-    opt["model"]["DFNet"]["act"] = act
+    trunk_act, _, enc_act = act.partition("/")
+    opt["model"]["DFNet"]["act"] = trunk_act
     opt["model"]["DFNet"]["dims"] = list(hidden)
-    opt["model"]["StrEnc"]["act"] = act
+    opt["model"]["StrEnc"]["act"] = enc_act or trunk_act
     opt["model"]["StrEnc"]["use"] = use_enc
     if not use_enc:
         opt["model"]["DFNet"]["in_dim"] = 84
@@ -93,7 +97,7 @@ def one(name):
 
 
 if __name__ == "__main__":
-    for name in CASES:
+    for name in (sys.argv[1:] or CASES):
         o = one(name)
         np.savez_compressed(os.path.join(HERE, f"depth_{name}.npz"), **o)
         d = o["d_f32"][:, 0]

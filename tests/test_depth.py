@@ -15,7 +15,10 @@ import pytest
 
 from conftest import GOLDEN, d_rows, fp32_noise, outlier_gate, pose_gate, rel_err_rows, traj_envelope, traj_margin
 
-CASES = ["d1_lrelu", "d4_lrelu", "d4_softplus", "d7_lrelu", "d7_softplus", "wide_relu", "noenc_d3_lrelu"]
+CASES = ["d1_lrelu", "d4_lrelu", "d4_softplus", "d7_lrelu", "d7_softplus", "wide_relu", "noenc_d3_lrelu",
+         "mix_softplus_lreluenc", "mix_relu_softplusenc"]      # the last two: model.StrEnc.act != model.DFNet.act ("trunk/encoder")
+KERNELS = {("relu", "relu"): "pndf_generic_relu_kernel", ("softplus", "softplus"): "pndf_generic_softplus_kernel",
+           ("softplus", "relu"): "pndf_generic_softplus_reluenc_kernel", ("relu", "softplus"): "pndf_generic_relu_spenc_kernel"}
 TOL = 1e-4
 
 
@@ -31,7 +34,9 @@ def load_case(name):
 
 def config_for(hidden, act, enc, device):
     from posendf_amd import amass_config
-    cfg = amass_config(act, device)
+    trunk_act, _, enc_act = act.partition("/")
+    cfg = amass_config(trunk_act, device)
+    cfg["model"]["StrEnc"]["act"] = enc_act or trunk_act
     cfg["model"]["DFNet"]["dims"] = list(hidden)
     cfg["model"]["StrEnc"]["use"] = enc
     if not enc:
@@ -128,7 +133,9 @@ def test_runtime_planned_kernels(name, precision):
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     net.eval()
     _check_network(net, torch, g, act, sd, f"{name} {precision}", "cuda:0")
-    want = "pndf_generic_softplus_kernel" if act == "softplus" else "pndf_generic_relu_kernel"
+    fam = lambda a: "softplus" if a == "softplus" else "relu"      # noqa: E731
+    trunk_act, _, enc_act = act.partition("/")
+    want = KERNELS[(fam(trunk_act), fam(enc_act or trunk_act) if enc else fam(trunk_act))]
     assert net._engine_for(torch.device("cuda:0")).kernel_name() == want
 
 
