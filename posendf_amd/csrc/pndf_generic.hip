@@ -19,9 +19,9 @@
 //     Infinity Cache;
 //     the first form of this kernel (one block of four output tiles per pass: the operand re-read once per block, prefetched
 //     16 MFMAs ahead) ran at 0.22 of the fp32 MFMA peak, waiting for those loads (profiles/r06/generic_arch_v1.jsonl);
-//   * weights: fp32 tiles `tile(M, nt, kt)` in consumption order [k tile][output tile], read straight from global memory (every
-//     wave of every workgroup reads the same 1-KiB tiles: L1 / L2 hits), a group of four prefetched while the previous group's
-//     sixteen MFMAs issue (an fp32 MFMA occupies the pipe for 32 cycles).
+//   * weights: fp32 tiles `tile(M, nt, kt)` in consumption order [pass][k tile][tile of the pass], streamed global -> LDS by DMA into a
+//     five-slot ring PRIVATE to each wave, four slots (2,048 cycles of matrix pipe) ahead, counted vmcnt waits, no barrier in the trunk
+//     (see "the trunk's weight ring" below for the forms that were measured before it).
 // Roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic work per pose-step 4 x sum_l in_l out_l FLOP.  Not the benchmark path
 // (BASELINE.json names amass.yaml); measured in profiles/r06/generic_arch.txt.
 #include "pndf_device.h"
@@ -42,46 +42,100 @@ constexpr int NTB = PNDF_GEN_NTB;
 constexpr int TILE_F4 = 64;              // f32x4 elements of a weight tile (one per lane)
 constexpr int SLOT_F4 = WG_THREADS;      // f32x4 elements of a scratch tile slot (one per thread of the workgroup)
 
-// acc[t] += sum_k W(t, k) X[k] for `NG * NTB` output tiles (one pass over a layer) at once: every operand tile X[k] is loaded
-// ONCE per pass (the operand lives in the workgroup's global scratch -- L2 / Infinity Cache latency -- and is prefetched a whole
-// k step, up to 128 MFMAs, ahead); the weights stream through in the order they are packed, [k][group][tile of the group], one group
-// (four 1-KiB tiles, the same for every wave of every workgroup: L1 / L2 hits) prefetched while the previous one is multiplied.
-// `w` = this lane's element of the layer's first weight tile, `x` = this thread's element of the operand's tile 0.
-// Register indices must be compile-time, so the number of groups is a template parameter: the plan rounds a layer's output
-// tiles up to whole groups of NTB (host side: gen_round_tiles) and the layer code is instantiated per group count of a pass.  (A
-// first form kept 64 accumulators under run-time guards `if (group < ng)`: hipcc answered with 700 spilled registers.)
+// ---- the trunk's weight ring: PRIVATE to each wave, fed by LDS-DMA
+// The rocprofv3 counters of the register-prefetch form (profiles/r06/generic/): 47.6 % MFMA busy, 47.7 % of the wave cycles at an
+// s_waitcnt, L2 hit rate 76 % -- 22 MB of fp32 weights per step do not fit 4 MB of L2, workgroups that wait drift apart, and with one
+// group (1,024 cycles) of look-ahead every miss is a stall.  Sharing a group among the four waves through LDS with a barrier per group
+// is slower still (0.41: the barrier hands every wave the slowest wave's miss).  What the fused kernels have is DISTANCE without
+// registers: global_load_lds_dwordx4 moves a tile global -> LDS with no destination register, so any number of slots can be in flight;
+// here every wave runs its own five-slot ring (4 tiles = 16 MFMAs per slot, fetched FOUR slots = 2,048 cycles ahead, counted vmcnt
+// waits, no barrier anywhere: the waves of a workgroup share nothing in the trunk), and the operand tile of the next k step comes the
+// same way.  The encoder's ring buffers (80 KiB) and the chunk-mask rows (unused here) are idle during the trunk.
+constexpr int GW_SLOT_TILES = 4;
+constexpr int GW_SLOT_BYTES = GW_SLOT_TILES * TILE_BYTES;          // 4 KiB
+constexpr int GW_RING = 5;
+constexpr int GW_AHEAD = GW_RING - 1;
+constexpr int GW_WAVE_BYTES = GW_RING * GW_SLOT_BYTES;             // 20 KiB per wave
+constexpr int GX_WAVE_BYTES = 2 * TILE_BYTES;                      // operand tile, double buffered
+static_assert(4 * GW_WAVE_BYTES <= RING_SLOTS * SLOT_BYTES, "four private rings live in the encoder's ring buffers");
+static_assert(4 * GX_WAVE_BYTES <= MASK_ROWS * WG_THREADS, "the operand buffers live in the chunk-mask rows");
+static_assert(NTB % GW_SLOT_TILES == 0, "a group of output tiles is whole slots");
+
+struct GenLds {
+    uint32_t w_lds;        // uniform: LDS address of this wave's ring
+    uint32_t x_lds;        // uniform: LDS address of this wave's two operand tiles
+    const char* w_ptr;     // per lane: its 16 bytes of tile 0 of ring slot 0
+    const char* x_ptr;     // per lane: its 16 bytes of operand buffer 0
+    uint32_t lane16;
+};
+
+// one ring slot (4 tiles): M0 = LDS destination, the instruction offset moves both addresses (pndf_device.h: ring_dma_piece)
+__device__ __forceinline__ void gw_dma_slot(const char* base, uint32_t voff, uint32_t dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %1\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %0, %1 offset:3072"
+                 : : "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
+}
+__device__ __forceinline__ void gw_dma_tile(const char* base, uint32_t voff, uint32_t dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
+}
+
+// acc[t] += sum_k W(t, k) X[k] for `NG * NTB` output tiles (one pass over a layer) at once.  `wbase` (uniform) = the pass's first weight
+// tile, stream order [k][tile of the pass]; `xbase` (uniform) = this wave's 1 KiB of operand tile 0 (tiles 4 KiB apart).  Register
+// indices must be compile-time, so the number of groups is a template parameter: the plan rounds a layer's output tiles up to whole
+// groups (host side: gen_round_tiles) and the layer code is instantiated per group count of a pass.  (A first form kept 64
+// accumulators under run-time guards `if (group < ng)`: hipcc answered with 700 spilled registers.)
+// vmcnt bookkeeping (loads retire in order; other operations of the wave in the queue only make a counted wait stricter):
+//   slot t + 1 is read (one slot ahead of its MFMAs) after DMA(t + 4) has been issued: three younger slots x 4 pieces -> vmcnt(12).
+//   Operand tile k + 1 is issued at the top of k step k and read at the top of k step k + 1: the SPK slots issued in between are
+//   younger -> vmcnt(min(4 SPK, 12)).
 template <int NG>
-__device__ __forceinline__ void gen_layer(const f32x4* __restrict__ w, const f32x4* x, int nk, f32x4 (&acc)[NG * NTB]) {
-    // One group (NTB = 8 tiles = 32 MFMAs = 1,024 cycles of matrix pipe) of weights is in flight ahead of the MFMAs that use it, and
-    // the operand tile of the next k step.  The distance is what matters: an L2 hit is ~480 cycles and 3 % of the weight stream
-    // misses the L2.  With groups of four tiles (512 cycles ahead) this loop ran at 0.45 of the fp32 MFMA peak; the first form of
-    // the kernel (operand re-read per block of four tiles) at 0.22 (profiles/r06/generic_arch_v1.jsonl, _v2.jsonl).  A deeper
-    // pipeline through registers does not work: rotating three buffers by copies makes hipcc wait for the YOUNGEST load at the end
-    // of every group (`s_waitcnt vmcnt(0)` at the loop head); the buffers would have to rotate by name, i.e. by unrolling.
-    const f32x4* const wlast = w + (size_t)(nk * NG - 1) * NTB * TILE_F4;      // (the last group is re-read instead of branching)
-    f32x4 wc[NTB], xc = x[0];
+__device__ __forceinline__ void gen_layer(const char* wbase, const char* xbase, int nk, f32x4 (&acc)[NG * NTB], const GenLds& L) {
+    constexpr int SPK = NG * NTB / GW_SLOT_TILES;                  // slots per k step
+    const uint32_t last = (uint32_t)(nk * SPK - 1) * GW_SLOT_BYTES + L.lane16;      // (fetches past the end re-read the last slot: no branch)
+    gw_dma_tile(xbase, L.lane16, L.x_lds);
+    uint32_t fetch = L.lane16, fbuf = 0, rbuf = 0;
 #pragma unroll
-    for (int j = 0; j < NTB; ++j) wc[j] = w[j * TILE_F4];
-    const f32x4* wnext = w + NTB * TILE_F4;                    // the group after the current one, in stream order
+    for (int i = 0; i < GW_AHEAD; ++i) {
+        gw_dma_slot(wbase, fetch < last ? fetch : last, L.w_lds + fbuf);
+        fetch += GW_SLOT_BYTES;
+        fbuf += GW_SLOT_BYTES;
+    }
+    // the tiles of a slot are read from LDS one slot ahead of their MFMAs (an LDS read issued right in front of its MFMAs is ~100
+    // cycles of idle matrix pipe per 512): slot 0 now, slot t + 1 in front of the MFMAs of slot t
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * (GW_AHEAD - 1)) : "memory");
+    f32x4 wc[GW_SLOT_TILES];
+#pragma unroll
+    for (int j = 0; j < GW_SLOT_TILES; ++j) wc[j] = *(const f32x4*)(L.w_ptr + j * TILE_BYTES);
+    rbuf = GW_SLOT_BYTES;                                          // ring buffer of the next slot to read
     for (int k = 0; k < nk; ++k) {
-        const f32x4 xn = x[(size_t)((k + 1 < nk) ? k + 1 : k) * SLOT_F4];
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * SPK < 4 * (GW_AHEAD - 1) ? 4 * SPK : 4 * (GW_AHEAD - 1)) : "memory");
+        const f32x4 xc = *(const f32x4*)(L.x_ptr + (k & 1) * TILE_BYTES);
+        gw_dma_tile(xbase, (uint32_t)((k + 1 < nk) ? k + 1 : k) * (SLOT_F4 * 16u) + L.lane16, L.x_lds + ((k + 1) & 1) * TILE_BYTES);
 #pragma unroll
-        for (int gi = 0; gi < NG; ++gi) {
-            f32x4 wn[NTB];
-            const f32x4* src = (wnext <= wlast) ? wnext : wlast;
+        for (int si = 0; si < SPK; ++si) {
+            // slot t: fetch slot t + 4 into the buffer slot t - 1 was read from (a slot ago), wait for slot t + 1, read it, multiply slot t
+            gw_dma_slot(wbase, fetch < last ? fetch : last, L.w_lds + fbuf);
+            fetch += GW_SLOT_BYTES;
+            fbuf = (fbuf == (GW_RING - 1) * GW_SLOT_BYTES) ? 0u : fbuf + GW_SLOT_BYTES;
+            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * (GW_AHEAD - 1)) : "memory");
+            f32x4 wn[GW_SLOT_TILES];
 #pragma unroll
-            for (int j = 0; j < NTB; ++j) wn[j] = src[j * TILE_F4];
-            wnext += NTB * TILE_F4;
+            for (int j = 0; j < GW_SLOT_TILES; ++j) wn[j] = *(const f32x4*)(L.w_ptr + rbuf + j * TILE_BYTES);
+            rbuf = (rbuf == (GW_RING - 1) * GW_SLOT_BYTES) ? 0u : rbuf + GW_SLOT_BYTES;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
-                for (int j = 0; j < NTB; ++j) acc[gi * NTB + j] = mfma4(wc[j][s], xc[s], acc[gi * NTB + j]);      // eight independent chains
+                for (int j = 0; j < GW_SLOT_TILES; ++j)
+                    acc[si * GW_SLOT_TILES + j] = mfma4(wc[j][s], xc[s], acc[si * GW_SLOT_TILES + j]);      // four independent chains
             }
 #pragma unroll
-            for (int j = 0; j < NTB; ++j) wc[j] = wn[j];
+            for (int j = 0; j < GW_SLOT_TILES; ++j) wc[j] = wn[j];
         }
-        xc = xn;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the re-reads of the last slot)
 }
 
 // hidden activation of one D tile (reference net_modules.py:30-41,64-65) and its derivative factor
@@ -101,12 +155,16 @@ __device__ __forceinline__ void gen_act(f32x4& z, f32x4& dfac, float slope, cons
 
 // one forward layer with NG groups of output tiles: bias -> accumulate -> (hidden layers) activation, derivative factor
 template <int NG, bool SP>
-__device__ __forceinline__ void gen_forward(const f32x4* w, const float* bias, const f32x4* xin, f32x4* xout, f32x4* dl, int nk, bool last,
-                                            float slope, const SpK& k, int g, f32x4& zlast) {
+__device__ __forceinline__ void gen_forward(const char* w, const float* bias, const char* xin, f32x4* xout, f32x4* dl, int nk, bool last,
+                                            float slope, const SpK& k, int g, f32x4& zlast, const GenLds& L) {
     f32x4 acc[NG * NTB];
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) acc[t] = *(const f32x4*)(bias + 16 * t + 4 * g);
-    gen_layer<NG>(w, xin, nk, acc);
+    // the bias loads are consumed HERE: left pending, hipcc waits for them with `s_waitcnt vmcnt(0)` at the head of the k loop --
+    // in every iteration, which drains the weight ring's look-ahead once per k step
+#pragma unroll
+    for (int t = 0; t < NG * NTB; ++t) asm volatile("" : "+v"(acc[t]));
+    gen_layer<NG>(w, xin, nk, acc, L);
     if (last) {                    // the output layer: one unit, row 0 of tile 0; its activation is the caller's
         zlast = acc[0];
         return;
@@ -123,11 +181,12 @@ __device__ __forceinline__ void gen_forward(const f32x4* w, const float* bias, c
 
 // one backward layer: G_in = W^T G_out, times the derivative factors of the layer below (l > 0) or into the pose's feature row
 template <int NG>
-__device__ __forceinline__ void gen_backward(const f32x4* w, const f32x4* gin, f32x4* gout, const f32x4* dprev, float* my_f, int nk, int g, int t0) {
+__device__ __forceinline__ void gen_backward(const char* w, const char* gin, f32x4* gout, const f32x4* dprev, float* my_f, int nk, int g, int t0,
+                                             const GenLds& L) {
     f32x4 acc[NG * NTB];
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gen_layer<NG>(w, gin, nk, acc);
+    gen_layer<NG>(w, gin, nk, acc, L);
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) {
         if (dprev) gout[(size_t)t * SLOT_F4] = acc[t] * dprev[(size_t)t * SLOT_F4];      // x act'(z_{l-1})
@@ -160,6 +219,15 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
     // this workgroup's scratch: [0, 64) activations ping, [64, 128) pong, then the derivative factors (args.d_off)
     f32x4* const wg = (f32x4*)args.scratch + (size_t)blockIdx.x * args.wg_tiles * SLOT_F4 + tid;
     f32x4* const xbuf[2] = {wg, wg + (size_t)PNDF_GEN_XTILES * SLOT_F4};
+    // the same two buffers as the LDS-DMA sees them: uniform address of this WAVE's 1 KiB of tile 0 (the lanes add 16 bytes each)
+    const char* const xwave = (const char*)((f32x4*)args.scratch + (size_t)blockIdx.x * args.wg_tiles * SLOT_F4) + wave * TILE_BYTES;
+    const char* const xuni[2] = {xwave, xwave + (size_t)PNDF_GEN_XTILES * SLOT_F4 * 16};
+    GenLds gl;
+    gl.w_lds = (uint32_t)(size_t)(PNDF_LDS char*)(smem + LDS_RING) + wave * GW_WAVE_BYTES;
+    gl.x_lds = (uint32_t)(size_t)(PNDF_LDS char*)(smem + LDS_MASK) + wave * GX_WAVE_BYTES;
+    gl.w_ptr = smem + LDS_RING + wave * GW_WAVE_BYTES + lane * 16;
+    gl.x_ptr = smem + LDS_MASK + wave * GX_WAVE_BYTES + lane * 16;
+    gl.lane16 = (uint32_t)lane * 16u;
 
     ActP ap;                         // the TRUNK's activation parameters ...
     ap.slope = args.slope;
@@ -225,6 +293,7 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                 const float pe = encoder_forward<ESP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ape, g);
                 if constexpr (ESP) poison = pe;
                 ring_wait_dma();      // (the ring fetched ahead into the section's padding: drain before the next restart)
+                __syncthreads();      // ... by EVERY wave: the trunk's private weight rings reuse the ring's buffers
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) xbuf[0][(size_t)t * SLOT_F4] = *(const f32x4*)(my_f + 16 * t + 4 * g);
@@ -233,14 +302,14 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
             f32x4 zlast = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int l = 0; l < L; ++l) {
                 const int nk = args.kt[l], ng = args.ntp[l] / NTB;
-                const f32x4* w = (const f32x4*)args.wfwd + (size_t)args.wf_off[l] * TILE_F4 + lane;
+                const char* w = (const char*)args.wfwd + (size_t)args.wf_off[l] * TILE_BYTES;
                 const float* bias = args.lbias + args.b_off[l];
                 f32x4* dl = wg + (size_t)args.d_off[l] * SLOT_F4;
                 for (int g0 = 0; g0 < ng; g0 += GEN_PASS_GROUPS) {      // passes of at most 8 groups of output tiles
                     const int n = (ng - g0 < GEN_PASS_GROUPS) ? ng - g0 : GEN_PASS_GROUPS, t0 = g0 * NTB;
-                    const f32x4* wp = w + (size_t)g0 * nk * NTB * TILE_F4;      // stream order: [pass][k tile][tile of the pass]
+                    const char* wp = w + (size_t)g0 * nk * NTB * TILE_BYTES;      // stream order: [pass][k tile][tile of the pass]
                     switch (n) {
-#define PNDF_GEN_FWD(N) case N: gen_forward<N, SP>(wp, bias + 16 * t0, xbuf[l & 1], xbuf[(l + 1) & 1] + (size_t)t0 * SLOT_F4, dl + (size_t)t0 * SLOT_F4, nk, l == L - 1, args.slope, ap.k, g, zlast); break;
+#define PNDF_GEN_FWD(N) case N: gen_forward<N, SP>(wp, bias + 16 * t0, xuni[l & 1], xbuf[(l + 1) & 1] + (size_t)t0 * SLOT_F4, dl + (size_t)t0 * SLOT_F4, nk, l == L - 1, args.slope, ap.k, g, zlast, gl); break;
                         PNDF_GEN_GROUP_CASES(PNDF_GEN_FWD)
 #undef PNDF_GEN_FWD
                         default: break;      // (pndf_generic_create plans no other group count)
@@ -275,13 +344,13 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
             xbuf[0][0] = (g == 0) ? f32x4{1.f, 0.f, 0.f, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
             for (int l = L - 1; l >= 0; --l) {
                 const int nk = args.nt[l], ng = args.ktp[l] / NTB;
-                const f32x4* w = (const f32x4*)args.wbwd + (size_t)args.wb_off[l] * TILE_F4 + lane;
+                const char* w = (const char*)args.wbwd + (size_t)args.wb_off[l] * TILE_BYTES;
                 const f32x4* dprev = (l > 0) ? wg + (size_t)args.d_off[l - 1] * SLOT_F4 : nullptr;
                 for (int g0 = 0; g0 < ng; g0 += GEN_PASS_GROUPS) {
                     const int n = (ng - g0 < GEN_PASS_GROUPS) ? ng - g0 : GEN_PASS_GROUPS, t0 = g0 * NTB;
-                    const f32x4* wp = w + (size_t)g0 * nk * NTB * TILE_F4;
+                    const char* wp = w + (size_t)g0 * nk * NTB * TILE_BYTES;
                     switch (n) {
-#define PNDF_GEN_BWD(N) case N: gen_backward<N>(wp, xbuf[cur], xbuf[cur ^ 1] + (size_t)t0 * SLOT_F4, dprev ? dprev + (size_t)t0 * SLOT_F4 : nullptr, my_f, nk, g, t0); break;
+#define PNDF_GEN_BWD(N) case N: gen_backward<N>(wp, xuni[cur], xbuf[cur ^ 1] + (size_t)t0 * SLOT_F4, dprev ? dprev + (size_t)t0 * SLOT_F4 : nullptr, my_f, nk, g, t0, gl); break;
                         PNDF_GEN_GROUP_CASES(PNDF_GEN_BWD)
 #undef PNDF_GEN_BWD
                         default: break;
