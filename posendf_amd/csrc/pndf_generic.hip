@@ -23,7 +23,15 @@
 //     five-slot ring PRIVATE to each wave, four slots (2,048 cycles of matrix pipe) ahead, counted vmcnt waits, no barrier in the trunk
 //     (see "the trunk's weight ring" below for the forms that were measured before it).
 // Roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic work per pose-step 4 x sum_l in_l out_l FLOP.  Not the benchmark path
-// (BASELINE.json names amass.yaml); measured in profiles/r06/generic_arch.txt.
+// (BASELINE.json names amass.yaml).  Measured (tools/bench_generic.py, B = 65,536 x 10 steps, profiles/r06/generic_arch*.jsonl), as a
+// fraction of the fp32 MFMA peak on configs/amass.yaml itself (PNDF_FORCE_GENERIC=1; the fused exact-fp32 kernel: 0.89):
+//   v1 0.22  one block of four output tiles per pass over the operand, weights and operand prefetched one k step through registers
+//   v2 0.45  the accumulators of a pass (32 tiles) resident: the operand is read once per pass
+//   v3 0.47  weight groups of eight tiles (1,024 cycles of look-ahead)         -> rocprofv3: 48 % of the wave cycles at a waitcnt, L2 hit 76 %
+//   v4 0.41  a group shared by the four waves through LDS, one barrier per group (the barrier hands every wave the slowest wave's miss)
+//   v5 0.60  a five-slot weight ring PRIVATE to each wave, fed by LDS-DMA four slots ahead, no barrier in the trunk
+//   v6 0.68  the slot laid out by hand: DMA pieces and the next slot's tile reads between the rounds of MFMAs (this file; 0.72 on a
+//            wider network, 0.63 with Softplus)
 #include "pndf_device.h"
 
 #include <stdlib.h>
@@ -78,6 +86,19 @@ __device__ __forceinline__ void gw_dma_slot(const char* base, uint32_t voff, uin
                  "global_load_lds_dwordx4 %0, %1 offset:3072"
                  : : "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
 }
+// the same slot piece by piece, one piece behind each round of four MFMAs (pieces 1 .. 3 rely on M0 as piece 0 left it: nothing
+// else in the trunk writes M0 between them -- the operand tile's DMA is issued at the top of a k step, outside a slot)
+template <int PIECE>
+__device__ __forceinline__ void gw_dma_piece(const char* base, uint32_t voff, uint32_t dst) {
+    if constexpr (PIECE == 0)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
+    else if constexpr (PIECE == 1)
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(voff), "s"(base) : "memory");
+    else if constexpr (PIECE == 2)
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(voff), "s"(base) : "memory");
+    else
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(voff), "s"(base) : "memory");
+}
 __device__ __forceinline__ void gw_dma_tile(const char* base, uint32_t voff, uint32_t dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
 }
@@ -93,7 +114,8 @@ __device__ __forceinline__ void gw_dma_tile(const char* base, uint32_t voff, uin
 //   younger -> vmcnt(min(4 SPK, 12)).
 template <int NG>
 __device__ __forceinline__ void gen_layer(const char* wbase, const char* xbase, int nk, f32x4 (&acc)[NG * NTB], const GenLds& L) {
-    constexpr int SPK = NG * NTB / GW_SLOT_TILES;                  // slots per k step
+    constexpr int SPK = NG * NTB / GW_SLOT_TILES;                  // slots per k step: even, so the two register sets below alternate by si
+    static_assert(SPK % 2 == 0, "the tile registers of consecutive slots alternate by slot parity");
     const uint32_t last = (uint32_t)(nk * SPK - 1) * GW_SLOT_BYTES + L.lane16;      // (fetches past the end re-read the last slot: no branch)
     gw_dma_tile(xbase, L.lane16, L.x_lds);
     uint32_t fetch = L.lane16, fbuf = 0, rbuf = 0;
@@ -103,12 +125,15 @@ __device__ __forceinline__ void gen_layer(const char* wbase, const char* xbase, 
         fetch += GW_SLOT_BYTES;
         fbuf += GW_SLOT_BYTES;
     }
-    // the tiles of a slot are read from LDS one slot ahead of their MFMAs (an LDS read issued right in front of its MFMAs is ~100
-    // cycles of idle matrix pipe per 512): slot 0 now, slot t + 1 in front of the MFMAs of slot t
+    // The tiles of a slot are read from LDS one slot ahead of their MFMAs, into one of two register sets that alternate by slot
+    // parity (no copies).  One wave per SIMD overlaps its own non-MFMA instructions with its own MFMAs only when they sit between
+    // them in program order (DESIGN.md section 2 "epilogue in MFMA slots"), so a slot is laid out by hand and pinned:
+    //   M M M M  P0 | M M M M  P1 | M M M M  P2 P3  wait(slot t + 1)  R R R R | M M M M
+    // P = one 1-KiB piece of the fetch of slot t + 4, R = the four tile reads of slot t + 1 (their latency hides behind the last round).
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * (GW_AHEAD - 1)) : "memory");
-    f32x4 wc[GW_SLOT_TILES];
+    f32x4 wt[2][GW_SLOT_TILES];
 #pragma unroll
-    for (int j = 0; j < GW_SLOT_TILES; ++j) wc[j] = *(const f32x4*)(L.w_ptr + j * TILE_BYTES);
+    for (int j = 0; j < GW_SLOT_TILES; ++j) wt[0][j] = *(const f32x4*)(L.w_ptr + j * TILE_BYTES);
     rbuf = GW_SLOT_BYTES;                                          // ring buffer of the next slot to read
     for (int k = 0; k < nk; ++k) {
         asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * SPK < 4 * (GW_AHEAD - 1) ? 4 * SPK : 4 * (GW_AHEAD - 1)) : "memory");
@@ -116,25 +141,33 @@ __device__ __forceinline__ void gen_layer(const char* wbase, const char* xbase, 
         gw_dma_tile(xbase, (uint32_t)((k + 1 < nk) ? k + 1 : k) * (SLOT_F4 * 16u) + L.lane16, L.x_lds + ((k + 1) & 1) * TILE_BYTES);
 #pragma unroll
         for (int si = 0; si < SPK; ++si) {
-            // slot t: fetch slot t + 4 into the buffer slot t - 1 was read from (a slot ago), wait for slot t + 1, read it, multiply slot t
-            gw_dma_slot(wbase, fetch < last ? fetch : last, L.w_lds + fbuf);
+            const f32x4 (&wc)[GW_SLOT_TILES] = wt[si & 1];
+            f32x4 (&wn)[GW_SLOT_TILES] = wt[(si + 1) & 1];
+            const uint32_t voff = fetch < last ? fetch : last;
+            const uint32_t dst = L.w_lds + fbuf;                   // the buffer slot t - 1 was read from, a slot ago
             fetch += GW_SLOT_BYTES;
             fbuf = (fbuf == (GW_RING - 1) * GW_SLOT_BYTES) ? 0u : fbuf + GW_SLOT_BYTES;
-            asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * (GW_AHEAD - 1)) : "memory");
-            f32x4 wn[GW_SLOT_TILES];
-#pragma unroll
-            for (int j = 0; j < GW_SLOT_TILES; ++j) wn[j] = *(const f32x4*)(L.w_ptr + rbuf + j * TILE_BYTES);
-            rbuf = (rbuf == (GW_RING - 1) * GW_SLOT_BYTES) ? 0u : rbuf + GW_SLOT_BYTES;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < GW_SLOT_TILES; ++j)
                     acc[si * GW_SLOT_TILES + j] = mfma4(wc[j][s], xc[s], acc[si * GW_SLOT_TILES + j]);      // four independent chains
-            }
+                __builtin_amdgcn_sched_barrier(0);
+                if (s == 0) gw_dma_piece<0>(wbase, voff, dst);
+                if (s == 1) gw_dma_piece<1>(wbase, voff, dst);
+                if (s == 2) {
+                    gw_dma_piece<2>(wbase, voff, dst);
+                    gw_dma_piece<3>(wbase, voff, dst);
+                    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * (GW_AHEAD - 1)) : "memory");      // slot t + 1 has landed
 #pragma unroll
-            for (int j = 0; j < GW_SLOT_TILES; ++j) wc[j] = wn[j];
+                    for (int j = 0; j < GW_SLOT_TILES; ++j) wn[j] = *(const f32x4*)(L.w_ptr + rbuf + j * TILE_BYTES);
+                    rbuf = (rbuf == (GW_RING - 1) * GW_SLOT_BYTES) ? 0u : rbuf + GW_SLOT_BYTES;
+                }
+            }
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the re-reads of the last slot)
 }
 
