@@ -1,9 +1,14 @@
-/* posendf_amd_debug.h -- bring-up, profiling and measurement aids of libposendf_amd.so.
+/* posendf_amd_debug.h -- bring-up, profiling and measurement aids: the entry points of libposendf_amd_debug.so.
  *
- * NOT part of the drop-in boundary (include/posendf_amd.h): nothing here has a counterpart in the reference, no caller of the
- * reference's path needs it, and a maintainer binding the library binds the public header only.  These entry points exist for
- * the repository's own tests (tests/test_timing_probe.py, tools/gpu_selfcheck.py) and for bench.py --diagnostics; they may
- * change or disappear between versions.  Plain C99 like the public header.
+ * NOT part of the drop-in boundary (include/posendf_amd.h) and NOT in the product library: libposendf_amd.so exports no pndf_debug_*
+ * symbol and carries no instrumented kernel, stage-dump kernel or probe.  Nothing here has a counterpart in the reference, no
+ * caller of the reference's path needs it, and a maintainer binding the library binds the public header only.  These entry points
+ * exist for the repository's own tests (tests/test_timing_probe.py, tools/gpu_selfcheck.py) and for bench.py --diagnostics; they
+ * may change or disappear between versions.  Plain C99 like the public header.
+ *
+ * The debug library has no link-time dependency on the product library: after loading both, the host hands it the addresses of
+ * the product library's three pndf_internal_* hooks (pndf_debug_bind; posendf_amd.engine.load_library does it), so that a variant
+ * product build is always instrumented by its own debug build.
  */
 #ifndef POSENDF_AMD_DEBUG_H
 #define POSENDF_AMD_DEBUG_H
@@ -13,6 +18,12 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* addresses of pndf_internal_launch, pndf_internal_describe, pndf_internal_fail of the PRODUCT library that created the handles
+ * the calls below will see; every handle-taking entry point returns PNDF_ERR_BAD_ARG before this has been called */
+int pndf_debug_bind(void* internal_launch, void* internal_describe, void* internal_fail);
+/* csrc/pndf_experiment.h: the OR of this library's per-translation-unit experiment words; 0 in a product build */
+unsigned pndf_debug_experiment_word(void);
 
 /* Bring-up aid: forward_grad on the first 64 poses with per-stage register dumps of workgroup 0.
  * `dump` is a device buffer of pndf_debug_floats() floats. */

@@ -11,7 +11,6 @@
 #include <vector>
 
 #include "../../include/posendf_amd.h"
-#include "../../include/posendf_amd_debug.h"
 #include "pndf_layout.h"
 #include "pndf_args.h"
 #include "pndf_host.h"
@@ -23,20 +22,12 @@ using namespace pndf;
 extern "C" __global__ void pndf_fused_relu_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_softplus_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_split_relu_kernel(PndfKernelArgs args);
-extern "C" __global__ void pndf_fused_split_relu_kernel_timing(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_split_softplus_kernel(PndfKernelArgs args);
-extern "C" __global__ void pndf_fused_split_softplus_kernel_timing(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_split2_relu_kernel(PndfKernelArgs args);        // pndf_kernel_split_x2.hip
 extern "C" __global__ void pndf_fused_split2_softplus_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_half_relu_kernel(PndfKernelArgs args);
-extern "C" __global__ void pndf_fused_half_relu_kernel_timing(PndfKernelArgs args);
-extern "C" __global__ void pndf_fused_relu_kernel_timing(PndfKernelArgs args);
-extern "C" int pndf_kernel_timing_regions();
-extern "C" int pndf_kernel_timing_layout(int what);
 extern "C" long long pndf_kernel_softplus_scratch_floats_per_wg();
-extern "C" __global__ void pndf_fused_relu_kernel_dbg(PndfKernelArgs args);
 extern "C" int pndf_kernel_lds_bytes();
-extern "C" int pndf_kernel_dbg_floats();
 
 
 struct pndf_engine {
@@ -81,12 +72,12 @@ static int fail(pndf_engine* h, int code, const std::string& msg) {
 // ablation macro that differs from its product default; a product library reports 0.
 PNDF_EXPORT_EXPERIMENT_WORD(capi)
 extern "C" {
-extern const unsigned pndf_experiment_word_fp32, pndf_experiment_word_fp32_timing, pndf_experiment_word_split,
-    pndf_experiment_word_split_x2, pndf_experiment_word_split_timing, pndf_experiment_word_lbs, pndf_experiment_word_generic;
+extern const unsigned pndf_experiment_word_fp32, pndf_experiment_word_split, pndf_experiment_word_split_x2, pndf_experiment_word_lbs,
+    pndf_experiment_word_generic;
 }
 extern "C" unsigned pndf_experiment_word(void) {
-    return pndf_experiment_word_capi | pndf_experiment_word_fp32 | pndf_experiment_word_fp32_timing | pndf_experiment_word_split |
-           pndf_experiment_word_split_x2 | pndf_experiment_word_split_timing | pndf_experiment_word_lbs | pndf_experiment_word_generic;
+    return pndf_experiment_word_capi | pndf_experiment_word_fp32 | pndf_experiment_word_split | pndf_experiment_word_split_x2 |
+           pndf_experiment_word_lbs | pndf_experiment_word_generic;
 }
 extern "C" const char* pndf_version(void) {
     static const std::string v = [] {
@@ -193,11 +184,7 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_split_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)pndf_fused_split_relu_kernel_timing, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
-    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_split_softplus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)pndf_fused_split_softplus_kernel_timing, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_split2_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
@@ -205,13 +192,7 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_half_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)pndf_fused_half_relu_kernel_timing, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
-    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_softplus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)pndf_fused_relu_kernel_timing, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)pndf_fused_relu_kernel_dbg, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e != hipSuccess) {
         std::string m = std::string("pndf_create: ") + hipGetErrorString(e);
         pndf_destroy(h);
@@ -508,8 +489,12 @@ extern "C" const char* pndf_kernel_name(pndf_handle h) {
 }
 
 // ------------------------------------------------------------------------------------------ launches
+// `instrumented`: a kernel of the DEBUG library (libposendf_amd_debug.so: the s_memtime / stage-dump builds of the fused kernels) to
+// launch instead of the handle's own, with the same arguments, grid and LDS -- pndf_internal_launch below; nullptr on every
+// product path.  The debug library decides which of its kernels matches the handle (pndf_internal_describe).
 static int launch(pndf_engine* h, int mode, const float* q, const float* gout, float* qo, float* d, int64_t B,
-                  int steps, float* dbg, void* stream, bool timing = false) {
+                  int steps, float* dbg, void* stream, const void* instrumented = nullptr) {
+    const bool timing = instrumented != nullptr;
     if (!h) return PNDF_ERR_BAD_ARG;
     if (!h->have_weights) return fail(h, PNDF_ERR_NO_WEIGHTS, "pndf_load_weights has not been called");
     if (B < 0 || steps < 0) return fail(h, PNDF_ERR_BAD_ARG, "negative batch or step count");
@@ -543,17 +528,9 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
     DeviceGuard guard(h->device);
     if (!guard.ok) return fail(h, PNDF_ERR_HIP, "hipSetDevice failed");
     const bool softplus = h->cfg.act == PNDF_ACT_SOFTPLUS;
-    if (a.noenc && dbg && !timing) return fail(h, PNDF_ERR_UNSUPPORTED, "the stage-dump kernel expects the structure encoder");
-    // the instrumented kernels exist for the three-term split kernels (relu family and softplus), the plain-f16 and the fp32
-    // relu-family kernel: refuse everything else rather than time another kernel than pndf_kernel_name() reports
-    if (timing && h->cfg.precision == PNDF_PREC_F16X3 && h->lo_all_zero)
-        return fail(h, PNDF_ERR_UNSUPPORTED, "no instrumented build of the two-term split kernels (set PNDF_THREE_TERMS=1 to time the three-term ones)");
-    if (timing && softplus && h->cfg.precision != PNDF_PREC_F16X3)
-        return fail(h, PNDF_ERR_UNSUPPORTED, "softplus timing kernel: f16x3 only");
+    if (dbg && !timing) return fail(h, PNDF_ERR_BAD_ARG, "a dump buffer needs an instrumented kernel (libposendf_amd_debug.so)");
     if (timing && softplus && B > (int64_t)WG_POSES * h->resident_wgs)
-        return fail(h, PNDF_ERR_UNSUPPORTED, "softplus timing kernel: at most one 64-pose block per compute unit");
-    if (softplus && dbg && !(timing && h->cfg.precision == PNDF_PREC_F16X3))
-        return fail(h, PNDF_ERR_UNSUPPORTED, "the debug dump exists for the relu-family kernel only");
+        return fail(h, PNDF_ERR_UNSUPPORTED, "instrumented softplus kernel: at most one 64-pose block per compute unit");
     if (mode == MODE_PROJECT && steps == 0) {
         // zero iterations: the loop body never runs (sample_poses.py:70); poses pass through
         if (qo != q) HIP_TRY(h, hipMemcpyAsync(qo, q, (size_t)B * NQ * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -574,9 +551,10 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
         if (h->sp_pending && h->sp_stream != stream && !capturing)
             HIP_TRY(h, hipStreamWaitEvent((hipStream_t)stream, h->sp_done, 0));
         a.scratch = h->d_scratch;
-        if (timing)     // instrumented: one workgroup per block like the relu timing kernel needs B <= 64 * resident_wgs
-            hipLaunchKernelGGL(pndf_fused_split_softplus_kernel_timing, pgrid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
-        else if (h->cfg.precision == PNDF_PREC_F16X3 && h->lo_all_zero)
+        if (timing) {   // instrumented: one workgroup per block like the relu timing kernel needs B <= 64 * resident_wgs
+            void* kargs[] = {&a};
+            HIP_TRY(h, hipLaunchKernel(instrumented, pgrid, block, kargs, pndf_kernel_lds_bytes(), (hipStream_t)stream));
+        } else if (h->cfg.precision == PNDF_PREC_F16X3 && h->lo_all_zero)
             hipLaunchKernelGGL(pndf_fused_split2_softplus_kernel, pgrid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
         else if (h->cfg.precision == PNDF_PREC_F16X3)
             hipLaunchKernelGGL(pndf_fused_split_softplus_kernel, pgrid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
@@ -591,14 +569,12 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
         return PNDF_OK;
     }
     const bool split = h->cfg.precision == PNDF_PREC_F16X3, half = h->cfg.precision == PNDF_PREC_F16;
-    if ((split || half) && dbg && !timing) return fail(h, PNDF_ERR_UNSUPPORTED, "the stage-dump kernel exists for fp32 precision only");
-    if (half && timing) hipLaunchKernelGGL(pndf_fused_half_relu_kernel_timing, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
-    else if (half) hipLaunchKernelGGL(pndf_fused_half_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
-    else if (split && timing) hipLaunchKernelGGL(pndf_fused_split_relu_kernel_timing, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+    if (timing) {
+        void* kargs[] = {&a};
+        HIP_TRY(h, hipLaunchKernel(instrumented, grid, block, kargs, pndf_kernel_lds_bytes(), (hipStream_t)stream));
+    } else if (half) hipLaunchKernelGGL(pndf_fused_half_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else if (split && h->lo_all_zero) hipLaunchKernelGGL(pndf_fused_split2_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else if (split) hipLaunchKernelGGL(pndf_fused_split_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
-    else if (timing) hipLaunchKernelGGL(pndf_fused_relu_kernel_timing, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
-    else if (dbg) hipLaunchKernelGGL(pndf_fused_relu_kernel_dbg, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else hipLaunchKernelGGL(pndf_fused_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     HIP_TRY(h, hipGetLastError());
     return PNDF_OK;
@@ -621,20 +597,26 @@ extern "C" int pndf_project(pndf_handle h, const float* q_in, float* q_out, floa
     return launch(h, MODE_PROJECT, q_in, nullptr, q_out, d_last, B, steps, nullptr, stream);
 }
 
-extern "C" int64_t pndf_debug_floats(void) { return pndf_kernel_dbg_floats(); }
-
-extern "C" int pndf_debug_forward_grad(pndf_handle h, const float* q, float* d, float* dq, int64_t B, float* dump,
-                                       void* stream) {
-    if (!dump) return fail(h, PNDF_ERR_BAD_ARG, "dump is null");
-    return launch(h, MODE_FORWARD_GRAD, q, nullptr, dq, d, B, 1, dump, stream);
+// ---- hooks for the debug library (libposendf_amd_debug.so; include/posendf_amd_debug.h).  Not declared in any installed header and
+// not part of the boundary: the instrumented builds of the fused kernels, the stage-dump kernel and the memory probes live in a
+// library of their own, which reaches the engine through these three entry points -- bound at run time by
+// posendf_amd.engine (function addresses handed to pndf_debug_bind), so that a variant product library (PNDF_LIBRARY) is
+// instrumented by its own debug library and never by the default one.
+extern "C" int pndf_internal_launch(pndf_handle h, int mode, const float* q, const float* gout, float* qo, float* d, int64_t B, int steps,
+                                    float* dbg, void* stream, const void* kernel) {
+    if (!kernel) return fail(h, PNDF_ERR_BAD_ARG, "pndf_internal_launch: no kernel");
+    return launch(h, mode, q, gout, qo, d, B, steps, dbg, stream, kernel);
 }
-
-extern "C" int pndf_debug_timing_regions(void) { return pndf_kernel_timing_regions(); }
-extern "C" int pndf_debug_timing_layout(int what) { return pndf_kernel_timing_layout(what); }
-
-// project() through the instrumented kernel; cycles[(wg * 4 + wave) * regions + r] = shader cycles
-extern "C" int pndf_debug_project_timing(pndf_handle h, const float* q_in, float* q_out, int64_t B, int steps,
-                                         unsigned long long* cycles, void* stream) {
-    if (!cycles) return fail(h, PNDF_ERR_BAD_ARG, "cycles is null");
-    return launch(h, MODE_PROJECT, q_in, nullptr, q_out, nullptr, B, steps, (float*)cycles, stream, true);
+// what[0..6] = precision, act, lo_all_zero, noenc, runtime-planned, resident workgroups, LDS bytes of a fused kernel
+extern "C" int pndf_internal_describe(pndf_handle h, int* what, int n) {
+    if (!h || !what || n < 7) return PNDF_ERR_BAD_ARG;
+    what[0] = h->cfg.precision;
+    what[1] = h->cfg.act;
+    what[2] = h->lo_all_zero ? 1 : 0;
+    what[3] = (h->cfg.dims[0] == NOENC_IN) ? 1 : 0;
+    what[4] = h->generic ? 1 : 0;
+    what[5] = h->resident_wgs;
+    what[6] = pndf_kernel_lds_bytes();
+    return PNDF_OK;
 }
+extern "C" int pndf_internal_fail(pndf_handle h, int code, const char* msg) { return fail(h, code, msg ? msg : ""); }

@@ -499,13 +499,22 @@ __device__ __forceinline__ void pndf_fused_body(const PndfKernelArgs& args) {
     }   // block loop
 }
 
-#ifdef PNDF_TIMING_TU
-// relu-family kernel with s_memtime region stamps (performance analysis only; its own translation unit,
-// pndf_kernel_timing.hip, with the ring's sampled event stamps compiled in: pndf_device.h PNDF_RING_STAMPS)
+#if defined(PNDF_TIMING_TU)
+// relu-family kernel with s_memtime region stamps (performance analysis only; its own translation unit, pndf_kernel_timing.hip,
+// with the ring's sampled event stamps compiled in -- pndf_device.h PNDF_RING_STAMPS -- and part of the DEBUG library only)
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1)
 pndf_fused_relu_kernel_timing(PndfKernelArgs args) {
     pndf_fused_body<false, false, true>(args);
 }
+extern "C" int pndf_kernel_timing_regions() { return TIMING_REGIONS + TIMING_GROUPS + TIMING_RING; }
+extern "C" int pndf_kernel_timing_layout(int what) { return what == 0 ? TIMING_REGIONS : what == 1 ? TIMING_GROUPS : what == 2 ? TIMING_RING : what == 3 ? (int)RING_STAMP_PERIOD : RING_SLOTS; }
+#elif defined(PNDF_DBG_TU)
+// relu-family kernel with per-stage register dumps from workgroup 0 (tests / bring-up only; pndf_kernel_dbg.hip, DEBUG library)
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1)
+pndf_fused_relu_kernel_dbg(PndfKernelArgs args) {
+    pndf_fused_body<true, false>(args);
+}
+extern "C" int pndf_kernel_dbg_floats() { return DBG_TOTAL * WG_THREADS; }
 #else
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1)
 pndf_fused_relu_kernel(PndfKernelArgs args) {
@@ -518,16 +527,7 @@ pndf_fused_softplus_kernel(PndfKernelArgs args) {
     pndf_fused_body<false, true>(args);
 }
 
-// relu-family kernel with per-stage register dumps from workgroup 0 (tests / bring-up only).
-extern "C" __global__ void __launch_bounds__(WG_THREADS, 1)
-pndf_fused_relu_kernel_dbg(PndfKernelArgs args) {
-    pndf_fused_body<true, false>(args);
-}
-
-extern "C" int pndf_kernel_timing_regions() { return TIMING_REGIONS + TIMING_GROUPS + TIMING_RING; }
-extern "C" int pndf_kernel_timing_layout(int what) { return what == 0 ? TIMING_REGIONS : what == 1 ? TIMING_GROUPS : what == 2 ? TIMING_RING : what == 3 ? (int)RING_STAMP_PERIOD : RING_SLOTS; }
 extern "C" int pndf_kernel_lds_bytes() { return LDS_TOTAL; }
-extern "C" int pndf_kernel_dbg_floats() { return DBG_TOTAL * WG_THREADS; }
 extern "C" long long pndf_kernel_softplus_scratch_floats_per_wg() { return SP_WG_FLOATS; }
 #endif
 

@@ -216,3 +216,5 @@ extern "C" int pndf_debug_ring_stream(int device, int passes, double* sec_per_pa
     if (buf) (void)hipFree(buf);
     return rc;
 }
+
+PNDF_EXPORT_EXPERIMENT_WORD(probe)

@@ -32,6 +32,55 @@ class PndfError(RuntimeError):
     pass
 
 
+def debug_library_path(product_path: str) -> str:
+    """libposendf_amd.so -> libposendf_amd_debug.so (variant builds: lib_<name>.so -> lib_<name>_debug.so, next to it)"""
+    base, ext = os.path.splitext(product_path)
+    return base + "_debug" + ext
+
+
+class _PndfLibrary(ctypes.CDLL):
+    """The PRODUCT library.  It exports no `pndf_debug_*` symbol (include/posendf_amd_debug.h lives in libposendf_amd_debug.so);
+    asking this object for one loads the debug library that was built next to it -- on first use only, so a process that never
+    profiles maps the product library alone --, binds it to this library's `pndf_internal_*` hooks and answers from there."""
+
+    def __getattr__(self, name):
+        if name.startswith("pndf_debug_"):
+            fn = getattr(self._debug(), name)
+            setattr(self, name, fn)
+            return fn
+        return super().__getattr__(name)
+
+    def _debug(self):
+        dbg = self.__dict__.get("_pndf_debug_lib")
+        if dbg is None:
+            path = debug_library_path(self._name)
+            if not os.path.exists(path):
+                raise PndfError(f"{path} not found (the debug library is built with the product one: __graft_entry__.build())")
+            dbg = ctypes.CDLL(path)
+            H = c_void_p
+            dbg.pndf_debug_bind.argtypes = [c_void_p, c_void_p, c_void_p]
+            dbg.pndf_debug_bind.restype = c_int
+            dbg.pndf_debug_experiment_word.restype = ctypes.c_uint
+            dbg.pndf_debug_forward_grad.argtypes = [H, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
+            dbg.pndf_debug_forward_grad.restype = c_int
+            dbg.pndf_debug_floats.restype = c_int64
+            dbg.pndf_debug_project_timing.argtypes = [H, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]
+            dbg.pndf_debug_project_timing.restype = c_int
+            dbg.pndf_debug_timing_regions.restype = c_int
+            dbg.pndf_debug_timing_layout.argtypes = [c_int]
+            dbg.pndf_debug_timing_layout.restype = c_int
+            dbg.pndf_debug_mem_probe.argtypes = [c_int, c_void_p, c_int]
+            dbg.pndf_debug_mem_probe.restype = c_int
+            dbg.pndf_debug_ring_stream.argtypes = [c_int, c_int, c_void_p]
+            dbg.pndf_debug_ring_stream.restype = c_int
+            hooks = [ctypes.cast(ctypes.CDLL.__getattr__(self, n), c_void_p) for n in
+                     ("pndf_internal_launch", "pndf_internal_describe", "pndf_internal_fail")]
+            if dbg.pndf_debug_bind(*hooks) != 0:
+                raise PndfError("pndf_debug_bind failed")
+            self.__dict__["_pndf_debug_lib"] = dbg
+        return dbg
+
+
 def load_library(path: str | None = None) -> ctypes.CDLL:
     path = path or os.environ.get("PNDF_LIBRARY") or _LIB_PATH      # PNDF_LIBRARY: A/B runs of two builds on one box
     # PyTorch is the plumbing for device memory and streams, so the library must share PyTorch's HIP runtime:
@@ -45,7 +94,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     if not os.path.exists(path):
         raise PndfError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). The engine has no fallback path.")
-    lib = ctypes.CDLL(path)
+    lib = _PndfLibrary(path)
     H = c_void_p
     lib.pndf_default_config.argtypes = [POINTER(PndfConfig), c_int32, c_float]
     lib.pndf_default_config.restype = None
@@ -55,17 +104,6 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.pndf_forward.argtypes = [H, c_void_p, c_void_p, c_int64, c_void_p]
     lib.pndf_forward_grad.argtypes = [H, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
     lib.pndf_project.argtypes = [H, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]
-    lib.pndf_debug_forward_grad.argtypes = [H, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
-    lib.pndf_debug_floats.restype = c_int64
-    lib.pndf_debug_project_timing.argtypes = [H, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]
-    lib.pndf_debug_project_timing.restype = c_int
-    lib.pndf_debug_timing_regions.restype = c_int
-    lib.pndf_debug_timing_layout.argtypes = [c_int]
-    lib.pndf_debug_timing_layout.restype = c_int
-    lib.pndf_debug_mem_probe.argtypes = [c_int, c_void_p, c_int]
-    lib.pndf_debug_mem_probe.restype = c_int
-    lib.pndf_debug_ring_stream.argtypes = [c_int, c_int, c_void_p]
-    lib.pndf_debug_ring_stream.restype = c_int
     lib.pndf_packed_sizes.argtypes = [POINTER(c_int64)] * 2
     lib.pndf_packed_sizes.restype = None
     lib.pndf_pack_host.argtypes = [POINTER(c_void_p), POINTER(c_int64), c_int, c_void_p, c_void_p]
@@ -132,17 +170,19 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.pndf_kernel_name.argtypes = [H]
     lib.pndf_kernel_name.restype = c_char_p
     for name in ("pndf_create", "pndf_destroy", "pndf_load_weights", "pndf_forward", "pndf_forward_grad",
-                 "pndf_project", "pndf_debug_forward_grad", "pndf_pack_host", "pndf_pack_host_split"):
+                 "pndf_project", "pndf_pack_host", "pndf_pack_host_split"):
         getattr(lib, name).restype = c_int
     return lib
 
 
 # bring-up / profiling / measurement aids: include/posendf_amd_debug.h, NOT the drop-in boundary
-DEBUG_EXPORTS = ("pndf_debug_forward_grad", "pndf_debug_floats", "pndf_debug_project_timing", "pndf_debug_timing_regions",
-                 "pndf_debug_timing_layout", "pndf_debug_mem_probe", "pndf_debug_ring_stream")
+DEBUG_EXPORTS = ("pndf_debug_bind", "pndf_debug_experiment_word", "pndf_debug_forward_grad", "pndf_debug_floats", "pndf_debug_project_timing",
+                 "pndf_debug_timing_regions", "pndf_debug_timing_layout", "pndf_debug_mem_probe", "pndf_debug_ring_stream")
 # per-translation-unit experiment words (csrc/pndf_experiment.h): data symbols, all zero in a product build
-EXPERIMENT_WORDS = ("pndf_experiment_word_capi", "pndf_experiment_word_fp32", "pndf_experiment_word_fp32_timing", "pndf_experiment_word_split",
-                    "pndf_experiment_word_split_x2", "pndf_experiment_word_split_timing", "pndf_experiment_word_lbs", "pndf_experiment_word_generic")
+EXPERIMENT_WORDS = ("pndf_experiment_word_capi", "pndf_experiment_word_fp32", "pndf_experiment_word_split", "pndf_experiment_word_split_x2",
+                    "pndf_experiment_word_lbs", "pndf_experiment_word_generic")
+DEBUG_EXPERIMENT_WORDS = ("pndf_experiment_word_debug", "pndf_experiment_word_fp32_timing", "pndf_experiment_word_split_timing",
+                          "pndf_experiment_word_fp32_dbg", "pndf_experiment_word_probe")
 
 
 def experiment_word(lib=None) -> int:
@@ -152,6 +192,9 @@ def experiment_word(lib=None) -> int:
     w = 0
     for name in EXPERIMENT_WORDS:
         w |= int(ctypes.c_uint.in_dll(lib, name).value)
+    dbg = lib._debug() if isinstance(lib, _PndfLibrary) else None      # (the debug library next to it: the same rule)
+    for name in (DEBUG_EXPERIMENT_WORDS if dbg is not None else ()):
+        w |= int(ctypes.c_uint.in_dll(dbg, name).value)
     return w
 
 

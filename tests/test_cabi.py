@@ -41,7 +41,17 @@ def test_debug_entry_points_live_in_their_own_header(lib):
     assert dbg == set(engine.DEBUG_EXPORTS) and all(n.startswith("pndf_debug_") for n in dbg)
     assert not (dbg & set(engine.EXPORTS))
     for name in dbg:
-        assert hasattr(lib, name), f"{name} declared in the debug header but not exported"
+        assert hasattr(lib, name), f"{name} declared in the debug header but not exported"      # (answered by the debug library, lazily)
+    # ... and the PRODUCT library carries none of it: no pndf_debug_* symbol, no instrumented / stage-dump kernel, no probe
+    import subprocess
+    import __graft_entry__ as ge
+    syms = subprocess.run(["nm", "-D", "--defined-only", ge.LIB], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in syms.splitlines() if ln.strip()]
+    assert any(n == "pndf_project" for n in names) and any(n == "pndf_fused_split_relu_kernel" for n in names)
+    leaked = [n for n in names if "debug" in n or "timing" in n or n.endswith("_dbg") or "probe" in n]
+    assert not leaked, leaked
+    dsyms = subprocess.run(["nm", "-D", "--defined-only", engine.debug_library_path(ge.LIB)], capture_output=True, text=True, check=True).stdout
+    assert all(any(ln.split()[-1] == n for ln in dsyms.splitlines() if ln.strip()) for n in dbg)
 
 
 def test_product_library_carries_no_experiment(lib, tmp_path):
@@ -52,7 +62,9 @@ def test_product_library_carries_no_experiment(lib, tmp_path):
     from posendf_amd import engine
     for name in engine.EXPERIMENT_WORDS:
         assert ctypes.c_uint.in_dll(lib, name).value == 0, name
-    assert engine.experiment_word(lib) == 0 and lib.pndf_experiment_word() == 0
+    for name in engine.DEBUG_EXPERIMENT_WORDS:      # the debug library built next to it: the same rule
+        assert ctypes.c_uint.in_dll(lib._debug(), name).value == 0, name
+    assert engine.experiment_word(lib) == 0 and lib.pndf_experiment_word() == 0 and lib.pndf_debug_experiment_word() == 0
     assert b"experiments=0x00000000" in lib.pndf_version()
     hdr = os.path.join(REPO, "posendf_amd", "csrc", "pndf_experiment.h")
     cc = ["gcc", "-x", "c", "-fsyntax-only", hdr]

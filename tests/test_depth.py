@@ -208,3 +208,53 @@ def test_what_the_engine_still_refuses():
     assert rc in (0, -6), (rc, lib.pndf_last_error(None))
     if h.value:
         lib.pndf_destroy(h)
+
+
+# width / depth extremes that no fixture of the reference covers: the oracle -- pinned at 1, 3, 4, 6 and 7 hidden layers above -- is the checker
+EXTREMES = [([1], "lrelu", True), ([16], "relu", True), ([17], "softplus", True), ([1024], "lrelu", True), ([1, 1], "lrelu", True),
+            ([15, 17, 33], "softplus", True), ([1024, 1024], "relu", True), ([64] * 7, "lrelu", True), ([1000, 3, 900], "lrelu", True),
+            ([7, 1024, 5, 1024, 3, 1024, 9], "softplus", False), ([512, 513], "lrelu", False), ([256, 512, 1024, 512, 256, 64, 32], "relu", True)]
+
+
+def live_weights(dims, act):
+    """the first seed (deterministic) whose network is not clipped to d = 0 on most poses: a dead network tests nothing"""
+    from oracle import posendf_np as onp
+    from posendf_amd import synth
+    probe = synth.make_poses(48, seed=60)
+    for seed in range(50, 90):
+        sd = synth.make_weights(seed, 2.5, 0.3, dims=dims)
+        d = onp.forward(probe, sd, act)
+        if (d > 1e-3).mean() > 0.8:
+            return sd
+    raise AssertionError(f"no live weight set for {dims} {act}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hidden,act,enc", EXTREMES, ids=lambda v: "-".join(map(str, v)) if isinstance(v, list) else str(v))
+def test_runtime_planned_kernels_width_and_depth_extremes(hidden, act, enc):
+    """Hidden widths 1, 15 - 17, one past a tile / a pass / 512, 1024; one to seven hidden layers; bottlenecks of a few units between
+    1024-wide layers: single step and a 3-step projection against the numpy oracle (fp64 truth, the fp32 oracle's own noise as the
+    envelope), through the per-pose gates."""
+    import torch
+    from oracle import posendf_np as onp
+    from posendf_amd import PoseNDF, synth
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X (no CPU fallback exists)"
+    dims = (126 if enc else 84, *hidden, 1)
+    sd = live_weights(dims, act)
+    net = PoseNDF(config_for(hidden, act, enc, "cuda:0"))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    q_np = np.concatenate([synth.make_poses(100, seed=61), synth.make_poses(100, seed=62, signed=True)])
+    q = torch.from_numpy(q_np).cuda().requires_grad_(True)
+    d = net(q, train=False)["dist_pred"]
+    (dq,) = torch.autograd.grad(d.sum(), q)
+    assert net._engine_for(q.device).kernel_name().startswith("pndf_generic_")
+    sig_d, sig_g, d64, g64 = fp32_noise(q_np, sd, act)
+    what = f"{hidden} {act} enc={enc}"
+    pose_gate(d_rows(d.detach().cpu().numpy(), d64), sig_d, what + " d")
+    pose_gate(rel_err_rows(dq.cpu().numpy(), g64), sig_g, what + " dq", exempt=kink_exempt(q_np, sd, act))
+    qp, _ = net.project(torch.from_numpy(q_np).cuda(), steps=3)
+    q64, _ = onp.project(q_np, sd, steps=3, act=act, dtype=np.float64)
+    q32, _ = onp.project(q_np, sd, steps=3, act=act)
+    env = traj_envelope(q_np, sd, act, 3, q64)
+    outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, what + " project 3", margin=env["margin"], sigma=env["sigma"])

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.join(REPO, "tools"))
 import isa_hazards  # noqa: E402
 
 LIB = os.path.join(REPO, "posendf_amd", "lib", "libposendf_amd.so")
+LIB_DEBUG = os.path.join(REPO, "posendf_amd", "lib", "libposendf_amd_debug.so")      # (the instrumented builds: the same rules)
 
 
 def test_checker_flags_a_short_distance_and_a_foreign_m0_write():
@@ -31,7 +32,12 @@ def test_checker_flags_a_short_distance_and_a_foreign_m0_write():
 @pytest.mark.skipif(not os.path.exists(LIB), reason="library not built")
 def test_shipped_kernels_keep_their_wait_states_and_m0():
     ks = isa_hazards.kernels(LIB)
-    assert any(k.startswith("pndf_fused_split_relu_kernel") for k in ks)
+    assert any(k.startswith("pndf_fused_split_relu_kernel") for k in ks) and any(k.startswith("pndf_generic_") for k in ks)
+    assert not any("timing" in k or "_dbg" in k or "probe" in k for k in ks), sorted(ks)      # those live in the debug library
+    if os.path.exists(LIB_DEBUG):
+        dk = isa_hazards.kernels(LIB_DEBUG)
+        assert any(k.endswith("_timing") for k in dk)
+        ks = {**ks, **dk}
     findings = []
     for name, ins in ks.items():
         bad_w, _, _ = isa_hazards.check_wait_states(ins)
