@@ -42,8 +42,8 @@ struct PndfGenericArgs {
     const float* grad_out;  // [B] or null
     const char* enc_stream; // encoder forward section | backward section (PNDF_GEN_ENC_SECTION_TILES KiB each), null without encoder
     const float* bias;      // BIAS_FLOATS block (the encoder's biases)
-    const float* wfwd;      // forward weight tiles of all layers, [block][k tile][tile of the block] per layer
-    const float* wbwd;      // the same for the transposed matrices
+    const float* wfwd;      // the step's weight stream: forward tiles of all layers, [pass][k tile][tile of the pass] per layer, then
+    const float* wbwd;      //   the transposed matrices in the backward pass's order (wf_off / wb_off index this ONE stream; wbwd == wfwd)
     const float* lbias;     // biases, each layer padded to whole blocks of tiles
     float* scratch;         // gridDim.x * wg_tiles tile slots of 4 KiB: activations (ping, pong), derivative factors per layer
     long long B;
@@ -61,6 +61,7 @@ struct PndfGenericArgs {
     int d_off[PNDF_GEN_MAXLIN];  // first tile slot of the layer's derivative factors in the workgroup's scratch
     int enc_d_off;               // softplus: first tile slot of the encoder's 42 derivative tiles
     int wg_tiles;                // tile slots per workgroup
+    int w_slots;                 // 4-tile slots of the step's weight stream (forward half, then the backward half in its own order)
 };
 constexpr int PNDF_GEN_ENC_SECTION_TILES = 48 + 4 * 16;      // the encoder's 3 slots + what the ring fetches ahead (4 slots)
 

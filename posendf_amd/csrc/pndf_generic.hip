@@ -103,50 +103,65 @@ __device__ __forceinline__ void gw_dma_tile(const char* base, uint32_t voff, uin
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
 }
 
-// acc[t] += sum_k W(t, k) X[k] for `NG * NTB` output tiles (one pass over a layer) at once.  `wbase` (uniform) = the pass's first weight
-// tile, stream order [k][tile of the pass]; `xbase` (uniform) = this wave's 1 KiB of operand tile 0 (tiles 4 KiB apart).  Register
+// The weight stream of a step is ONE sequence of slots in consumption order -- forward passes layer by layer, then the transposed
+// matrices in the backward pass's order -- so the ring is started once per step and runs through every pass: a pass ends with the
+// first slots of the next one already in flight (with a ring per pass the 16 passes of a step each began on an empty ring).
+struct GenRing {
+    uint32_t fetch, last;        // per lane: byte offset of the next slot to fetch / of the stream's last slot (+ lane * 16)
+    uint32_t fbuf, rbuf;         // uniform: ring buffer the next fetch goes to / the next read comes from
+    f32x4 wt[2][GW_SLOT_TILES];  // the tiles of the current slot (set 0 at every pass boundary: a pass is an even number of slots)
+};
+__device__ __forceinline__ void gen_ring_start(GenRing& R, const char* wbase, int total_slots, const GenLds& L) {
+    R.last = (uint32_t)(total_slots - 1) * GW_SLOT_BYTES + L.lane16;      // (fetches past the end re-read the last slot: no branch)
+    R.fetch = L.lane16;
+    R.fbuf = 0;
+#pragma unroll
+    for (int i = 0; i < GW_AHEAD; ++i) {
+        gw_dma_slot(wbase, R.fetch < R.last ? R.fetch : R.last, L.w_lds + R.fbuf);
+        R.fetch += GW_SLOT_BYTES;
+        R.fbuf += GW_SLOT_BYTES;
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * (GW_AHEAD - 1)) : "memory");
+#pragma unroll
+    for (int j = 0; j < GW_SLOT_TILES; ++j) R.wt[0][j] = *(const f32x4*)(L.w_ptr + j * TILE_BYTES);
+    R.rbuf = GW_SLOT_BYTES;
+}
+
+// acc[t] += sum_k W(t, k) X[k] for `NG * NTB` output tiles (one pass over a layer) at once: the next nk * SPK slots of the ring.
+// `wbase` (uniform) = the stream's first tile; `xbase` (uniform) = this wave's 1 KiB of operand tile 0 (tiles 4 KiB apart).  Register
 // indices must be compile-time, so the number of groups is a template parameter: the plan rounds a layer's output tiles up to whole
 // groups (host side: gen_round_tiles) and the layer code is instantiated per group count of a pass.  (A first form kept 64
 // accumulators under run-time guards `if (group < ng)`: hipcc answered with 700 spilled registers.)
+// The tiles of a slot are read from LDS one slot ahead of their MFMAs, into one of two register sets that alternate by slot parity
+// (no copies).  One wave per SIMD overlaps its own non-MFMA instructions with its own MFMAs only when they sit between them in
+// program order (DESIGN.md section 2 "epilogue in MFMA slots"), so a slot is laid out by hand and pinned:
+//   M M M M  P0 | M M M M  P1 | M M M M  P2 P3  wait(slot t + 1)  R R R R  [X] | M M M M
+// P = one 1-KiB piece of the fetch of slot t + 4, R = the four tile reads of slot t + 1, X (last slot of a k step) = the read of the
+// NEXT k step's operand tile: their latency hides behind the last round.
 // vmcnt bookkeeping (loads retire in order; other operations of the wave in the queue only make a counted wait stricter):
-//   slot t + 1 is read (one slot ahead of its MFMAs) after DMA(t + 4) has been issued: three younger slots x 4 pieces -> vmcnt(12).
-//   Operand tile k + 1 is issued at the top of k step k and read at the top of k step k + 1: the SPK slots issued in between are
-//   younger -> vmcnt(min(4 SPK, 12)).
+//   slot t + 1 is read after DMA(t + 4) has been issued: three younger slots x 4 pieces -> vmcnt(12).  Operand tile k + 1 is issued
+//   at the top of k step k and read in its last slot: the SPK slots issued in between are younger -> vmcnt(min(4 SPK, 12)).  Operand
+//   tile 0 of a pass is the youngest operation when it is needed: vmcnt(0), once per pass (the ring's slots land meanwhile).
 template <int NG>
-__device__ __forceinline__ void gen_layer(const char* wbase, const char* xbase, int nk, f32x4 (&acc)[NG * NTB], const GenLds& L) {
-    constexpr int SPK = NG * NTB / GW_SLOT_TILES;                  // slots per k step: even, so the two register sets below alternate by si
+__device__ __forceinline__ void gen_layer(GenRing& R, const char* wbase, const char* xbase, int nk, f32x4 (&acc)[NG * NTB], const GenLds& L) {
+    constexpr int SPK = NG * NTB / GW_SLOT_TILES;                  // slots per k step: even, so the two register sets alternate by si
     static_assert(SPK % 2 == 0, "the tile registers of consecutive slots alternate by slot parity");
-    const uint32_t last = (uint32_t)(nk * SPK - 1) * GW_SLOT_BYTES + L.lane16;      // (fetches past the end re-read the last slot: no branch)
+    constexpr int XWAIT = 4 * SPK < 4 * (GW_AHEAD - 1) ? 4 * SPK : 4 * (GW_AHEAD - 1);
     gw_dma_tile(xbase, L.lane16, L.x_lds);
-    uint32_t fetch = L.lane16, fbuf = 0, rbuf = 0;
-#pragma unroll
-    for (int i = 0; i < GW_AHEAD; ++i) {
-        gw_dma_slot(wbase, fetch < last ? fetch : last, L.w_lds + fbuf);
-        fetch += GW_SLOT_BYTES;
-        fbuf += GW_SLOT_BYTES;
-    }
-    // The tiles of a slot are read from LDS one slot ahead of their MFMAs, into one of two register sets that alternate by slot
-    // parity (no copies).  One wave per SIMD overlaps its own non-MFMA instructions with its own MFMAs only when they sit between
-    // them in program order (DESIGN.md section 2 "epilogue in MFMA slots"), so a slot is laid out by hand and pinned:
-    //   M M M M  P0 | M M M M  P1 | M M M M  P2 P3  wait(slot t + 1)  R R R R | M M M M
-    // P = one 1-KiB piece of the fetch of slot t + 4, R = the four tile reads of slot t + 1 (their latency hides behind the last round).
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * (GW_AHEAD - 1)) : "memory");
-    f32x4 wt[2][GW_SLOT_TILES];
-#pragma unroll
-    for (int j = 0; j < GW_SLOT_TILES; ++j) wt[0][j] = *(const f32x4*)(L.w_ptr + j * TILE_BYTES);
-    rbuf = GW_SLOT_BYTES;                                          // ring buffer of the next slot to read
+    if (nk > 1) gw_dma_tile(xbase, SLOT_F4 * 16u + L.lane16, L.x_lds + TILE_BYTES);
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(0) : "memory");
+    f32x4 xc = *(const f32x4*)L.x_ptr, xn = xc;
     for (int k = 0; k < nk; ++k) {
-        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * SPK < 4 * (GW_AHEAD - 1) ? 4 * SPK : 4 * (GW_AHEAD - 1)) : "memory");
-        const f32x4 xc = *(const f32x4*)(L.x_ptr + (k & 1) * TILE_BYTES);
-        gw_dma_tile(xbase, (uint32_t)((k + 1 < nk) ? k + 1 : k) * (SLOT_F4 * 16u) + L.lane16, L.x_lds + ((k + 1) & 1) * TILE_BYTES);
+        // operand tile k + 2 -> the buffer tile k was read from (k >= 1: at the end of k step k - 1; k = 0: just now)
+        if (k >= 1) gw_dma_tile(xbase, (uint32_t)((k + 1 < nk) ? k + 1 : k) * (SLOT_F4 * 16u) + L.lane16, L.x_lds + ((k + 1) & 1) * TILE_BYTES);
 #pragma unroll
         for (int si = 0; si < SPK; ++si) {
-            const f32x4 (&wc)[GW_SLOT_TILES] = wt[si & 1];
-            f32x4 (&wn)[GW_SLOT_TILES] = wt[(si + 1) & 1];
-            const uint32_t voff = fetch < last ? fetch : last;
-            const uint32_t dst = L.w_lds + fbuf;                   // the buffer slot t - 1 was read from, a slot ago
-            fetch += GW_SLOT_BYTES;
-            fbuf = (fbuf == (GW_RING - 1) * GW_SLOT_BYTES) ? 0u : fbuf + GW_SLOT_BYTES;
+            const f32x4 (&wc)[GW_SLOT_TILES] = R.wt[si & 1];
+            f32x4 (&wn)[GW_SLOT_TILES] = R.wt[(si + 1) & 1];
+            const uint32_t voff = R.fetch < R.last ? R.fetch : R.last;
+            const uint32_t dst = L.w_lds + R.fbuf;                 // the buffer slot t - 1 was read from, a slot ago
+            R.fetch += GW_SLOT_BYTES;
+            R.fbuf = (R.fbuf == (GW_RING - 1) * GW_SLOT_BYTES) ? 0u : R.fbuf + GW_SLOT_BYTES;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -159,16 +174,18 @@ __device__ __forceinline__ void gen_layer(const char* wbase, const char* xbase, 
                 if (s == 2) {
                     gw_dma_piece<2>(wbase, voff, dst);
                     gw_dma_piece<3>(wbase, voff, dst);
-                    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * (GW_AHEAD - 1)) : "memory");      // slot t + 1 has landed
+                    if (si == SPK - 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XWAIT) : "memory");                 // slot t + 1 AND operand tile k + 1
+                    else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * (GW_AHEAD - 1)) : "memory");                 // slot t + 1 has landed
 #pragma unroll
-                    for (int j = 0; j < GW_SLOT_TILES; ++j) wn[j] = *(const f32x4*)(L.w_ptr + rbuf + j * TILE_BYTES);
-                    rbuf = (rbuf == (GW_RING - 1) * GW_SLOT_BYTES) ? 0u : rbuf + GW_SLOT_BYTES;
+                    for (int j = 0; j < GW_SLOT_TILES; ++j) wn[j] = *(const f32x4*)(L.w_ptr + R.rbuf + j * TILE_BYTES);
+                    R.rbuf = (R.rbuf == (GW_RING - 1) * GW_SLOT_BYTES) ? 0u : R.rbuf + GW_SLOT_BYTES;
+                    if (si == SPK - 1) xn = *(const f32x4*)(L.x_ptr + ((k + 1) & 1) * TILE_BYTES);
                 }
             }
         }
+        xc = xn;
     }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the re-reads of the last slot)
 }
 
 // hidden activation of one D tile (reference net_modules.py:30-41,64-65) and its derivative factor
@@ -189,7 +206,7 @@ __device__ __forceinline__ void gen_act(f32x4& z, f32x4& dfac, float slope, cons
 // one forward layer with NG groups of output tiles: bias -> accumulate -> (hidden layers) activation, derivative factor
 template <int NG, bool SP>
 __device__ __forceinline__ void gen_forward(const char* w, const float* bias, const char* xin, f32x4* xout, f32x4* dl, int nk, bool last,
-                                            float slope, const SpK& k, int g, f32x4& zlast, const GenLds& L) {
+                                            float slope, const SpK& k, int g, f32x4& zlast, const GenLds& L, GenRing& R, const char* wbase) {
     f32x4 acc[NG * NTB];
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) acc[t] = *(const f32x4*)(bias + 16 * t + 4 * g);
@@ -197,7 +214,8 @@ __device__ __forceinline__ void gen_forward(const char* w, const float* bias, co
     // in every iteration, which drains the weight ring's look-ahead once per k step
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) asm volatile("" : "+v"(acc[t]));
-    gen_layer<NG>(w, xin, nk, acc, L);
+    (void)w;
+    gen_layer<NG>(R, wbase, xin, nk, acc, L);
     if (last) {                    // the output layer: one unit, row 0 of tile 0; its activation is the caller's
         zlast = acc[0];
         return;
@@ -215,11 +233,12 @@ __device__ __forceinline__ void gen_forward(const char* w, const float* bias, co
 // one backward layer: G_in = W^T G_out, times the derivative factors of the layer below (l > 0) or into the pose's feature row
 template <int NG>
 __device__ __forceinline__ void gen_backward(const char* w, const char* gin, f32x4* gout, const f32x4* dprev, float* my_f, int nk, int g, int t0,
-                                             const GenLds& L) {
+                                             const GenLds& L, GenRing& R, const char* wbase) {
+    (void)w;
     f32x4 acc[NG * NTB];
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gen_layer<NG>(w, gin, nk, acc, L);
+    gen_layer<NG>(R, wbase, gin, nk, acc, L);
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) {
         if (dprev) gout[(size_t)t * SLOT_F4] = acc[t] * dprev[(size_t)t * SLOT_F4];      // x act'(z_{l-1})
@@ -331,7 +350,10 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) xbuf[0][(size_t)t * SLOT_F4] = *(const f32x4*)(my_f + 16 * t + 4 * g);
 
-            // ---------------- trunk forward, layer by layer (net_modules.py:51-69)
+            // ---------------- trunk forward, layer by layer (net_modules.py:51-69); the weight ring starts here and runs to the end of the
+            // backward pass (forward-only calls leave it after the forward half: drained below)
+            GenRing wring;
+            gen_ring_start(wring, (const char*)args.wfwd, args.w_slots, gl);
             f32x4 zlast = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int l = 0; l < L; ++l) {
                 const int nk = args.kt[l], ng = args.ntp[l] / NTB;
@@ -342,7 +364,7 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                     const int n = (ng - g0 < GEN_PASS_GROUPS) ? ng - g0 : GEN_PASS_GROUPS, t0 = g0 * NTB;
                     const char* wp = w + (size_t)g0 * nk * NTB * TILE_BYTES;      // stream order: [pass][k tile][tile of the pass]
                     switch (n) {
-#define PNDF_GEN_FWD(N) case N: gen_forward<N, SP>(wp, bias + 16 * t0, xuni[l & 1], xbuf[(l + 1) & 1] + (size_t)t0 * SLOT_F4, dl + (size_t)t0 * SLOT_F4, nk, l == L - 1, args.slope, ap.k, g, zlast, gl); break;
+#define PNDF_GEN_FWD(N) case N: gen_forward<N, SP>(wp, bias + 16 * t0, xuni[l & 1], xbuf[(l + 1) & 1] + (size_t)t0 * SLOT_F4, dl + (size_t)t0 * SLOT_F4, nk, l == L - 1, args.slope, ap.k, g, zlast, gl, wring, (const char*)args.wfwd); break;
                         PNDF_GEN_GROUP_CASES(PNDF_GEN_FWD)
 #undef PNDF_GEN_FWD
                         default: break;      // (pndf_generic_create plans no other group count)
@@ -363,7 +385,10 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                     gz7 += poison;
                 }
             }
-            if (args.mode == MODE_FORWARD) break;
+            if (args.mode == MODE_FORWARD) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the ring's look-ahead into the backward half)
+                break;
+            }
             float gscale = gz7;
             if (args.mode == MODE_FORWARD_GRAD && args.grad_out) {
                 long long pidx = pose0 + wp;
@@ -383,7 +408,7 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                     const int n = (ng - g0 < GEN_PASS_GROUPS) ? ng - g0 : GEN_PASS_GROUPS, t0 = g0 * NTB;
                     const char* wp = w + (size_t)g0 * nk * NTB * TILE_BYTES;
                     switch (n) {
-#define PNDF_GEN_BWD(N) case N: gen_backward<N>(wp, xuni[cur], xbuf[cur ^ 1] + (size_t)t0 * SLOT_F4, dprev ? dprev + (size_t)t0 * SLOT_F4 : nullptr, my_f, nk, g, t0, gl); break;
+#define PNDF_GEN_BWD(N) case N: gen_backward<N>(wp, xuni[cur], xbuf[cur ^ 1] + (size_t)t0 * SLOT_F4, dprev ? dprev + (size_t)t0 * SLOT_F4 : nullptr, my_f, nk, g, t0, gl, wring, (const char*)args.wfwd); break;
                         PNDF_GEN_GROUP_CASES(PNDF_GEN_BWD)
 #undef PNDF_GEN_BWD
                         default: break;
@@ -391,6 +416,7 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                 }
                 cur ^= 1;
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the ring's re-reads of the stream's last slot
             __syncthreads();
 
             // ---------------- encoder backward + normalise backward + update (fp32, as the fused kernels)
@@ -538,6 +564,14 @@ int pndf_generic_create(PndfGeneric** out, const pndf_config& cfg, int resident_
     P.nlayers = L;
     P.noenc = g->enc ? 0 : 1;
     int wf = 0, wb = 0, bo = 0, slot = 2 * PNDF_GEN_XTILES;
+    for (int l = 0; l < L; ++l) wf += gen_round_tiles(ceil_div(cfg.dims[l + 1], 16)) * ceil_div((l == 0) ? 128 : cfg.dims[l], 16);
+    g->wf_tiles = wf;                 // the backward matrices follow the forward ones in ONE stream, in the order the backward pass walks them
+    wf = 0;
+    for (int l = L - 1; l >= 0; --l) {
+        P.wb_off[l] = (int)g->wf_tiles + wb;
+        wb += gen_round_tiles(ceil_div((l == 0) ? 128 : cfg.dims[l], 16)) * ceil_div(cfg.dims[l + 1], 16);
+    }
+    g->wb_tiles = wb;
     for (int l = 0; l < L; ++l) {
         const int in = (l == 0) ? 128 : cfg.dims[l];      // x0 is the pose's 128-row feature buffer (126 | 84 rows used, the rest zero)
         const int outw = cfg.dims[l + 1];
@@ -546,24 +580,21 @@ int pndf_generic_create(PndfGeneric** out, const pndf_config& cfg, int resident_
         P.ktp[l] = gen_round_tiles(P.kt[l]);
         P.ntp[l] = gen_round_tiles(P.nt[l]);
         P.wf_off[l] = wf;
-        P.wb_off[l] = wb;
         P.b_off[l] = bo;
         P.d_off[l] = slot;
         wf += P.ntp[l] * P.kt[l];
-        wb += P.ktp[l] * P.nt[l];
         bo += 16 * P.ntp[l];
         if (l < L - 1) slot += P.ntp[l];
     }
     P.enc_d_off = slot;
     if (gen_enc_act(cfg) == PNDF_ACT_SOFTPLUS && g->enc) slot += 2 * NJ;
     P.wg_tiles = slot;
-    g->wf_tiles = wf;
-    g->wb_tiles = wb;
+    P.w_slots = (int)((g->wf_tiles + g->wb_tiles) / GW_SLOT_TILES);      // (every pass is whole groups of NTB = 2 slots)
     g->lbias_floats = bo;
     hipError_t e = hipMalloc((void**)&g->d_bias, BIAS_FLOATS * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&g->d_enc, (size_t)2 * PNDF_GEN_ENC_SECTION_TILES * TILE_BYTES);
-    if (e == hipSuccess) e = hipMalloc((void**)&g->d_wf, g->wf_tiles * TILE_BYTES);
-    if (e == hipSuccess) e = hipMalloc((void**)&g->d_wb, g->wb_tiles * TILE_BYTES);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->d_wf, (g->wf_tiles + g->wb_tiles) * TILE_BYTES);
+    g->d_wb = nullptr;                // (one stream: the backward half lives behind the forward half in d_wf)
     if (e == hipSuccess) e = hipMalloc((void**)&g->d_lb, g->lbias_floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&g->d_scratch, (size_t)resident_wgs * P.wg_tiles * SLOT_F4 * sizeof(f32x4));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->done, hipEventDisableTiming);
@@ -620,7 +651,7 @@ int pndf_generic_load(PndfGeneric* g, const float* const* tensors, const int64_t
         for (int t0 = 0; t0 < P.ntp[l]; t0 += PT)
             for (int k = 0; k < P.kt[l]; ++k)
                 for (int t = t0; t < P.ntp[l] && t < t0 + PT; ++t, dst += TILE_FLOATS) pndf_pack::emit_tile(F, t, k, dst);
-        dst = wb.data() + (size_t)P.wb_off[l] * TILE_FLOATS;
+        dst = wb.data() + (size_t)(P.wb_off[l] - (int)g->wf_tiles) * TILE_FLOATS;
         for (int t0 = 0; t0 < P.ktp[l]; t0 += PT)
             for (int k = 0; k < P.nt[l]; ++k)
                 for (int t = t0; t < P.ktp[l] && t < t0 + PT; ++t, dst += TILE_FLOATS) pndf_pack::emit_tile(T, t, k, dst);
@@ -636,7 +667,7 @@ int pndf_generic_load(PndfGeneric* g, const float* const* tensors, const int64_t
     }
     hipError_t e = hipDeviceSynchronize();      // no launch may still be reading the old weights
     if (e == hipSuccess) e = hipMemcpy(g->d_wf, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(g->d_wb, wb.data(), wb.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->d_wf + g->wf_tiles * TILE_FLOATS, wb.data(), wb.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(g->d_lb, lb.data(), lb.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(g->d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(g->d_enc, enc.data(), enc.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -656,7 +687,7 @@ int pndf_generic_launch(PndfGeneric* g, int mode, const float* q, const float* g
     if (!g->have_weights) { err = "pndf_load_weights has not been called"; return PNDF_ERR_NO_WEIGHTS; }
     PndfGenericArgs a = g->plan;
     a.q_in = q; a.q_out = qo; a.d_out = d; a.grad_out = gout;
-    a.enc_stream = g->d_enc; a.bias = g->d_bias; a.wfwd = g->d_wf; a.wbwd = g->d_wb; a.lbias = g->d_lb; a.scratch = g->d_scratch;
+    a.enc_stream = g->d_enc; a.bias = g->d_bias; a.wfwd = g->d_wf; a.wbwd = g->d_wf; a.lbias = g->d_lb; a.scratch = g->d_scratch;
     a.B = B; a.steps = steps; a.mode = mode;
     a.slope = (g->cfg.act == PNDF_ACT_LRELU) ? 0.01f : 0.0f;      // nn.LeakyReLU() default slope, net_modules.py:31
     a.beta = g->cfg.beta;
