@@ -40,10 +40,11 @@ struct PndfGenericArgs {
     float* q_out;           // [B,84]
     float* d_out;           // [B]
     const float* grad_out;  // [B] or null
-    const char* enc_stream; // encoder forward section | backward section (PNDF_GEN_ENC_SECTION_TILES KiB each), null without encoder
+    const char* enc_stream; // the step's weight stream (1-KiB tiles): encoder forward (48) | trunk forward passes, then the transposed matrices in the
+                            // backward pass's order, padded to whole 16-tile slots | encoder backward (48), + a replica of its first slots
     const float* bias;      // BIAS_FLOATS block (the encoder's biases)
-    const float* wfwd;      // the step's weight stream: forward tiles of all layers, [pass][k tile][tile of the pass] per layer, then
-    const float* wbwd;      //   the transposed matrices in the backward pass's order (wf_off / wb_off index this ONE stream; wbwd == wfwd)
+    const float* wfwd;      // (unused: the trunk's tiles are part of enc_stream; wf_off / wb_off count tiles from its tile 48)
+    const float* wbwd;
     const float* lbias;     // biases, each layer padded to whole blocks of tiles
     float* scratch;         // gridDim.x * wg_tiles tile slots of 4 KiB: activations (ping, pong), derivative factors per layer
     long long B;
@@ -61,7 +62,7 @@ struct PndfGenericArgs {
     int d_off[PNDF_GEN_MAXLIN];  // first tile slot of the layer's derivative factors in the workgroup's scratch
     int enc_d_off;               // softplus: first tile slot of the encoder's 42 derivative tiles
     int wg_tiles;                // tile slots per workgroup
-    int w_slots;                 // 4-tile slots of the step's weight stream (forward half, then the backward half in its own order)
+    int w_slots;                 // 16-tile ring slots of the step's weight stream
 };
 constexpr int PNDF_GEN_ENC_SECTION_TILES = 48 + 4 * 16;      // the encoder's 3 slots + what the ring fetches ahead (4 slots)
 

@@ -24,7 +24,7 @@
     defined(PNDF_MFMA_ORDER) || defined(PNDF_BIG_CT) || defined(PNDF_SPLIT_FOUR) || defined(PNDF_SP_FORM) || defined(PNDF_SP_FORM_OUT) || \
     defined(PNDF_SP_FORM_ENC) || defined(PNDF_SP_FORM_TILES) || defined(PNDF_SP_FORM_CHUNK) || defined(PNDF_SP_NT) || defined(PNDF_EXP_LO_BITS) || \
     defined(PNDF_LBS_DIAG) || defined(PNDF_LBS_FLA) || defined(PNDF_LBS_RLA) || defined(PNDF_LBS_PAIR_READS) || defined(PNDF_STAGGER) || \
-    defined(PNDF_SP_WRAP)
+    defined(PNDF_SP_WRAP) || defined(PNDF_GEN_ABLATE)
 #error "an experiment macro is set without -DPNDF_EXPERIMENT=1: the product library takes no tuning / ablation macros (pndf_experiment.h)"
 #endif
 #endif
@@ -117,6 +117,10 @@
 #ifndef PNDF_SP_WRAP
 #define PNDF_SP_WRAP 0           // pndf_device.h: softplus derivative slots wrap after this many (same bytes, smaller footprint: does the
 #endif                           // scratch cost what it costs because 216 MB + the rest overflow the 256 MB Infinity Cache?), WRONG results
+#ifndef PNDF_GEN_ABLATE
+#define PNDF_GEN_ABLATE 0        // pndf_generic.hip, timing arms only (WRONG results): 1 = no activation / derivative / gradient stores in the
+#endif                           // layer epilogues, 2 = no derivative loads in the backward epilogues, 4 = no operand-tile DMA after a pass's
+                                 // first two, 8 = no bias loads, 16 = no activation arithmetic, 32 = no vmcnt(0) at a pass's start, 64 = no weight-tile reads, 128 = no ring events; 256 = plain instead of non-temporal epilogue stores (correct results)
 #ifndef PNDF_STAGGER
 #define PNDF_STAGGER 0           // pndf_kernel_split.hip: workgroups of XCD x start x * PNDF_STAGGER sleeps (~4 us each) late (round 6:
 #endif                           // does a chip whose XCDs are in different phases of a step sit closer to the power cap?)
@@ -130,7 +134,7 @@
      ((PNDF_BIG_CT) != 2 ? 1u << 11 : 0u) | ((PNDF_SPLIT_FOUR) != 0 ? 1u << 12 : 0u) |                                              \
      (((PNDF_SP_FORM) != 1 || (PNDF_SP_FORM_OUT) != 1 || (PNDF_SP_FORM_ENC) != 1 || (PNDF_SP_FORM_TILES) != 1 || (PNDF_SP_FORM_CHUNK) != 1) ? 1u << 13 : 0u) | \
      ((PNDF_SP_NT) != 0 ? 1u << 14 : 0u) | (PNDF_X_EXP_LO_BITS ? 1u << 15 : 0u) | ((PNDF_LBS_DIAG) != 0 ? 1u << 16 : 0u) |          \
-     (((PNDF_LBS_FLA) != 2 || (PNDF_LBS_RLA) != 1 || (PNDF_LBS_PAIR_READS) != 0) ? 1u << 17 : 0u) | ((PNDF_STAGGER) != 0 ? 1u << 18 : 0u) | ((PNDF_SP_WRAP) != 0 ? 1u << 19 : 0u) | ((PNDF_EXPERIMENT) != 0 ? 1u << 31 : 0u))
+     (((PNDF_LBS_FLA) != 2 || (PNDF_LBS_RLA) != 1 || (PNDF_LBS_PAIR_READS) != 0) ? 1u << 17 : 0u) | ((PNDF_STAGGER) != 0 ? 1u << 18 : 0u) | ((PNDF_SP_WRAP) != 0 ? 1u << 19 : 0u) | ((PNDF_GEN_ABLATE) != 0 ? 1u << 20 : 0u) | ((PNDF_EXPERIMENT) != 0 ? 1u << 31 : 0u))
 
 // `PNDF_EXPORT_EXPERIMENT_WORD(tag)` in a translation unit: its word as an exported constant of the shared library
 #define PNDF_EXPORT_EXPERIMENT_WORD_(tag)                                                                  \

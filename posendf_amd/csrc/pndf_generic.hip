@@ -50,142 +50,166 @@ constexpr int NTB = PNDF_GEN_NTB;
 constexpr int TILE_F4 = 64;              // f32x4 elements of a weight tile (one per lane)
 constexpr int SLOT_F4 = WG_THREADS;      // f32x4 elements of a scratch tile slot (one per thread of the workgroup)
 
-// ---- the trunk's weight ring: PRIVATE to each wave, fed by LDS-DMA
-// The rocprofv3 counters of the register-prefetch form (profiles/r06/generic/): 47.6 % MFMA busy, 47.7 % of the wave cycles at an
-// s_waitcnt, L2 hit rate 76 % -- 22 MB of fp32 weights per step do not fit 4 MB of L2, workgroups that wait drift apart, and with one
-// group (1,024 cycles) of look-ahead every miss is a stall.  Sharing a group among the four waves through LDS with a barrier per group
-// is slower still (0.41: the barrier hands every wave the slowest wave's miss).  What the fused kernels have is DISTANCE without
-// registers: global_load_lds_dwordx4 moves a tile global -> LDS with no destination register, so any number of slots can be in flight;
-// here every wave runs its own five-slot ring (4 tiles = 16 MFMAs per slot, fetched FOUR slots = 2,048 cycles ahead, counted vmcnt
-// waits, no barrier anywhere: the waves of a workgroup share nothing in the trunk), and the operand tile of the next k step comes the
-// same way.  The encoder's ring buffers (80 KiB) and the chunk-mask rows (unused here) are idle during the trunk.
-constexpr int GW_SLOT_TILES = 4;
-constexpr int GW_SLOT_BYTES = GW_SLOT_TILES * TILE_BYTES;          // 4 KiB
-constexpr int GW_RING = 5;
-constexpr int GW_AHEAD = GW_RING - 1;
-constexpr int GW_WAVE_BYTES = GW_RING * GW_SLOT_BYTES;             // 20 KiB per wave
-constexpr int GX_WAVE_BYTES = 2 * TILE_BYTES;                      // operand tile, double buffered
-static_assert(4 * GW_WAVE_BYTES <= RING_SLOTS * SLOT_BYTES, "four private rings live in the encoder's ring buffers");
+// ---- the trunk's weights come through the SAME ring as in the fused kernels (pndf_device.h: Ring)
+// One stream per step, in consumption order: encoder forward tiles (3 slots) | trunk forward passes, then the transposed matrices in
+// the backward pass's order | encoder backward tiles (3 slots), followed by a replica of its first slots so that the fetch pointer
+// never wraps inside a step.  Slots of 16 tiles, each wave DMAs a quarter of a slot, five buffers = a slot is fetched FOUR slots
+// ahead, the counted vmcnt wait + one barrier sit in the middle of the slot being consumed.  Because the four waves SHARE a slot, a
+// slot lasts 64 MFMAs per wave = 2,048 cycles and the look-ahead is 8,192 cycles for the ring's 80 KiB -- four times what a ring per
+// wave buys with the same LDS (v5 - v7 of this file: 0.60 - 0.68 of the fp32 MFMA peak, L2 hit rate 78 %, 17 % of the wave cycles
+// stalled: profiles/r06/generic_v7/), and the waves of a workgroup walk the stream in step, as the fused kernels' do.
+// History of this loop on configs/amass.yaml (fraction of the fp32 MFMA peak; the fused exact-fp32 kernel: 0.89):
+//   v1 0.22  one block of four output tiles per pass over the operand, weights and operand prefetched one k step through registers
+//   v2 0.45  the accumulators of a pass (32 tiles) resident: the operand is read once per pass
+//   v3 0.47  weight groups of eight tiles (1,024 cycles of look-ahead)         -> rocprofv3: 48 % of the wave cycles at a waitcnt, L2 hit 76 %
+//   v4 0.41  a group shared by the four waves through LDS, ONE group ahead, a barrier per group (every wave gets the slowest wave's miss)
+//   v5 0.60  a five-slot ring PRIVATE to each wave, fed by LDS-DMA four slots (2,048 cycles) ahead, no barrier in the trunk
+//   v6 0.68  the slot laid out by hand: DMA pieces and the next slot's tile reads between the rounds of MFMAs
+//   v7 0.68  one weight stream per step (no ring start-up per pass), operand read pipelined
+//   v8 0.65  the fused kernels' shared ring, the non-MFMA items in four blocks between rounds of eight MFMAs (two register sets, copies)
+//   v9 0.66  the shared ring, one item behind each MFMA, the next group's tiles read in ONE round straight into the registers they replace
+//   v10 0.46 two register sets again, reads and copies spread over the group: hipcc answers with 3.7 register moves per MFMA
+//   v11 0.66 MFMAs in tile pairs, every read straight into the registers its pair just released, spread evenly
+//   v12 0.74 nothing decided at run time inside a k step (see gen_layer)
+//   v13      this: the backward epilogue's derivative loads one group ahead of its stores (see gen_backward)
+// The operand tile of a k step is the wave's own (its 16 poses): it comes by DMA as well, three k steps deep, into three 1-KiB buffers
+// per wave in the chunk-mask rows (unused here), so that no compiler-visible vector-memory instruction sits in the k loop.
+constexpr int GX_BUFS = 3;
+constexpr int GX_WAVE_BYTES = GX_BUFS * TILE_BYTES;
 static_assert(4 * GX_WAVE_BYTES <= MASK_ROWS * WG_THREADS, "the operand buffers live in the chunk-mask rows");
-static_assert(NTB % GW_SLOT_TILES == 0, "a group of output tiles is whole slots");
+static_assert(NTB * 2 == SLOT_TILES, "a group of output tiles is half a ring slot: groups alternate between the two halves");
 
 struct GenLds {
-    uint32_t w_lds;        // uniform: LDS address of this wave's ring
-    uint32_t x_lds;        // uniform: LDS address of this wave's two operand tiles
-    const char* w_ptr;     // per lane: its 16 bytes of tile 0 of ring slot 0
+    uint32_t x_lds;        // uniform: LDS address of this wave's operand buffers
     const char* x_ptr;     // per lane: its 16 bytes of operand buffer 0
     uint32_t lane16;
 };
-
-// one ring slot (4 tiles): M0 = LDS destination, the instruction offset moves both addresses (pndf_device.h: ring_dma_piece)
-__device__ __forceinline__ void gw_dma_slot(const char* base, uint32_t voff, uint32_t dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %0, %1\n\t"
-                 "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
-                 "global_load_lds_dwordx4 %0, %1 offset:3072"
-                 : : "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
-}
-// the same slot piece by piece, one piece behind each round of four MFMAs (pieces 1 .. 3 rely on M0 as piece 0 left it: nothing
-// else in the trunk writes M0 between them -- the operand tile's DMA is issued at the top of a k step, outside a slot)
-template <int PIECE>
-__device__ __forceinline__ void gw_dma_piece(const char* base, uint32_t voff, uint32_t dst) {
-    if constexpr (PIECE == 0)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
-    else if constexpr (PIECE == 1)
-        asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" : : "v"(voff), "s"(base) : "memory");
-    else if constexpr (PIECE == 2)
-        asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" : : "v"(voff), "s"(base) : "memory");
-    else
-        asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" : : "v"(voff), "s"(base) : "memory");
-}
 __device__ __forceinline__ void gw_dma_tile(const char* base, uint32_t voff, uint32_t dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
 }
 
-// The weight stream of a step is ONE sequence of slots in consumption order -- forward passes layer by layer, then the transposed
-// matrices in the backward pass's order -- so the ring is started once per step and runs through every pass: a pass ends with the
-// first slots of the next one already in flight (with a ring per pass the 16 passes of a step each began on an empty ring).
-struct GenRing {
-    uint32_t fetch, last;        // per lane: byte offset of the next slot to fetch / of the stream's last slot (+ lane * 16)
-    uint32_t fbuf, rbuf;         // uniform: ring buffer the next fetch goes to / the next read comes from
-    f32x4 wt[2][GW_SLOT_TILES];  // the tiles of the current slot (set 0 at every pass boundary: a pass is an even number of slots)
+// the tiles of the group being multiplied
+struct GenW {
+    f32x4 wc[NTB];
 };
-__device__ __forceinline__ void gen_ring_start(GenRing& R, const char* wbase, int total_slots, const GenLds& L) {
-    R.last = (uint32_t)(total_slots - 1) * GW_SLOT_BYTES + L.lane16;      // (fetches past the end re-read the last slot: no branch)
-    R.fetch = L.lane16;
-    R.fbuf = 0;
+// the first group of the trunk (tile 0 of the slot behind the encoder's three)
+__device__ __forceinline__ void gen_trunk_begin(Ring& ring, GenW& W) {
+    ring_boundary(ring);
 #pragma unroll
-    for (int i = 0; i < GW_AHEAD; ++i) {
-        gw_dma_slot(wbase, R.fetch < R.last ? R.fetch : R.last, L.w_lds + R.fbuf);
-        R.fetch += GW_SLOT_BYTES;
-        R.fbuf += GW_SLOT_BYTES;
+    for (int j = 0; j < NTB; ++j) W.wc[j] = ring_tile(ring, j);
+}
+// the end of the trunk's stream.  The last group has already run the events of the group behind it, which is padding (`half` = the half of
+// its slot that one is): the second half of the last slot -- nothing left to do --, or the first half of a slot of padding, whose
+// mid-slot events still have to happen
+__device__ __forceinline__ void gen_trunk_end(Ring& ring, int half) {
+    if (half == 0) {
+        ring_midslot_sync(ring);
+        DmaSrc src;
+        uint32_t dst;
+        ring_dma_begin(ring, src, dst);
+        dst = __builtin_amdgcn_readfirstlane(dst);      // (see gen_layer)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ring_dma_piece(src, dst, j);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * (GW_AHEAD - 1)) : "memory");
-#pragma unroll
-    for (int j = 0; j < GW_SLOT_TILES; ++j) R.wt[0][j] = *(const f32x4*)(L.w_ptr + j * TILE_BYTES);
-    R.rbuf = GW_SLOT_BYTES;
 }
 
-// acc[t] += sum_k W(t, k) X[k] for `NG * NTB` output tiles (one pass over a layer) at once: the next nk * SPK slots of the ring.
-// `wbase` (uniform) = the stream's first tile; `xbase` (uniform) = this wave's 1 KiB of operand tile 0 (tiles 4 KiB apart).  Register
-// indices must be compile-time, so the number of groups is a template parameter: the plan rounds a layer's output tiles up to whole
-// groups (host side: gen_round_tiles) and the layer code is instantiated per group count of a pass.  (A first form kept 64
+// acc[t] += sum_k W(t, k) X[k] for `NG * NTB` output tiles (one pass over a layer) at once: the next nk * NG groups of the stream.
+// `xbase` (uniform) = this wave's 1 KiB of operand tile 0 (tiles 4 KiB apart); H0 = the half of its slot the pass's first group is.
+// Register indices must be compile-time, so the number of groups is a template parameter: the plan rounds a layer's output tiles up to
+// whole groups (host side: gen_round_tiles) and the layer code is instantiated per group count of a pass.  (A first form kept 64
 // accumulators under run-time guards `if (group < ng)`: hipcc answered with 700 spilled registers.)
-// The tiles of a slot are read from LDS one slot ahead of their MFMAs, into one of two register sets that alternate by slot parity
-// (no copies).  One wave per SIMD overlaps its own non-MFMA instructions with its own MFMAs only when they sit between them in
-// program order (DESIGN.md section 2 "epilogue in MFMA slots"), so a slot is laid out by hand and pinned:
-//   M M M M  P0 | M M M M  P1 | M M M M  P2 P3  wait(slot t + 1)  R R R R  [X] | M M M M
-// P = one 1-KiB piece of the fetch of slot t + 4, R = the four tile reads of slot t + 1, X (last slot of a k step) = the read of the
-// NEXT k step's operand tile: their latency hides behind the last round.
-// vmcnt bookkeeping (loads retire in order; other operations of the wave in the queue only make a counted wait stricter):
-//   slot t + 1 is read after DMA(t + 4) has been issued: three younger slots x 4 pieces -> vmcnt(12).  Operand tile k + 1 is issued
-//   at the top of k step k and read in its last slot: the SPK slots issued in between are younger -> vmcnt(min(4 SPK, 12)).  Operand
-//   tile 0 of a pass is the youngest operation when it is needed: vmcnt(0), once per pass (the ring's slots land meanwhile).
-template <int NG>
-__device__ __forceinline__ void gen_layer(GenRing& R, const char* wbase, const char* xbase, int nk, f32x4 (&acc)[NG * NTB], const GenLds& L) {
-    constexpr int SPK = NG * NTB / GW_SLOT_TILES;                  // slots per k step: even, so the two register sets alternate by si
-    static_assert(SPK % 2 == 0, "the tile registers of consecutive slots alternate by slot parity");
-    constexpr int XWAIT = 4 * SPK < 4 * (GW_AHEAD - 1) ? 4 * SPK : 4 * (GW_AHEAD - 1);
+// One wave per SIMD overlaps its own non-MFMA instructions with its own MFMAs only when they sit between them in program order, and
+// an fp32 MFMA covers 32 cycles: at most ONE memory item behind each MFMA.  A group = 32 MFMAs over its 8 tiles in PAIRS:
+// m = 8 pr + 2 s + h multiplies k sub-step s of tile 2 pr + h (two interleaved accumulator chains, as part B of the fused kernels), so
+// a tile's registers are dead after 8 MFMAs and the next group's tile is read straight into them -- no second register set, no copies,
+// and the eight reads of a group are spread evenly over it:
+//   m = 2              (last group of a k step) the NEXT k step's operand tile: counted wait + LDS read
+//   m = 4              the ring events of the NEXT group: slot boundary, or counted wait + barrier
+//   m = 8 pr + 6 + h   tile 2 pr + h of the next group -> wc[2 pr + h] (its last MFMA is this one; needed again 26 MFMAs later)
+//   m = 9, 11, 17, 19  one 1-KiB piece each of the slot fetch (groups whose successor is the second half of a slot)
+// NOTHING in a k step is decided at run time: which half of a slot a group is is a template parameter (H0, alternating; the pass
+// dispatcher tracks it), and every group has a successor in the stream -- the host pads the trunk's section so that the group behind the
+// last one is padding (pndf_generic_create).  With run-time flags for both (v11) there was a branch behind every third MFMA
+// (SQ_INSTS_BRANCH 4.9e8 against 1.77e9 MFMAs), and the reads, fetch pieces and epilogues that the fused kernels hide completely behind
+// their MFMAs cost 8 ms of a 34 ms launch.
+// Measured on the way here (profiles/r06/generic_ablate.txt; the bare MFMA loop of this kernel runs at 0.87 with the encoder): the four
+// waves of a workgroup run in step behind the ring's barrier, so what one wave does in a round all four do.
+//   v8  k-sub-step-major MFMAs, two register sets, the reads in two blocks and the 32 copies in one block between groups: 0.65
+//   v9  the eight reads of a group in its LAST round, each straight into the registers its MFMA just released: 32 KiB for the LDS in 256
+//       cycles -- exactly its bandwidth; the reads cost 7.5 % of the launch at the waits of the next round: 0.66
+//   v10 two register sets, a read behind every other MFMA of rounds 0 - 1, copies behind round 3: hipcc keeps one set in AGPRs and
+//       renames the accumulators (v_mfma with vDst != SrcC), 3.7 moves per MFMA (SQ_INSTS_VALU 9.0e9 against 2.3e9): 0.46
+// vmcnt bookkeeping (loads retire in order; other operations of the wave in the queue only make a counted wait stricter): the ring's own
+// wait is pndf_device.h's (at most two slot fetches of this wave in flight: vmcnt(8)).  Operand tile k + 1 is issued at the top of k step
+// k - 1 and read at m = 2 of the last group of k step k: operand tile k + 2 and the slot fetches of at least NG - 1 groups are younger
+// -> vmcnt(4 (NG - 1) + 1).  Operand tiles 0 and 1 of a pass are the youngest operations when they are needed: vmcnt(0), once per pass.
+template <int NG, int H0>
+__device__ __forceinline__ void gen_layer(Ring& ring, GenW& W, const char* xbase, int nk, f32x4 (&acc)[NG * NTB], const GenLds& L) {
+    constexpr int XWAIT = 4 * (NG - 1) + 1;
     gw_dma_tile(xbase, L.lane16, L.x_lds);
-    if (nk > 1) gw_dma_tile(xbase, SLOT_F4 * 16u + L.lane16, L.x_lds + TILE_BYTES);
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(0) : "memory");
+    gw_dma_tile(xbase, (uint32_t)(nk > 1 ? 1 : 0) * (SLOT_F4 * 16u) + L.lane16, L.x_lds + TILE_BYTES);
+    if (!(PNDF_GEN_ABLATE & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     f32x4 xc = *(const f32x4*)L.x_ptr, xn = xc;
-    for (int k = 0; k < nk; ++k) {
-        // operand tile k + 2 -> the buffer tile k was read from (k >= 1: at the end of k step k - 1; k = 0: just now)
-        if (k >= 1) gw_dma_tile(xbase, (uint32_t)((k + 1 < nk) ? k + 1 : k) * (SLOT_F4 * 16u) + L.lane16, L.x_lds + ((k + 1) & 1) * TILE_BYTES);
+    uint32_t xb = 0;                                               // operand buffer of k step k: k mod 3
+    // one k step: NG groups, the first one in half HS of its slot
+    auto kstep = [&](auto hs, int k) {
+        constexpr int HS = decltype(hs)::value;
+        const uint32_t xb1 = (xb == GX_BUFS - 1) ? 0u : xb + 1, xb2 = (xb1 == GX_BUFS - 1) ? 0u : xb1 + 1;
+        // operand tile k + 2 -> the buffer tile k - 1 was read from (during k step k - 2)
+        if (!(PNDF_GEN_ABLATE & 4)) gw_dma_tile(xbase, (uint32_t)((k + 2 < nk) ? k + 2 : nk - 1) * (SLOT_F4 * 16u) + L.lane16, L.x_lds + xb2 * TILE_BYTES);
 #pragma unroll
-        for (int si = 0; si < SPK; ++si) {
-            const f32x4 (&wc)[GW_SLOT_TILES] = R.wt[si & 1];
-            f32x4 (&wn)[GW_SLOT_TILES] = R.wt[(si + 1) & 1];
-            const uint32_t voff = R.fetch < R.last ? R.fetch : R.last;
-            const uint32_t dst = L.w_lds + R.fbuf;                 // the buffer slot t - 1 was read from, a slot ago
-            R.fetch += GW_SLOT_BYTES;
-            R.fbuf = (R.fbuf == (GW_RING - 1) * GW_SLOT_BYTES) ? 0u : R.fbuf + GW_SLOT_BYTES;
+        for (int gi = 0; gi < NG; ++gi) {
+            const int nh = ((HS + gi) & 1) ^ 1;                   // the half of its slot the NEXT group of the stream is
+            DmaSrc src{nullptr, 0u};
+            uint32_t dst = 0;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int m = 0; m < 4 * NTB; ++m) {
+                const int pr = m / 8, sI = (m % 8) / 2, j = 2 * pr + (m & 1);
+                acc[gi * NTB + j] = mfma4(W.wc[j][sI], xc[sI], acc[gi * NTB + j]);      // two interleaved chains per pair of tiles
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < GW_SLOT_TILES; ++j)
-                    acc[si * GW_SLOT_TILES + j] = mfma4(wc[j][s], xc[s], acc[si * GW_SLOT_TILES + j]);      // four independent chains
-                __builtin_amdgcn_sched_barrier(0);
-                if (s == 0) gw_dma_piece<0>(wbase, voff, dst);
-                if (s == 1) gw_dma_piece<1>(wbase, voff, dst);
-                if (s == 2) {
-                    gw_dma_piece<2>(wbase, voff, dst);
-                    gw_dma_piece<3>(wbase, voff, dst);
-                    if (si == SPK - 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XWAIT) : "memory");                 // slot t + 1 AND operand tile k + 1
-                    else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * (GW_AHEAD - 1)) : "memory");                 // slot t + 1 has landed
-#pragma unroll
-                    for (int j = 0; j < GW_SLOT_TILES; ++j) wn[j] = *(const f32x4*)(L.w_ptr + R.rbuf + j * TILE_BYTES);
-                    R.rbuf = (R.rbuf == (GW_RING - 1) * GW_SLOT_BYTES) ? 0u : R.rbuf + GW_SLOT_BYTES;
-                    if (si == SPK - 1) xn = *(const f32x4*)(L.x_ptr + ((k + 1) & 1) * TILE_BYTES);
+                if (m == 2 && gi == NG - 1) {
+                    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XWAIT) : "memory");
+                    xn = *(const f32x4*)(L.x_ptr + xb1 * TILE_BYTES);
                 }
+                if (m == 4 && !(PNDF_GEN_ABLATE & 128)) {
+                    if (nh == 0) ring_boundary(ring);
+                    else ring_midslot_sync(ring);
+                }
+                if (m % 8 >= 6 && !(PNDF_GEN_ABLATE & 64)) W.wc[j] = ring_tile(ring, nh * NTB + j);
+                if ((m == 9 || m == 11 || m == 17 || m == 19) && nh == 1) {
+                    // (under SGPR pressure hipcc keeps ring state in VGPR lanes and hands one to `s_mov_b32 m0`: readfirstlane is free
+                    // when the value is in an SGPR already)
+                    if (m == 9) {
+                        ring_dma_begin(ring, src, dst);
+                        dst = __builtin_amdgcn_readfirstlane(dst);
+                    }
+                    ring_dma_piece(src, dst, m == 9 ? 0 : m == 11 ? 1 : m == 17 ? 2 : 3);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         xc = xn;
+        xb = xb1;
+    };
+    if constexpr (NG % 2 == 0) {
+        for (int k = 0; k < nk; ++k) kstep(std::integral_constant<int, H0>{}, k);
+    } else {                      // an odd group count flips the half from one k step to the next: two k steps per iteration
+        int k = 0;
+        for (; k + 1 < nk; k += 2) {
+            kstep(std::integral_constant<int, H0>{}, k);
+            kstep(std::integral_constant<int, H0 ^ 1>{}, k + 1);
+        }
+        if (k < nk) kstep(std::integral_constant<int, H0>{}, k);
     }
     __builtin_amdgcn_sched_barrier(0);
+}
+
+// a tile store of an epilogue: non-temporal -- 2 MB per workgroup-step that nobody reads before 64 KiB .. 1 MB more have been written
+// (28.8 against 29.6 ms per launch with plain stores, arm 256 of PNDF_GEN_ABLATE: every counted vmcnt wait behind an epilogue waits
+// for its stores as well, gfx950 has one counter for loads and stores)
+__device__ __forceinline__ void gen_store(f32x4* p, const f32x4& v) {
+    if (PNDF_GEN_ABLATE & 256) *p = v;
+    else __builtin_nontemporal_store(v, p);
 }
 
 // hidden activation of one D tile (reference net_modules.py:30-41,64-65) and its derivative factor
@@ -204,47 +228,72 @@ __device__ __forceinline__ void gen_act(f32x4& z, f32x4& dfac, float slope, cons
 }
 
 // one forward layer with NG groups of output tiles: bias -> accumulate -> (hidden layers) activation, derivative factor
-template <int NG, bool SP>
-__device__ __forceinline__ void gen_forward(const char* w, const float* bias, const char* xin, f32x4* xout, f32x4* dl, int nk, bool last,
-                                            float slope, const SpK& k, int g, f32x4& zlast, const GenLds& L, GenRing& R, const char* wbase) {
+template <int NG, int H0, bool SP>
+__device__ __forceinline__ void gen_forward(Ring& ring, GenW& W, const float* bias, const char* xin, f32x4* xout, f32x4* dl, int nk, bool last,
+                                            float slope, const SpK& k, int g, f32x4& zlast, const GenLds& L) {
     f32x4 acc[NG * NTB];
 #pragma unroll
-    for (int t = 0; t < NG * NTB; ++t) acc[t] = *(const f32x4*)(bias + 16 * t + 4 * g);
+    for (int t = 0; t < NG * NTB; ++t) acc[t] = (PNDF_GEN_ABLATE & 8) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(bias + 16 * t + 4 * g);
     // the bias loads are consumed HERE: left pending, hipcc waits for them with `s_waitcnt vmcnt(0)` at the head of the k loop --
     // in every iteration, which drains the weight ring's look-ahead once per k step
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) asm volatile("" : "+v"(acc[t]));
-    (void)w;
-    gen_layer<NG>(R, wbase, xin, nk, acc, L);
+    gen_layer<NG, H0>(ring, W, xin, nk, acc, L);
     if (last) {                    // the output layer: one unit, row 0 of tile 0; its activation is the caller's
         zlast = acc[0];
         return;
     }
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) {
-        f32x4 df;
-        gen_act<SP>(acc[t], df, slope, k);
-        xout[(size_t)t * SLOT_F4] = acc[t];
-        dl[(size_t)t * SLOT_F4] = df;
+        f32x4 df = acc[t];
+        if (!(PNDF_GEN_ABLATE & 16)) gen_act<SP>(acc[t], df, slope, k);
+        if (!(PNDF_GEN_ABLATE & 1) || t == 0) {
+            gen_store(xout + (size_t)t * SLOT_F4, acc[t]);
+            gen_store(dl + (size_t)t * SLOT_F4, df);
+        } else {
+            asm volatile("" : : "v"(acc[t]), "v"(df));      // (the arm keeps the arithmetic)
+        }
         if (t % NTB == NTB - 1) __builtin_amdgcn_sched_barrier(0);      // a group at a time: the accumulators fill up to half the register file
     }
 }
 
 // one backward layer: G_in = W^T G_out, times the derivative factors of the layer below (l > 0) or into the pose's feature row
-template <int NG>
-__device__ __forceinline__ void gen_backward(const char* w, const char* gin, f32x4* gout, const f32x4* dprev, float* my_f, int nk, int g, int t0,
-                                             const GenLds& L, GenRing& R, const char* wbase) {
-    (void)w;
+template <int NG, int H0>
+__device__ __forceinline__ void gen_backward(Ring& ring, GenW& W, const char* gin, f32x4* gout, const f32x4* dprev, float* my_f, int nk, int g, int t0,
+                                             const GenLds& L) {
     f32x4 acc[NG * NTB];
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gen_layer<NG>(R, wbase, gin, nk, acc, L);
+    gen_layer<NG, H0>(ring, W, gin, nk, acc, L);
+    if (dprev) {
+        // x act'(z_{l-1}), a group of tiles at a time with the NEXT group's derivative factors already on their way: in program order
+        // L0 | L1 S0 | L2 S1 | ..., so the counted wait hipcc puts in front of a group's multiplies (vmcnt counts loads and stores alike,
+        // in order) never includes a store.  With load - multiply - store group after group, every group's loads queued behind the
+        // previous group's stores: 3 ms of a 30 ms launch (arms 1, 2 and 3 of PNDF_GEN_ABLATE, profiles/r06/generic_ablate.txt).
+        f32x4 dp[2][NTB];
 #pragma unroll
-    for (int t = 0; t < NG * NTB; ++t) {
-        if (dprev) gout[(size_t)t * SLOT_F4] = acc[t] * dprev[(size_t)t * SLOT_F4];      // x act'(z_{l-1})
-        else if (t0 + t < 8) *(f32x4*)(my_f + 16 * (t0 + t) + 4 * g) = acc[t];           // d z_out / d x0 (t0 = 0: one pass)
-        // (without it hipcc hoists all derivative loads above the first multiply: up to 256 more live registers)
-        if (t % NTB == NTB - 1) __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < NTB; ++j) dp[0][j] = (PNDF_GEN_ABLATE & 2) ? f32x4{1.f, 1.f, 1.f, 1.f} : dprev[(size_t)j * SLOT_F4];
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            if (gq + 1 < NG) {
+#pragma unroll
+                for (int j = 0; j < NTB; ++j)
+                    dp[(gq + 1) & 1][j] = (PNDF_GEN_ABLATE & 2) ? f32x4{1.f, 1.f, 1.f, 1.f} : dprev[(size_t)((gq + 1) * NTB + j) * SLOT_F4];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) {
+                const int t = gq * NTB + j;
+                const f32x4 go = acc[t] * dp[gq & 1][j];
+                if (!(PNDF_GEN_ABLATE & 1) || t == 0) gen_store(gout + (size_t)t * SLOT_F4, go);
+                else asm volatile("" : : "v"(go));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {                       // d z_out / d x0 into the pose's feature row (t0 = 0: one pass)
+#pragma unroll
+        for (int t = 0; t < NG * NTB; ++t)
+            if (t0 + t < 8) *(f32x4*)(my_f + 16 * (t0 + t) + 4 * g) = acc[t];
     }
 }
 
@@ -252,7 +301,7 @@ __device__ __forceinline__ void gen_backward(const char* w, const char* gin, f32
 // A pass keeps at most 4 groups = 32 tiles = 128 accumulator registers (a whole 1024-wide layer at once -- 256 -- left hipcc 150 - 220
 // spilled registers: everything that is not an MFMA accumulator has to fit the 256 architectural VGPRs); wider layers take two
 // passes, each of which reads the operand tiles once.
-#define PNDF_GEN_GROUP_CASES(X) X(1) X(2) X(3) X(4)
+#define PNDF_GEN_GROUP_CASES(X) X(1, 0) X(1, 1) X(2, 0) X(2, 1) X(3, 0) X(3, 1) X(4, 0) X(4, 1)
 constexpr int GEN_PASS_GROUPS = 4;
 
 // SP: the trunk's activation is Softplus (else relu / lrelu); ESP: the encoder's.  Every config of the reference has ESP == SP;
@@ -275,9 +324,7 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
     const char* const xwave = (const char*)((f32x4*)args.scratch + (size_t)blockIdx.x * args.wg_tiles * SLOT_F4) + wave * TILE_BYTES;
     const char* const xuni[2] = {xwave, xwave + (size_t)PNDF_GEN_XTILES * SLOT_F4 * 16};
     GenLds gl;
-    gl.w_lds = (uint32_t)(size_t)(PNDF_LDS char*)(smem + LDS_RING) + wave * GW_WAVE_BYTES;
     gl.x_lds = (uint32_t)(size_t)(PNDF_LDS char*)(smem + LDS_MASK) + wave * GX_WAVE_BYTES;
-    gl.w_ptr = smem + LDS_RING + wave * GW_WAVE_BYTES + lane * 16;
     gl.x_ptr = smem + LDS_MASK + wave * GX_WAVE_BYTES + lane * 16;
     gl.lane16 = (uint32_t)lane * 16u;
 
@@ -303,6 +350,7 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
     float* const my_gn = (float*)(smem + LDS_GN) + wp * FSTRIDE;   // aliases the feature row of the pose
 
     Ring ring;
+    ring.gstream = args.enc_stream;      // the step's stream: encoder forward | trunk | encoder backward (+ replica of its first slots)
     ring.smem = smem;
     ring.lane = lane;
     ring.st_wait = ring.st_bar = 0;
@@ -312,6 +360,7 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
     const long long nblocks = (args.B + WG_POSES - 1) / WG_POSES;
     for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
         const long long pose0 = blk * WG_POSES;
+        ring_start(ring, wave);      // slots 0..3 in flight; every block restarts the ring (the forward-only mode leaves it mid-stream)
         {
             long long nvalid = args.B - pose0;
             if (nvalid > WG_POSES) nvalid = WG_POSES;
@@ -322,53 +371,48 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                 ((f32x4*)lds_q)[i] = src[src_i];
             }
         }
+        ring_wait_dma();
         __syncthreads();
 
         const int nsteps = (args.mode == MODE_PROJECT) ? args.steps : 1;
         float dval = 0.f;
         for (int step = 0; step < nsteps; ++step) {
+            if (step) ring.fetch_off -= (uint32_t)args.w_slots * SLOT_BYTES;      // the fetch pointer has run one step's length (ring_next_step)
             // ---------------- encoder (or the normalised pose itself) -> x0, 128 rows in the pose's feature row
             uint32_t eb[6] = {0, 0, 0, 0, 0, 0};
             float poison = 0.f;
             if (args.noenc) {
                 poison = noenc_forward<SP>(my_q, my_f, g);
+                ring_skip_encoder_section(ring);
             } else {
                 if constexpr (SP && !ESP) {      // a Softplus trunk behind a relu-family encoder: the NaN / inf poison of the pose (joint_axis_norms)
                     float ss[4];
                     poison = joint_axis_norms<true>(my_q, ss);
                 }
-                // the encoder's tiles come through the weight ring like in the fused kernels: forward section of the stream
-                ring.gstream = args.enc_stream;
-                ring_start(ring, wave);
-                ring_wait_dma();
-                __syncthreads();
                 const float pe = encoder_forward<ESP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ape, g);
                 if constexpr (ESP) poison = pe;
-                ring_wait_dma();      // (the ring fetched ahead into the section's padding: drain before the next restart)
-                __syncthreads();      // ... by EVERY wave: the trunk's private weight rings reuse the ring's buffers
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) xbuf[0][(size_t)t * SLOT_F4] = *(const f32x4*)(my_f + 16 * t + 4 * g);
 
-            // ---------------- trunk forward, layer by layer (net_modules.py:51-69); the weight ring starts here and runs to the end of the
-            // backward pass (forward-only calls leave it after the forward half: drained below)
-            GenRing wring;
-            gen_ring_start(wring, (const char*)args.wfwd, args.w_slots, gl);
+            // ---------------- trunk forward, layer by layer (net_modules.py:51-69)
+            GenW wcur;
+            gen_trunk_begin(ring, wcur);
+            int half = 0;                  // which half of its slot the next group of the stream is (uniform)
             f32x4 zlast = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int l = 0; l < L; ++l) {
                 const int nk = args.kt[l], ng = args.ntp[l] / NTB;
-                const char* w = (const char*)args.wfwd + (size_t)args.wf_off[l] * TILE_BYTES;
                 const float* bias = args.lbias + args.b_off[l];
                 f32x4* dl = wg + (size_t)args.d_off[l] * SLOT_F4;
                 for (int g0 = 0; g0 < ng; g0 += GEN_PASS_GROUPS) {      // passes of at most 8 groups of output tiles
                     const int n = (ng - g0 < GEN_PASS_GROUPS) ? ng - g0 : GEN_PASS_GROUPS, t0 = g0 * NTB;
-                    const char* wp = w + (size_t)g0 * nk * NTB * TILE_BYTES;      // stream order: [pass][k tile][tile of the pass]
-                    switch (n) {
-#define PNDF_GEN_FWD(N) case N: gen_forward<N, SP>(wp, bias + 16 * t0, xuni[l & 1], xbuf[(l + 1) & 1] + (size_t)t0 * SLOT_F4, dl + (size_t)t0 * SLOT_F4, nk, l == L - 1, args.slope, ap.k, g, zlast, gl, wring, (const char*)args.wfwd); break;
+                    switch (2 * n + half) {      // (stream order: [pass][k tile][tile of the pass])
+#define PNDF_GEN_FWD(N, H) case 2 * N + H: gen_forward<N, H, SP>(ring, wcur, bias + 16 * t0, xuni[l & 1], xbuf[(l + 1) & 1] + (size_t)t0 * SLOT_F4, dl + (size_t)t0 * SLOT_F4, nk, l == L - 1, args.slope, ap.k, g, zlast, gl); break;
                         PNDF_GEN_GROUP_CASES(PNDF_GEN_FWD)
 #undef PNDF_GEN_FWD
                         default: break;      // (pndf_generic_create plans no other group count)
                     }
+                    half ^= (n * nk) & 1;
                 }
             }
             // row 0 of the output tile lives in register 0 of lane group 0: every lane of the pose reads it from there
@@ -385,10 +429,7 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                     gz7 += poison;
                 }
             }
-            if (args.mode == MODE_FORWARD) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the ring's look-ahead into the backward half)
-                break;
-            }
+            if (args.mode == MODE_FORWARD) break;      // (the ring stays mid-stream: drained at the end of the block)
             float gscale = gz7;
             if (args.mode == MODE_FORWARD_GRAD && args.grad_out) {
                 long long pidx = pose0 + wp;
@@ -402,32 +443,25 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
             xbuf[0][0] = (g == 0) ? f32x4{1.f, 0.f, 0.f, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
             for (int l = L - 1; l >= 0; --l) {
                 const int nk = args.nt[l], ng = args.ktp[l] / NTB;
-                const char* w = (const char*)args.wbwd + (size_t)args.wb_off[l] * TILE_BYTES;
                 const f32x4* dprev = (l > 0) ? wg + (size_t)args.d_off[l - 1] * SLOT_F4 : nullptr;
                 for (int g0 = 0; g0 < ng; g0 += GEN_PASS_GROUPS) {
                     const int n = (ng - g0 < GEN_PASS_GROUPS) ? ng - g0 : GEN_PASS_GROUPS, t0 = g0 * NTB;
-                    const char* wp = w + (size_t)g0 * nk * NTB * TILE_BYTES;
-                    switch (n) {
-#define PNDF_GEN_BWD(N) case N: gen_backward<N>(wp, xuni[cur], xbuf[cur ^ 1] + (size_t)t0 * SLOT_F4, dprev ? dprev + (size_t)t0 * SLOT_F4 : nullptr, my_f, nk, g, t0, gl, wring, (const char*)args.wfwd); break;
+                    switch (2 * n + half) {
+#define PNDF_GEN_BWD(N, H) case 2 * N + H: gen_backward<N, H>(ring, wcur, xuni[cur], xbuf[cur ^ 1] + (size_t)t0 * SLOT_F4, dprev ? dprev + (size_t)t0 * SLOT_F4 : nullptr, my_f, nk, g, t0, gl); break;
                         PNDF_GEN_GROUP_CASES(PNDF_GEN_BWD)
 #undef PNDF_GEN_BWD
                         default: break;
                     }
+                    half ^= (n * nk) & 1;
                 }
                 cur ^= 1;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the ring's re-reads of the stream's last slot
+            gen_trunk_end(ring, half);
             __syncthreads();
 
             // ---------------- encoder backward + normalise backward + update (fp32, as the fused kernels)
-            if (!args.noenc) {
-                ring.gstream = args.enc_stream + (size_t)PNDF_GEN_ENC_SECTION_TILES * TILE_BYTES;
-                ring_start(ring, wave);
-                ring_wait_dma();
-                __syncthreads();
-                encoder_backward<ESP>(my_f, my_gn, eb, ring, ape, g);
-                ring_wait_dma();
-            }
+            if (args.noenc) ring_skip_encoder_section(ring);
+            else encoder_backward<ESP>(my_f, my_gn, eb, ring, ape, g);
             {
                 float ss[4], dot[4], denom[4], kk[4];
                 ss[0] = ss[1] = ss[2] = ss[3] = 0.f;
@@ -507,6 +541,7 @@ struct PndfGeneric {
     int resident = 0;
     PndfGenericArgs plan;            // tile counts and offsets (pointers filled per launch)
     size_t wf_tiles = 0, wb_tiles = 0, lbias_floats = 0;
+    int trunk_tiles = 0;             // wf_tiles + wb_tiles rounded up to whole ring slots
     char* d_enc = nullptr;
     float *d_bias = nullptr, *d_wf = nullptr, *d_wb = nullptr, *d_lb = nullptr, *d_scratch = nullptr;
     bool have_weights = false;
@@ -532,6 +567,8 @@ bool pndf_generic_needed(const pndf_config& cfg) {
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up_int(int a, int b) { return ceil_div(a, b) * b; }
+constexpr int GEN_STREAM_PAD_SLOTS = 5;      // >= RING_SLOTS - 1: the replica of the stream's first slots behind it (the ring never wraps)
 static inline int gen_enc_act(const pndf_config& cfg) { return cfg.enc_act == -1 ? cfg.act : cfg.enc_act; }
 static inline float gen_enc_beta(const pndf_config& cfg) { return cfg.enc_beta > 0.f ? cfg.enc_beta : cfg.beta; }
 typedef void (*gen_kernel_t)(PndfGenericArgs);
@@ -589,12 +626,15 @@ int pndf_generic_create(PndfGeneric** out, const pndf_config& cfg, int resident_
     P.enc_d_off = slot;
     if (gen_enc_act(cfg) == PNDF_ACT_SOFTPLUS && g->enc) slot += 2 * NJ;
     P.wg_tiles = slot;
-    P.w_slots = (int)((g->wf_tiles + g->wb_tiles) / GW_SLOT_TILES);      // (every pass is whole groups of NTB = 2 slots)
+    // the step's stream: encoder forward (3 slots) | trunk (whole groups of NTB tiles, padded to whole slots) | encoder backward (3 slots)
+    // Every group of the trunk runs the ring events and the tile reads of the group BEHIND it (gen_layer has no "last group" case), so
+    // the last one needs padding behind it: the other half of its slot, or -- when the trunk fills its last slot -- a slot of its own.
+    g->trunk_tiles = round_up_int((int)(g->wf_tiles + g->wb_tiles) + NTB, SLOT_TILES);
+    P.w_slots = (2 * ENC_TILES_PADDED + g->trunk_tiles) / SLOT_TILES;
     g->lbias_floats = bo;
     hipError_t e = hipMalloc((void**)&g->d_bias, BIAS_FLOATS * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&g->d_enc, (size_t)2 * PNDF_GEN_ENC_SECTION_TILES * TILE_BYTES);
-    if (e == hipSuccess) e = hipMalloc((void**)&g->d_wf, (g->wf_tiles + g->wb_tiles) * TILE_BYTES);
-    g->d_wb = nullptr;                // (one stream: the backward half lives behind the forward half in d_wf)
+    if (e == hipSuccess) e = hipMalloc((void**)&g->d_enc, (size_t)(P.w_slots + GEN_STREAM_PAD_SLOTS) * SLOT_TILES * TILE_BYTES);
+    g->d_wf = g->d_wb = nullptr;      // (one stream: encoder and trunk tiles live in d_enc)
     if (e == hipSuccess) e = hipMalloc((void**)&g->d_lb, g->lbias_floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&g->d_scratch, (size_t)resident_wgs * P.wg_tiles * SLOT_F4 * sizeof(f32x4));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->done, hipEventDisableTiming);
@@ -641,17 +681,18 @@ int pndf_generic_load(PndfGeneric* g, const float* const* tensors, const int64_t
         }
     }
     const PndfGenericArgs& P = g->plan;
-    std::vector<float> wf(g->wf_tiles * TILE_FLOATS), wb(g->wb_tiles * TILE_FLOATS), lb(g->lbias_floats, 0.f), bias(BIAS_FLOATS, 0.f),
-        enc((size_t)2 * PNDF_GEN_ENC_SECTION_TILES * TILE_FLOATS, 0.f);
+    const size_t step_tiles = (size_t)P.w_slots * SLOT_TILES;
+    std::vector<float> stream((step_tiles + (size_t)GEN_STREAM_PAD_SLOTS * SLOT_TILES) * TILE_FLOATS, 0.f), lb(g->lbias_floats, 0.f), bias(BIAS_FLOATS, 0.f);
+    float* const trunk = stream.data() + (size_t)ENC_TILES_PADDED * TILE_FLOATS;      // wf_off / wb_off count tiles from here
     for (int l = 0; l < L; ++l) {
         const int in = g->cfg.dims[l], outw = g->cfg.dims[l + 1];
         const pndf_pack::Mat F{lin[2 * l], outw, in, false}, T{lin[2 * l], outw, in, true};
-        float* dst = wf.data() + (size_t)P.wf_off[l] * TILE_FLOATS;
+        float* dst = trunk + (size_t)P.wf_off[l] * TILE_FLOATS;
         const int PT = GEN_PASS_GROUPS * NTB;                  // consumption order: [pass of <= 32 output tiles][k tile][tile of the pass]
         for (int t0 = 0; t0 < P.ntp[l]; t0 += PT)
             for (int k = 0; k < P.kt[l]; ++k)
                 for (int t = t0; t < P.ntp[l] && t < t0 + PT; ++t, dst += TILE_FLOATS) pndf_pack::emit_tile(F, t, k, dst);
-        dst = wb.data() + (size_t)(P.wb_off[l] - (int)g->wf_tiles) * TILE_FLOATS;
+        dst = trunk + (size_t)P.wb_off[l] * TILE_FLOATS;
         for (int t0 = 0; t0 < P.ktp[l]; t0 += PT)
             for (int k = 0; k < P.nt[l]; ++k)
                 for (int t = t0; t < P.ktp[l] && t < t0 + PT; ++t, dst += TILE_FLOATS) pndf_pack::emit_tile(T, t, k, dst);
@@ -663,14 +704,14 @@ int pndf_generic_load(PndfGeneric* g, const float* const* tensors, const int64_t
             memcpy(bias.data() + ENCB_OFF + 32 * j, tensors[4 * j + 1], sizeof(float) * HID);
             memcpy(bias.data() + ENCB_OFF + 32 * j + 16 + ENC_FEAT_ROW, tensors[4 * j + 3], sizeof(float) * FEAT);
         }
-        pndf_pack::emit_encoder_sections(tensors, enc.data(), enc.data() + (size_t)PNDF_GEN_ENC_SECTION_TILES * TILE_FLOATS);
+        pndf_pack::emit_encoder_sections(tensors, stream.data(), stream.data() + ((size_t)ENC_TILES_PADDED + g->trunk_tiles) * TILE_FLOATS);
     }
+    // replica of the first slots behind the stream: the ring's fetch offset never wraps inside a step
+    memcpy(stream.data() + step_tiles * TILE_FLOATS, stream.data(), (size_t)GEN_STREAM_PAD_SLOTS * SLOT_TILES * TILE_FLOATS * sizeof(float));
     hipError_t e = hipDeviceSynchronize();      // no launch may still be reading the old weights
-    if (e == hipSuccess) e = hipMemcpy(g->d_wf, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(g->d_wf + g->wf_tiles * TILE_FLOATS, wb.data(), wb.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(g->d_lb, lb.data(), lb.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(g->d_bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(g->d_enc, enc.data(), enc.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g->d_enc, stream.data(), stream.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) { err = std::string("pndf_load_weights (runtime-planned DFNet): ") + hipGetErrorString(e); return PNDF_ERR_HIP; }
     g->have_weights = true;
     return PNDF_OK;
@@ -687,7 +728,7 @@ int pndf_generic_launch(PndfGeneric* g, int mode, const float* q, const float* g
     if (!g->have_weights) { err = "pndf_load_weights has not been called"; return PNDF_ERR_NO_WEIGHTS; }
     PndfGenericArgs a = g->plan;
     a.q_in = q; a.q_out = qo; a.d_out = d; a.grad_out = gout;
-    a.enc_stream = g->d_enc; a.bias = g->d_bias; a.wfwd = g->d_wf; a.wbwd = g->d_wf; a.lbias = g->d_lb; a.scratch = g->d_scratch;
+    a.enc_stream = g->d_enc; a.bias = g->d_bias; a.wfwd = nullptr; a.wbwd = nullptr; a.lbias = g->d_lb; a.scratch = g->d_scratch;
     a.B = B; a.steps = steps; a.mode = mode;
     a.slope = (g->cfg.act == PNDF_ACT_LRELU) ? 0.01f : 0.0f;      // nn.LeakyReLU() default slope, net_modules.py:31
     a.beta = g->cfg.beta;
