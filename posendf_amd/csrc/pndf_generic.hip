@@ -19,19 +19,14 @@
 //     Infinity Cache;
 //     the first form of this kernel (one block of four output tiles per pass: the operand re-read once per block, prefetched
 //     16 MFMAs ahead) ran at 0.22 of the fp32 MFMA peak, waiting for those loads (profiles/r06/generic_arch_v1.jsonl);
-//   * weights: fp32 tiles `tile(M, nt, kt)` in consumption order [pass][k tile][tile of the pass], streamed global -> LDS by DMA into a
-//     five-slot ring PRIVATE to each wave, four slots (2,048 cycles of matrix pipe) ahead, counted vmcnt waits, no barrier in the trunk
-//     (see "the trunk's weight ring" below for the forms that were measured before it).
+//   * weights: fp32 tiles `tile(M, nt, kt)` in consumption order [pass][k tile][tile of the pass], ONE stream per step (encoder forward |
+//     trunk forward | trunk backward | encoder backward) through the same five-slot LDS-DMA ring as the fused kernels (pndf_device.h:
+//     slots of 16 tiles shared by the four waves, fetched four slots = 8,192 cycles of matrix pipe ahead, counted vmcnt wait + one
+//     barrier in the middle of a slot); see "the trunk's weight ring" and gen_layer below for the forms that were measured before it.
 // Roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic work per pose-step 4 x sum_l in_l out_l FLOP.  Not the benchmark path
 // (BASELINE.json names amass.yaml).  Measured (tools/bench_generic.py, B = 65,536 x 10 steps, profiles/r06/generic_arch*.jsonl), as a
-// fraction of the fp32 MFMA peak on configs/amass.yaml itself (PNDF_FORCE_GENERIC=1; the fused exact-fp32 kernel: 0.89):
-//   v1 0.22  one block of four output tiles per pass over the operand, weights and operand prefetched one k step through registers
-//   v2 0.45  the accumulators of a pass (32 tiles) resident: the operand is read once per pass
-//   v3 0.47  weight groups of eight tiles (1,024 cycles of look-ahead)         -> rocprofv3: 48 % of the wave cycles at a waitcnt, L2 hit 76 %
-//   v4 0.41  a group shared by the four waves through LDS, one barrier per group (the barrier hands every wave the slowest wave's miss)
-//   v5 0.60  a five-slot weight ring PRIVATE to each wave, fed by LDS-DMA four slots ahead, no barrier in the trunk
-//   v6 0.68  the slot laid out by hand: DMA pieces and the next slot's tile reads between the rounds of MFMAs (this file; 0.72 on a
-//            wider network, 0.63 with Softplus)
+// fraction of the fp32 MFMA peak: 0.78 on configs/amass.yaml itself (PNDF_FORCE_GENERIC=1; the fused exact-fp32 kernel: 0.89), 0.72
+// with Softplus, 0.82 on 512-1024-1024-640-256-128; where the rest goes: profiles/r06/generic_ablate.txt.
 #include "pndf_device.h"
 
 #include <stdlib.h>
@@ -56,8 +51,8 @@ constexpr int SLOT_F4 = WG_THREADS;      // f32x4 elements of a scratch tile slo
 // never wraps inside a step.  Slots of 16 tiles, each wave DMAs a quarter of a slot, five buffers = a slot is fetched FOUR slots
 // ahead, the counted vmcnt wait + one barrier sit in the middle of the slot being consumed.  Because the four waves SHARE a slot, a
 // slot lasts 64 MFMAs per wave = 2,048 cycles and the look-ahead is 8,192 cycles for the ring's 80 KiB -- four times what a ring per
-// wave buys with the same LDS (v5 - v7 of this file: 0.60 - 0.68 of the fp32 MFMA peak, L2 hit rate 78 %, 17 % of the wave cycles
-// stalled: profiles/r06/generic_v7/), and the waves of a workgroup walk the stream in step, as the fused kernels' do.
+// wave buys with the same LDS (v5 - v7 of this file: L2 hit rate 78 %, 17 % of the wave cycles stalled: profiles/r06/generic_v7/), and
+// the waves of a workgroup walk the stream in step, as the fused kernels' do.
 // History of this loop on configs/amass.yaml (fraction of the fp32 MFMA peak; the fused exact-fp32 kernel: 0.89):
 //   v1 0.22  one block of four output tiles per pass over the operand, weights and operand prefetched one k step through registers
 //   v2 0.45  the accumulators of a pass (32 tiles) resident: the operand is read once per pass
@@ -71,7 +66,7 @@ constexpr int SLOT_F4 = WG_THREADS;      // f32x4 elements of a scratch tile slo
 //   v10 0.46 two register sets again, reads and copies spread over the group: hipcc answers with 3.7 register moves per MFMA
 //   v11 0.66 MFMAs in tile pairs, every read straight into the registers its pair just released, spread evenly
 //   v12 0.74 nothing decided at run time inside a k step (see gen_layer)
-//   v13      this: the backward epilogue's derivative loads one group ahead of its stores (see gen_backward)
+//   v13 0.78 this: the backward epilogue's derivative loads one group ahead of its stores (gen_backward), non-temporal stores (gen_store)
 // The operand tile of a k step is the wave's own (its 16 poses): it comes by DMA as well, three k steps deep, into three 1-KiB buffers
 // per wave in the chunk-mask rows (unused here), so that no compiler-visible vector-memory instruction sits in the k loop.
 constexpr int GX_BUFS = 3;
