@@ -213,7 +213,11 @@ def test_what_the_engine_still_refuses():
 # width / depth extremes that no fixture of the reference covers: the oracle -- pinned at 1, 3, 4, 6 and 7 hidden layers above -- is the checker
 EXTREMES = [([1], "lrelu", True), ([16], "relu", True), ([17], "softplus", True), ([1024], "lrelu", True), ([1, 1], "lrelu", True),
             ([15, 17, 33], "softplus", True), ([1024, 1024], "relu", True), ([64] * 7, "lrelu", True), ([1000, 3, 900], "lrelu", True),
-            ([7, 1024, 5, 1024, 3, 1024, 9], "softplus", False), ([512, 513], "lrelu", False), ([256, 512, 1024, 512, 256, 64, 32], "relu", True)]
+            ([7, 1024, 5, 1024, 3, 1024, 9], "softplus", False), ([512, 513], "lrelu", False), ([256, 512, 1024, 512, 256, 64, 32], "relu", True),
+            # three groups per pass (the k steps of such a pass alternate between the halves of a ring slot), passes of 4 + 1 and 4 + 3
+            # groups, an even and an odd number of groups in the whole stream (a slot of padding or half a slot behind the trunk)
+            ([384], "lrelu", True), ([384, 384], "softplus", True), ([640, 896], "relu", True), ([130, 384, 48], "lrelu", False),
+            ([128], "relu", False), ([128, 128], "lrelu", True)]
 
 
 def live_weights(dims, act):
