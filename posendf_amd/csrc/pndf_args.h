@@ -63,6 +63,10 @@ struct PndfGenericArgs {
     int enc_d_off;               // softplus: first tile slot of the encoder's 42 derivative tiles
     int wg_tiles;                // tile slots per workgroup
     int w_slots;                 // 16-tile ring slots of the step's weight stream
+    // split-precision trunk (precision f16x3): k blocks of 32 = two operand tiles, weight pairs (hi tile, lo tile), exact scales
+    int kb[PNDF_GEN_MAXLIN];     // contraction blocks of the forward pass = ceil(kt / 2)
+    int nb[PNDF_GEN_MAXLIN];     // contraction blocks of the backward pass = ceil(nt / 2)
+    float w_inv[PNDF_GEN_MAXLIN];// 1 / s_l: the stream carries s_l W, s_l = the power of two with max |W_l| s_l in [2^12, 2^13)
 };
 constexpr int PNDF_GEN_ENC_SECTION_TILES = 48 + 4 * 16;      // the encoder's 3 slots + what the ring fetches ahead (4 slots)
 

@@ -292,6 +292,229 @@ __device__ __forceinline__ void gen_backward(Ring& ring, GenW& W, const char* gi
     }
 }
 
+// ------------------------------------------------------------------ the same trunk on split-precision fp16 MFMAs (precision f16x3)
+// Every fp32 operand travels as fp16 hi + fp16 lo and a product block is three v_mfma_f32_16x16x32_f16 (hi hi + lo hi + hi lo, fp32
+// accumulate; the dropped lo lo term is 2^-22 relative) -- pndf_kernel_split.hip's arithmetic, with the layer-by-layer structure of this
+// file.  One MFMA contracts 32 k = TWO operand tiles, whose registers -- scaled, converted and packed -- are the B operand as they stand
+// (pndf_layout.h "split-precision stream": block(M, nt, kb)); a weight block is a PAIR of 1-KiB tiles (hi, lo), a group = 8 output tiles
+// x one k block = 8 pairs = ONE ring slot = 24 MFMAs, so every group runs the same ring events (no slot parity here).
+// Operand scaling (exact: every factor is a power of two), simpler than the fused kernels' because a layer is complete before the
+// next one starts: the stream carries s_l W (s_l: the largest |weight| of the layer in [2^12, 2^13), chosen by the packer), and every
+// pose scales the operand tensor of a layer by its own sigma(p) with max_i |x_i(p)| sigma in [2^13, 2^14) -- the bound is MEASURED for
+// every layer (running maximum over the epilogues of the producing layer + two cross-lane steps); the hi halves cannot overflow for
+// any finite weights and poses, and the lo half of every value down to 2^-10 of the pose's largest stays a NORMAL fp16.  The fp32
+// accumulators hold s_l sigma x the true value (they start from b s_l sigma); one multiply per value in the epilogue (`to_true`)
+// brings it back, and the scratch holds TRUE fp32 values exactly as on the fp32 path.
+typedef _Float16 gf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
+struct GBlk {          // one k block (32 k) of the operand as B operand
+    gf16x8 h, l;
+};
+struct GenWS {         // the eight weight pairs of the group being multiplied (tiles 2 j = hi, 2 j + 1 = lo of its slot)
+    gf16x8 h[NTB], l[NTB];
+};
+__device__ __forceinline__ f32x4 gmf16(gf16x8 a, gf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// (a, b) -> packed fp16 pairs: hi = rtz (one v_cvt_pkrtz), lo = rne(a - hi_a, b - hi_b) -- the remainders are exact in fp32, and a lo
+// half rounded to NEAREST keeps the residual unbiased (pndf_kernel_split.hip split2: the same three instructions)
+__device__ __forceinline__ void gsplit2(float a, float b, unsigned& hi, unsigned& lo) {
+    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+    hi = hp;
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(l) : "v"(hp), "v"(a), "v"(b));
+    lo = l;
+}
+// two fp32 C/D tiles (already scaled) -> the B operand of the k block they form
+__device__ __forceinline__ void gpack_blk(const f32x4& t0, const f32x4& t1, GBlk& o) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    gsplit2(t0[0], t0[1], h0, l0);
+    gsplit2(t0[2], t0[3], h1, l1);
+    gsplit2(t1[0], t1[1], h2, l2);
+    gsplit2(t1[2], t1[3], h3, l3);
+    o.h = __builtin_bit_cast(gf16x8, gu32x4{h0, h1, h2, h3});
+    o.l = __builtin_bit_cast(gf16x8, gu32x4{l0, l1, l2, l3});
+}
+// |x| <= bound -> the power of two sigma with bound sigma in [2^13, 2^14), clamped to 2^-40 .. 2^40 (pndf_kernel_split.hip pose_scale)
+__device__ __forceinline__ float gen_pose_scale(float bound) {
+    uint32_t e = (__builtin_bit_cast(uint32_t, bound) >> 23) & 0xffu;
+    e = e < 100u ? 100u : (e > 180u ? 180u : e);
+    return __builtin_bit_cast(float, (267u - e) << 23);
+}
+__device__ __forceinline__ float gen_pow2_rcp(float p) { return __builtin_bit_cast(float, 0x7F000000u - __builtin_bit_cast(uint32_t, p)); }
+// a pose's rows live in the four lane groups (lane = 16 g + p): maximum over them
+__device__ __forceinline__ float gen_pose_max(float m) {
+    m = fmaxf(m, __shfl_xor(m, 16));
+    return fmaxf(m, __shfl_xor(m, 32));
+}
+__device__ __forceinline__ float gen_absmax4(float m, const f32x4& v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+
+// the operand buffers of the split path: three k blocks of 2 KiB per wave, in the wave's OWN feature rows (LDS_F: free between the copy
+// of x0 into the scratch and the last backward epilogue, which writes them when the wave's k loop is over)
+constexpr int GXS_BLK_BYTES = 2 * TILE_BYTES;
+static_assert(GX_BUFS * GXS_BLK_BYTES <= 16 * FSTRIDE * 4, "the split path's operand buffers fit the wave's feature rows");
+static_assert((16 * FSTRIDE * 4) % 16 == 0, "16-byte aligned per wave");
+
+__device__ __forceinline__ void gen_trunk_begin_split(Ring& ring, GenWS& W) {
+    ring_boundary(ring);
+#pragma unroll
+    for (int j = 0; j < NTB / 2; ++j) {
+        W.h[j] = __builtin_bit_cast(gf16x8, ring_tile(ring, 2 * j));
+        W.l[j] = __builtin_bit_cast(gf16x8, ring_tile(ring, 2 * j + 1));
+    }
+    ring_midslot_sync(ring);
+    {
+        DmaSrc src;
+        uint32_t dst;
+        ring_dma_begin(ring, src, dst);
+        dst = __builtin_amdgcn_readfirstlane(dst);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ring_dma_piece(src, dst, j);
+    }
+#pragma unroll
+    for (int j = NTB / 2; j < NTB; ++j) {
+        W.h[j] = __builtin_bit_cast(gf16x8, ring_tile(ring, 2 * j));
+        W.l[j] = __builtin_bit_cast(gf16x8, ring_tile(ring, 2 * j + 1));
+    }
+}
+
+// acc[t] += sum_kb W(t, kb) X[kb] for NG * NTB output tiles: the next nkb * NG slots of the stream.  `sigma` = this lane's pose's scale
+// of the operand tensor.  A group = 24 MFMAs, m = 6 pr + 2 term + h over the tile pairs pr = 0 .. 3 (two interleaved accumulator
+// chains; term 0: Wh Xh, 1: Wl Xh, 2: Wh Xl), and the NEXT slot's tiles are read straight into the registers their last MFMA released:
+//   m = 0                 slot boundary                      m = 6 pr + 2 + h   lo tile of pair 2 pr + h of the next slot
+//   m = 1  (last group of a k step) counted wait + the two raw operand tiles of the next k block
+//   m = 6, 7  (same)      scale, split and pack them         m = 6 pr + 4 + h   hi tile of pair 2 pr + h of the next slot
+//   m = 12                counted wait + barrier + the first piece of the slot fetch; m = 13, 18, 19: its other pieces
+// (the reads of the next slot's second half -- pairs 4 .. 7, from m = 14 -- come behind the mid-slot events, pndf_device.h's protocol).
+// The phase is LDS-read bound like the fused split kernels (2 KiB of weight pair per 3 MFMAs per wave).
+// vmcnt: operand block kb + 2 is issued (two tiles) at the top of k step kb and read at m = 1 of the last group of k step kb + 1; younger
+// by then: the two tiles of block kb + 3 and the fetch pieces of 2 NG - 1 groups -> vmcnt(8 NG - 2).
+template <int NG>
+__device__ __forceinline__ void gen_layer_split(Ring& ring, GenWS& W, const char* xbase, int nkb, float sigma, f32x4 (&acc)[NG * NTB], const GenLds& L) {
+    constexpr int XWAIT = 8 * NG - 2;
+    auto dma_blk = [&](int kb, uint32_t buf) {
+        gw_dma_tile(xbase, (uint32_t)(2 * kb) * (SLOT_F4 * 16u) + L.lane16, L.x_lds + buf * GXS_BLK_BYTES);
+        gw_dma_tile(xbase, (uint32_t)(2 * kb + 1) * (SLOT_F4 * 16u) + L.lane16, L.x_lds + buf * GXS_BLK_BYTES + TILE_BYTES);
+    };
+    dma_blk(0, 0);
+    dma_blk(nkb > 1 ? 1 : 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GBlk xc, xn;
+    {
+        const f32x4 ra = *(const f32x4*)L.x_ptr, rb = *(const f32x4*)(L.x_ptr + TILE_BYTES);
+        gpack_blk(ra * sigma, rb * sigma, xc);
+        xn = xc;
+    }
+    uint32_t xb = 0;
+    for (int kb = 0; kb < nkb; ++kb) {
+        const uint32_t xb1 = (xb == GX_BUFS - 1) ? 0u : xb + 1, xb2 = (xb1 == GX_BUFS - 1) ? 0u : xb1 + 1;
+        dma_blk((kb + 2 < nkb) ? kb + 2 : nkb - 1, xb2);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            DmaSrc src{nullptr, 0u};
+            uint32_t dst = 0;
+            f32x4 ra = f32x4{0.f, 0.f, 0.f, 0.f}, rb = ra;
+#pragma unroll
+            for (int m = 0; m < 3 * NTB; ++m) {
+                const int pr = m / 6, term = (m % 6) / 2, j = 2 * pr + (m & 1);
+                acc[gi * NTB + j] = gmf16(term == 1 ? W.l[j] : W.h[j], term == 2 ? xc.l : xc.h, acc[gi * NTB + j]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (m == 0) ring_boundary(ring);
+                if (m == 1 && gi == NG - 1) {
+                    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XWAIT) : "memory");
+                    ra = *(const f32x4*)(L.x_ptr + xb1 * GXS_BLK_BYTES);
+                    rb = *(const f32x4*)(L.x_ptr + xb1 * GXS_BLK_BYTES + TILE_BYTES);
+                }
+                if (m % 6 == 2 || m % 6 == 3) W.l[j] = __builtin_bit_cast(gf16x8, ring_tile(ring, 2 * j + 1));
+                if (m % 6 == 4 || m % 6 == 5) W.h[j] = __builtin_bit_cast(gf16x8, ring_tile(ring, 2 * j));
+                if (m == 6 && gi == NG - 1) {
+                    ra = ra * sigma;
+                    rb = rb * sigma;
+                }
+                if (m == 7 && gi == NG - 1) gpack_blk(ra, rb, xn);
+                if (m == 12) {
+                    ring_midslot_sync(ring);
+                    ring_dma_begin(ring, src, dst);
+                    dst = __builtin_amdgcn_readfirstlane(dst);
+                    ring_dma_piece(src, dst, 0);
+                }
+                if (m == 13) ring_dma_piece(src, dst, 1);
+                if (m == 18) ring_dma_piece(src, dst, 2);
+                if (m == 19) ring_dma_piece(src, dst, 3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        xc = xn;
+        xb = xb1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NG, bool SP>
+__device__ __forceinline__ void gen_forward_split(Ring& ring, GenWS& W, const float* bias, const char* xin, f32x4* xout, f32x4* dl, int nkb, bool last,
+                                                  float slope, const SpK& k, int g, f32x4& zlast, const GenLds& L, float sigma, float to_true,
+                                                  float& amax) {
+    const float bscale = gen_pow2_rcp(to_true);
+    f32x4 acc[NG * NTB];
+#pragma unroll
+    for (int t = 0; t < NG * NTB; ++t) acc[t] = *(const f32x4*)(bias + 16 * t + 4 * g) * bscale;
+#pragma unroll
+    for (int t = 0; t < NG * NTB; ++t) asm volatile("" : "+v"(acc[t]));      // (see gen_forward)
+    gen_layer_split<NG>(ring, W, xin, nkb, sigma, acc, L);
+    if (last) {
+        zlast = acc[0] * to_true;
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < NG * NTB; ++t) {
+        f32x4 z = acc[t] * to_true, df;
+        gen_act<SP>(z, df, slope, k);
+        amax = gen_absmax4(amax, z);
+        gen_store(xout + (size_t)t * SLOT_F4, z);
+        gen_store(dl + (size_t)t * SLOT_F4, df);
+        if (t % NTB == NTB - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NG>
+__device__ __forceinline__ void gen_backward_split(Ring& ring, GenWS& W, const char* gin, f32x4* gout, const f32x4* dprev, float* my_f, int nkb, int g,
+                                                   int t0, const GenLds& L, float sigma, float to_true, float& amax) {
+    f32x4 acc[NG * NTB];
+#pragma unroll
+    for (int t = 0; t < NG * NTB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gen_layer_split<NG>(ring, W, gin, nkb, sigma, acc, L);
+    if (dprev) {                   // (the loads one group ahead of the stores: see gen_backward)
+        f32x4 dp[2][NTB];
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) dp[0][j] = dprev[(size_t)j * SLOT_F4];
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            if (gq + 1 < NG) {
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) dp[(gq + 1) & 1][j] = dprev[(size_t)((gq + 1) * NTB + j) * SLOT_F4];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NTB; ++j) {
+                const int t = gq * NTB + j;
+                const f32x4 go = (acc[t] * to_true) * dp[gq & 1][j];
+                amax = gen_absmax4(amax, go);
+                gen_store(gout + (size_t)t * SLOT_F4, go);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // the operand buffers ARE this wave's feature rows, and the last k steps re-issue their final block (the counted waits want a
+        // fixed number of operations per k step): such a fetch may still be in flight -- it must not land on top of the rows written here
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < NG * NTB; ++t)
+            if (t0 + t < 8) *(f32x4*)(my_f + 16 * (t0 + t) + 4 * g) = acc[t] * to_true;
+    }
+}
+
 // the group counts the layer code is instantiated for (the plan rounds up to the next one: at most a third of a layer is padding)
 // A pass keeps at most 4 groups = 32 tiles = 128 accumulator registers (a whole 1024-wide layer at once -- 256 -- left hipcc 150 - 220
 // spilled registers: everything that is not an MFMA accumulator has to fit the 256 architectural VGPRs); wider layers take two
@@ -301,7 +524,8 @@ constexpr int GEN_PASS_GROUPS = 4;
 
 // SP: the trunk's activation is Softplus (else relu / lrelu); ESP: the encoder's.  Every config of the reference has ESP == SP;
 // net_modules.py:128 reads model.StrEnc.act on its own, so the other two combinations exist as well.
-template <bool SP, bool ESP = SP>
+// SPLIT: the trunk on split-precision fp16 MFMAs (precision f16x3 / f16), else exact fp32.
+template <bool SP, bool ESP = SP, bool SPLIT = false>
 __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -319,8 +543,13 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
     const char* const xwave = (const char*)((f32x4*)args.scratch + (size_t)blockIdx.x * args.wg_tiles * SLOT_F4) + wave * TILE_BYTES;
     const char* const xuni[2] = {xwave, xwave + (size_t)PNDF_GEN_XTILES * SLOT_F4 * 16};
     GenLds gl;
-    gl.x_lds = (uint32_t)(size_t)(PNDF_LDS char*)(smem + LDS_MASK) + wave * GX_WAVE_BYTES;
-    gl.x_ptr = smem + LDS_MASK + wave * GX_WAVE_BYTES + lane * 16;
+    if constexpr (SPLIT) {           // (three k blocks of 2 KiB in the wave's own feature rows: see GXS_BLK_BYTES)
+        gl.x_lds = (uint32_t)(size_t)(PNDF_LDS char*)(smem + LDS_F) + wave * (16 * FSTRIDE * 4);
+        gl.x_ptr = smem + LDS_F + wave * (16 * FSTRIDE * 4) + lane * 16;
+    } else {
+        gl.x_lds = (uint32_t)(size_t)(PNDF_LDS char*)(smem + LDS_MASK) + wave * GX_WAVE_BYTES;
+        gl.x_ptr = smem + LDS_MASK + wave * GX_WAVE_BYTES + lane * 16;
+    }
     gl.lane16 = (uint32_t)lane * 16u;
 
     ActP ap;                         // the TRUNK's activation parameters ...
@@ -387,14 +616,41 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                 const float pe = encoder_forward<ESP>(my_q, my_f, lds_bias + ENCB_OFF, eb, ring, ape, g);
                 if constexpr (ESP) poison = pe;
             }
+            float amax = 0.f;              // (split path) largest |value| of this lane's rows of the tensor being produced
 #pragma unroll
-            for (int t = 0; t < 8; ++t) xbuf[0][(size_t)t * SLOT_F4] = *(const f32x4*)(my_f + 16 * t + 4 * g);
+            for (int t = 0; t < 8; ++t) {
+                const f32x4 v = *(const f32x4*)(my_f + 16 * t + 4 * g);
+                xbuf[0][(size_t)t * SLOT_F4] = v;
+                if constexpr (SPLIT) amax = gen_absmax4(amax, v);
+            }
 
             // ---------------- trunk forward, layer by layer (net_modules.py:51-69)
             GenW wcur;
-            gen_trunk_begin(ring, wcur);
-            int half = 0;                  // which half of its slot the next group of the stream is (uniform)
+            GenWS wsp;
+            int half = 0;                  // which half of its slot the next group of the stream is (uniform; fp32 path)
             f32x4 zlast = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (SPLIT) {
+                // (the x0 tiles this lane just stored come back through the operand DMA: the pass start's vmcnt(0) covers them)
+                gen_trunk_begin_split(ring, wsp);
+                for (int l = 0; l < L; ++l) {
+                    const int nkb = args.kb[l], ng = args.ntp[l] / NTB;
+                    const float* bias = args.lbias + args.b_off[l];
+                    f32x4* dl = wg + (size_t)args.d_off[l] * SLOT_F4;
+                    const float sigma = gen_pose_scale(gen_pose_max(amax));
+                    const float to_true = args.w_inv[l] * gen_pow2_rcp(sigma);
+                    amax = 0.f;
+                    for (int g0 = 0; g0 < ng; g0 += GEN_PASS_GROUPS) {
+                        const int n = (ng - g0 < GEN_PASS_GROUPS) ? ng - g0 : GEN_PASS_GROUPS, t0 = g0 * NTB;
+                        switch (n) {
+#define PNDF_GEN_FWDS(N) case N: gen_forward_split<N, SP>(ring, wsp, bias + 16 * t0, xuni[l & 1], xbuf[(l + 1) & 1] + (size_t)t0 * SLOT_F4, dl + (size_t)t0 * SLOT_F4, nkb, l == L - 1, args.slope, ap.k, g, zlast, gl, sigma, to_true, amax); break;
+                            PNDF_GEN_FWDS(1) PNDF_GEN_FWDS(2) PNDF_GEN_FWDS(3) PNDF_GEN_FWDS(4)
+#undef PNDF_GEN_FWDS
+                            default: break;
+                        }
+                    }
+                }
+            } else {
+            gen_trunk_begin(ring, wcur);
             for (int l = 0; l < L; ++l) {
                 const int nk = args.kt[l], ng = args.ntp[l] / NTB;
                 const float* bias = args.lbias + args.b_off[l];
@@ -409,6 +665,7 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                     }
                     half ^= (n * nk) & 1;
                 }
+            }
             }
             // row 0 of the output tile lives in register 0 of lane group 0: every lane of the pose reads it from there
             const float z7 = __shfl(zlast[0], p);
@@ -436,6 +693,28 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
             // and grad_outputs scale the result, as in the fused kernels)
             int cur = 0;
             xbuf[0][0] = (g == 0) ? f32x4{1.f, 0.f, 0.f, 0.f} : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (SPLIT) {
+                xbuf[0][SLOT_F4] = f32x4{0.f, 0.f, 0.f, 0.f};      // the other tile of the seed's k block
+                amax = 1.0f;
+                for (int l = L - 1; l >= 0; --l) {
+                    const int nkb = args.nb[l], ng = args.ktp[l] / NTB;
+                    const f32x4* dprev = (l > 0) ? wg + (size_t)args.d_off[l - 1] * SLOT_F4 : nullptr;
+                    const float sigma = gen_pose_scale(gen_pose_max(amax));
+                    const float to_true = args.w_inv[l] * gen_pow2_rcp(sigma);
+                    amax = 0.f;
+                    for (int g0 = 0; g0 < ng; g0 += GEN_PASS_GROUPS) {
+                        const int n = (ng - g0 < GEN_PASS_GROUPS) ? ng - g0 : GEN_PASS_GROUPS, t0 = g0 * NTB;
+                        switch (n) {
+#define PNDF_GEN_BWDS(N) case N: gen_backward_split<N>(ring, wsp, xuni[cur], xbuf[cur ^ 1] + (size_t)t0 * SLOT_F4, dprev ? dprev + (size_t)t0 * SLOT_F4 : nullptr, my_f, nkb, g, t0, gl, sigma, to_true, amax); break;
+                            PNDF_GEN_BWDS(1) PNDF_GEN_BWDS(2) PNDF_GEN_BWDS(3) PNDF_GEN_BWDS(4)
+#undef PNDF_GEN_BWDS
+                            default: break;
+                        }
+                    }
+                    cur ^= 1;
+                }
+                // (every group has run the whole slot behind it: the last one the slot of padding the host appends -- nothing left to do)
+            } else {
             for (int l = L - 1; l >= 0; --l) {
                 const int nk = args.nt[l], ng = args.ktp[l] / NTB;
                 const f32x4* dprev = (l > 0) ? wg + (size_t)args.d_off[l - 1] * SLOT_F4 : nullptr;
@@ -452,6 +731,7 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                 cur ^= 1;
             }
             gen_trunk_end(ring, half);
+            }
             __syncthreads();
 
             // ---------------- encoder backward + normalise backward + update (fp32, as the fused kernels)
@@ -526,6 +806,20 @@ extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_generic_softplu
     pndf_generic_body<true, false>(args);
 }
 
+// precision f16x3 (and f16) on run-time widths: the same four family pairs with the trunk on split-precision fp16 MFMAs
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_generic_split_relu_kernel(PndfGenericArgs args) {
+    pndf_generic_body<false, false, true>(args);
+}
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_generic_split_softplus_kernel(PndfGenericArgs args) {
+    pndf_generic_body<true, true, true>(args);
+}
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_generic_split_relu_spenc_kernel(PndfGenericArgs args) {
+    pndf_generic_body<false, true, true>(args);
+}
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_generic_split_softplus_reluenc_kernel(PndfGenericArgs args) {
+    pndf_generic_body<true, false, true>(args);
+}
+
 // ------------------------------------------------------------------------------------------ host side
 using namespace pndf;
 
@@ -537,6 +831,8 @@ struct PndfGeneric {
     PndfGenericArgs plan;            // tile counts and offsets (pointers filled per launch)
     size_t wf_tiles = 0, wb_tiles = 0, lbias_floats = 0;
     int trunk_tiles = 0;             // wf_tiles + wb_tiles rounded up to whole ring slots
+    bool split = false;              // the trunk on split-precision fp16 MFMAs (precision f16x3 / f16) -- decided at pndf_generic_load
+    size_t enc_alloc_tiles = 0;      // tiles allocated for the step's stream (the larger of the two plans)
     char* d_enc = nullptr;
     float *d_bias = nullptr, *d_wf = nullptr, *d_wb = nullptr, *d_lb = nullptr, *d_scratch = nullptr;
     bool have_weights = false;
@@ -567,8 +863,15 @@ constexpr int GEN_STREAM_PAD_SLOTS = 5;      // >= RING_SLOTS - 1: the replica o
 static inline int gen_enc_act(const pndf_config& cfg) { return cfg.enc_act == -1 ? cfg.act : cfg.enc_act; }
 static inline float gen_enc_beta(const pndf_config& cfg) { return cfg.enc_beta > 0.f ? cfg.enc_beta : cfg.beta; }
 typedef void (*gen_kernel_t)(PndfGenericArgs);
-static gen_kernel_t gen_kernel(const pndf_config& cfg, const char** name) {
+static gen_kernel_t gen_kernel(const pndf_config& cfg, bool split, const char** name) {
     const bool sp = cfg.act == PNDF_ACT_SOFTPLUS, esp = (cfg.dims[0] == DIMS[0]) ? gen_enc_act(cfg) == PNDF_ACT_SOFTPLUS : sp;
+    if (split) {
+        if (sp && esp) { *name = "pndf_generic_split_softplus_kernel"; return pndf_generic_split_softplus_kernel; }
+        if (!sp && !esp) { *name = "pndf_generic_split_relu_kernel"; return pndf_generic_split_relu_kernel; }
+        if (sp) { *name = "pndf_generic_split_softplus_reluenc_kernel"; return pndf_generic_split_softplus_reluenc_kernel; }
+        *name = "pndf_generic_split_relu_spenc_kernel";
+        return pndf_generic_split_relu_spenc_kernel;
+    }
     if (sp && esp) { *name = "pndf_generic_softplus_kernel"; return pndf_generic_softplus_kernel; }
     if (!sp && !esp) { *name = "pndf_generic_relu_kernel"; return pndf_generic_relu_kernel; }
     if (sp) { *name = "pndf_generic_softplus_reluenc_kernel"; return pndf_generic_softplus_reluenc_kernel; }
@@ -582,6 +885,55 @@ static inline int gen_round_tiles(int tiles) {
     return (full + rest) * NTB;      // (every 1 .. GEN_PASS_GROUPS groups of a last pass have their instantiation: PNDF_GEN_GROUP_CASES)
 }
 
+// tile counts and offsets of the step's stream and of the workgroup's scratch, for the fp32 or the split-precision trunk
+static void gen_plan(PndfGeneric* g, bool split) {
+    const pndf_config& cfg = g->cfg;
+    const int L = g->L;
+    PndfGenericArgs& P = g->plan;
+    memset(&P, 0, sizeof(P));
+    P.nlayers = L;
+    P.noenc = g->enc ? 0 : 1;
+    int bo = 0, slot = 2 * PNDF_GEN_XTILES;
+    for (int l = 0; l < L; ++l) {
+        const int in = (l == 0) ? 128 : cfg.dims[l];      // x0 is the pose's 128-row feature buffer (126 | 84 rows used, the rest zero)
+        const int outw = cfg.dims[l + 1];
+        P.kt[l] = ceil_div(in, 16);
+        P.nt[l] = ceil_div(outw, 16);
+        P.kb[l] = ceil_div(P.kt[l], 2);
+        P.nb[l] = ceil_div(P.nt[l], 2);
+        P.ktp[l] = gen_round_tiles(P.kt[l]);
+        P.ntp[l] = gen_round_tiles(P.nt[l]);
+        P.w_inv[l] = 1.0f;
+        P.b_off[l] = bo;
+        P.d_off[l] = slot;
+        bo += 16 * P.ntp[l];
+        if (l < L - 1) slot += P.ntp[l];
+    }
+    // stream tiles of a layer: fp32 one tile per (output tile, k tile); split one PAIR (hi, lo) per (output tile, k block of 32)
+    int wf = 0, wb = 0;
+    for (int l = 0; l < L; ++l) {
+        P.wf_off[l] = wf;
+        wf += split ? 2 * P.ntp[l] * P.kb[l] : P.ntp[l] * P.kt[l];
+    }
+    g->wf_tiles = wf;                 // the backward matrices follow the forward ones in ONE stream, in the order the backward pass walks them
+    for (int l = L - 1; l >= 0; --l) {
+        P.wb_off[l] = wf + wb;
+        wb += split ? 2 * P.ktp[l] * P.nb[l] : P.ktp[l] * P.nt[l];
+    }
+    g->wb_tiles = wb;
+    P.enc_d_off = slot;
+    if (gen_enc_act(cfg) == PNDF_ACT_SOFTPLUS && g->enc) slot += 2 * NJ;
+    P.wg_tiles = slot;
+    // the step's stream: encoder forward (3 slots) | trunk (whole groups of NTB tiles, padded to whole slots) | encoder backward (3 slots)
+    // Every group of the trunk runs the ring events and the tile reads of the group BEHIND it (gen_layer has no "last group" case), so
+    // the last one needs padding behind it: fp32 the other half of its slot, or -- when the trunk fills its last slot -- a slot of its
+    // own; split (a group = a slot) always a slot.
+    g->trunk_tiles = split ? (wf + wb) + SLOT_TILES : round_up_int((wf + wb) + NTB, SLOT_TILES);
+    P.w_slots = (2 * ENC_TILES_PADDED + g->trunk_tiles) / SLOT_TILES;
+    g->lbias_floats = bo;
+    g->split = split;
+}
+
 int pndf_generic_create(PndfGeneric** out, const pndf_config& cfg, int resident_wgs, std::string& err) {
     *out = nullptr;
     const int L = cfg.n_dims - 1;
@@ -591,50 +943,26 @@ int pndf_generic_create(PndfGeneric** out, const pndf_config& cfg, int resident_
     g->L = L;
     g->enc = cfg.dims[0] == DIMS[0];
     g->resident = resident_wgs;
+    // the stream is allocated for the larger of the two plans: pndf_generic_load falls back to the fp32 trunk when a layer cannot be
+    // scaled into the fp16 range (scratch and biases have the same layout in both)
+    gen_plan(g, false);
+    size_t alloc_slots = (size_t)g->plan.w_slots;
+    if (cfg.precision != PNDF_PREC_FP32) {
+        gen_plan(g, true);
+        if ((size_t)g->plan.w_slots > alloc_slots) alloc_slots = (size_t)g->plan.w_slots;
+    }
+    g->enc_alloc_tiles = (alloc_slots + GEN_STREAM_PAD_SLOTS) * SLOT_TILES;
     PndfGenericArgs& P = g->plan;
-    memset(&P, 0, sizeof(P));
-    P.nlayers = L;
-    P.noenc = g->enc ? 0 : 1;
-    int wf = 0, wb = 0, bo = 0, slot = 2 * PNDF_GEN_XTILES;
-    for (int l = 0; l < L; ++l) wf += gen_round_tiles(ceil_div(cfg.dims[l + 1], 16)) * ceil_div((l == 0) ? 128 : cfg.dims[l], 16);
-    g->wf_tiles = wf;                 // the backward matrices follow the forward ones in ONE stream, in the order the backward pass walks them
-    wf = 0;
-    for (int l = L - 1; l >= 0; --l) {
-        P.wb_off[l] = (int)g->wf_tiles + wb;
-        wb += gen_round_tiles(ceil_div((l == 0) ? 128 : cfg.dims[l], 16)) * ceil_div(cfg.dims[l + 1], 16);
-    }
-    g->wb_tiles = wb;
-    for (int l = 0; l < L; ++l) {
-        const int in = (l == 0) ? 128 : cfg.dims[l];      // x0 is the pose's 128-row feature buffer (126 | 84 rows used, the rest zero)
-        const int outw = cfg.dims[l + 1];
-        P.kt[l] = ceil_div(in, 16);
-        P.nt[l] = ceil_div(outw, 16);
-        P.ktp[l] = gen_round_tiles(P.kt[l]);
-        P.ntp[l] = gen_round_tiles(P.nt[l]);
-        P.wf_off[l] = wf;
-        P.b_off[l] = bo;
-        P.d_off[l] = slot;
-        wf += P.ntp[l] * P.kt[l];
-        bo += 16 * P.ntp[l];
-        if (l < L - 1) slot += P.ntp[l];
-    }
-    P.enc_d_off = slot;
-    if (gen_enc_act(cfg) == PNDF_ACT_SOFTPLUS && g->enc) slot += 2 * NJ;
-    P.wg_tiles = slot;
-    // the step's stream: encoder forward (3 slots) | trunk (whole groups of NTB tiles, padded to whole slots) | encoder backward (3 slots)
-    // Every group of the trunk runs the ring events and the tile reads of the group BEHIND it (gen_layer has no "last group" case), so
-    // the last one needs padding behind it: the other half of its slot, or -- when the trunk fills its last slot -- a slot of its own.
-    g->trunk_tiles = round_up_int((int)(g->wf_tiles + g->wb_tiles) + NTB, SLOT_TILES);
-    P.w_slots = (2 * ENC_TILES_PADDED + g->trunk_tiles) / SLOT_TILES;
-    g->lbias_floats = bo;
     hipError_t e = hipMalloc((void**)&g->d_bias, BIAS_FLOATS * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&g->d_enc, (size_t)(P.w_slots + GEN_STREAM_PAD_SLOTS) * SLOT_TILES * TILE_BYTES);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->d_enc, g->enc_alloc_tiles * TILE_BYTES);
     g->d_wf = g->d_wb = nullptr;      // (one stream: encoder and trunk tiles live in d_enc)
     if (e == hipSuccess) e = hipMalloc((void**)&g->d_lb, g->lbias_floats * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&g->d_scratch, (size_t)resident_wgs * P.wg_tiles * SLOT_F4 * sizeof(f32x4));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->done, hipEventDisableTiming);
     for (const void* kfn : {(const void*)pndf_generic_relu_kernel, (const void*)pndf_generic_softplus_kernel,
-                            (const void*)pndf_generic_relu_spenc_kernel, (const void*)pndf_generic_softplus_reluenc_kernel})
+                            (const void*)pndf_generic_relu_spenc_kernel, (const void*)pndf_generic_softplus_reluenc_kernel,
+                            (const void*)pndf_generic_split_relu_kernel, (const void*)pndf_generic_split_softplus_kernel,
+                            (const void*)pndf_generic_split_relu_spenc_kernel, (const void*)pndf_generic_split_softplus_reluenc_kernel})
         if (e == hipSuccess) e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     if (e != hipSuccess) {
         err = std::string("pndf_create (runtime-planned DFNet): ") + hipGetErrorString(e);
@@ -675,23 +1003,60 @@ int pndf_generic_load(PndfGeneric* g, const float* const* tensors, const int64_t
             return PNDF_ERR_BAD_SHAPE;
         }
     }
-    const PndfGenericArgs& P = g->plan;
+    // precision f16x3 / f16: the trunk on split-precision fp16 MFMAs -- the weights of layer l travel as s_l W, s_l = the power of two
+    // that brings the layer's largest |weight| into [2^12, 2^13) (pndf_capi.hip "split-precision stream").  A layer without a finite
+    // non-zero weight cannot be scaled: such a network runs the exact fp32 kernels, whatever precision was asked for.
+    float wscale[PNDF_GEN_MAXLIN];
+    bool split = g->cfg.precision != PNDF_PREC_FP32;
+    for (int l = 0; l < L && split; ++l) {
+        float mx = 0.f;
+        bool nan = false;
+        const int64_t n = (int64_t)g->cfg.dims[l] * g->cfg.dims[l + 1];
+        for (int64_t i = 0; i < n; ++i) {
+            const float a = fabsf(lin[2 * l][i]);
+            nan |= (a != a);
+            if (a > mx) mx = a;
+        }
+        if (nan || !(mx > 0x1p-100f && mx < 0x1p100f)) { split = false; break; }
+        int e;
+        (void)frexpf(mx, &e);                            // mx = f * 2^e, f in [0.5, 1)
+        wscale[l] = ldexpf(1.0f, 13 - e);                // s_l * mx in [2^12, 2^13)
+    }
+    gen_plan(g, split);
+    PndfGenericArgs& P = g->plan;
     const size_t step_tiles = (size_t)P.w_slots * SLOT_TILES;
+    if (step_tiles + (size_t)GEN_STREAM_PAD_SLOTS * SLOT_TILES > g->enc_alloc_tiles) { err = "internal: stream larger than its allocation"; return PNDF_ERR_BAD_SHAPE; }
     std::vector<float> stream((step_tiles + (size_t)GEN_STREAM_PAD_SLOTS * SLOT_TILES) * TILE_FLOATS, 0.f), lb(g->lbias_floats, 0.f), bias(BIAS_FLOATS, 0.f);
     float* const trunk = stream.data() + (size_t)ENC_TILES_PADDED * TILE_FLOATS;      // wf_off / wb_off count tiles from here
+    const bool sp_trunk = g->cfg.act == PNDF_ACT_SOFTPLUS;
     for (int l = 0; l < L; ++l) {
         const int in = g->cfg.dims[l], outw = g->cfg.dims[l + 1];
         const pndf_pack::Mat F{lin[2 * l], outw, in, false}, T{lin[2 * l], outw, in, true};
         float* dst = trunk + (size_t)P.wf_off[l] * TILE_FLOATS;
         const int PT = GEN_PASS_GROUPS * NTB;                  // consumption order: [pass of <= 32 output tiles][k tile][tile of the pass]
-        for (int t0 = 0; t0 < P.ntp[l]; t0 += PT)
-            for (int k = 0; k < P.kt[l]; ++k)
-                for (int t = t0; t < P.ntp[l] && t < t0 + PT; ++t, dst += TILE_FLOATS) pndf_pack::emit_tile(F, t, k, dst);
-        dst = trunk + (size_t)P.wb_off[l] * TILE_FLOATS;
-        for (int t0 = 0; t0 < P.ktp[l]; t0 += PT)
-            for (int k = 0; k < P.nt[l]; ++k)
-                for (int t = t0; t < P.ktp[l] && t < t0 + PT; ++t, dst += TILE_FLOATS) pndf_pack::emit_tile(T, t, k, dst);
+        if (split) {                                           // ... [pass][k block][tile of the pass] pairs (hi tile, lo tile)
+            P.w_inv[l] = 1.0f / wscale[l];
+            for (int t0 = 0; t0 < P.ntp[l]; t0 += PT)
+                for (int k = 0; k < P.kb[l]; ++k)
+                    for (int t = t0; t < P.ntp[l] && t < t0 + PT; ++t, dst += 2 * TILE_FLOATS) pndf_pack::emit_pair_f16(F, t, k, wscale[l], dst);
+            dst = trunk + (size_t)P.wb_off[l] * TILE_FLOATS;
+            for (int t0 = 0; t0 < P.ktp[l]; t0 += PT)
+                for (int k = 0; k < P.nb[l]; ++k)
+                    for (int t = t0; t < P.ktp[l] && t < t0 + PT; ++t, dst += 2 * TILE_FLOATS) pndf_pack::emit_pair_f16(T, t, k, wscale[l], dst);
+        } else {
+            for (int t0 = 0; t0 < P.ntp[l]; t0 += PT)
+                for (int k = 0; k < P.kt[l]; ++k)
+                    for (int t = t0; t < P.ntp[l] && t < t0 + PT; ++t, dst += TILE_FLOATS) pndf_pack::emit_tile(F, t, k, dst);
+            dst = trunk + (size_t)P.wb_off[l] * TILE_FLOATS;
+            for (int t0 = 0; t0 < P.ktp[l]; t0 += PT)
+                for (int k = 0; k < P.nt[l]; ++k)
+                    for (int t = t0; t < P.ktp[l] && t < t0 + PT; ++t, dst += TILE_FLOATS) pndf_pack::emit_tile(T, t, k, dst);
+        }
         memcpy(lb.data() + P.b_off[l], lin[2 * l + 1], sizeof(float) * outw);
+        // split path, Softplus: the zero-padded units of a layer would enter the per-pose operand bound it measures (softplus(0) =
+        // ln 2 / beta, derivative 1 / 2); a bias of -1e6 makes both exactly zero (pndf_capi.hip does the same for narrower networks)
+        if (split && sp_trunk && l < L - 1)
+            for (int j = outw; j < 16 * P.ntp[l]; ++j) lb[P.b_off[l] + j] = -1.0e6f;
     }
     for (int l = 0; l < 8; ++l) bias[SCALE_OFF + l] = 1.0f;
     if (g->enc) {
@@ -714,7 +1079,7 @@ int pndf_generic_load(PndfGeneric* g, const float* const* tensors, const int64_t
 
 const char* pndf_generic_kernel_name(const PndfGeneric* g) {
     const char* name = "";
-    (void)gen_kernel(g->cfg, &name);
+    (void)gen_kernel(g->cfg, g->split, &name);
     return name;
 }
 
@@ -738,7 +1103,7 @@ int pndf_generic_launch(PndfGeneric* g, int mode, const float* q, const float* g
     if (g->pending && g->last_stream != stream && !capturing) e = hipStreamWaitEvent((hipStream_t)stream, g->done, 0);
     if (e == hipSuccess) {
         const char* name = "";
-        hipLaunchKernelGGL(gen_kernel(g->cfg, &name), grid, block, LDS_TOTAL, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(gen_kernel(g->cfg, g->split, &name), grid, block, LDS_TOTAL, (hipStream_t)stream, a);
         e = hipGetLastError();
     }
     if (e == hipSuccess && !capturing) {

@@ -24,6 +24,21 @@ inline void emit_tile(const Mat& m, int nt, int kt, float* dst) {
         for (int s = 0; s < 4; ++s) dst[lane * 4 + s] = m.at(16 * nt + (lane & 15), 16 * kt + 4 * (lane >> 4) + s);
 }
 
+// split-precision block (pndf_layout.h "split-precision stream"): hi tile then lo tile of (16 rows x 32 k), 8 halfs per lane each,
+//   block(M, nt, kb)[lane * 8 + jj] = scale * M[16 nt + (lane & 15)][16 (2 kb + (jj >> 2)) + 4 (lane >> 4) + (jj & 3)]
+// hi = the value rounded to nearest even, lo = the remainder rounded to nearest (pndf_capi.hip emit_pair: the amass.yaml stream)
+inline void emit_pair_f16(const Mat& m, int nt, int kb, float scale, float* dst) {
+    _Float16* hi = (_Float16*)dst;
+    _Float16* lo = (_Float16*)(dst + TILE_FLOATS);
+    for (int lane = 0; lane < 64; ++lane)
+        for (int jj = 0; jj < 8; ++jj) {
+            const float w = scale * m.at(16 * nt + (lane & 15), 16 * (2 * kb + (jj >> 2)) + 4 * (lane >> 4) + (jj & 3));
+            const _Float16 h = (_Float16)w;
+            hi[lane * 8 + jj] = h;
+            lo[lane * 8 + jj] = (_Float16)(w - (float)h);
+        }
+}
+
 // 16x16 logical matrices of one encoder joint (zero padded), see pndf_layout.h "encoder on the MFMA pipe"
 struct EncMat {
     const float* w1;   // [10][in]

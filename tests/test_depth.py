@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, d_rows, fp32_noise, outlier_gate, pose_gate, rel_err_rows, traj_envelope, traj_margin
+from conftest import GOLDEN, d_rows, escalated_noise, fp32_noise, outlier_gate, pose_gate, rel_err_rows, traj_envelope, traj_margin
 
 CASES = ["d1_lrelu", "d4_lrelu", "d4_softplus", "d7_lrelu", "d7_softplus", "wide_relu", "noenc_d3_lrelu",
          "mix_softplus_lreluenc", "mix_relu_softplusenc"]      # the last two: model.StrEnc.act != model.DFNet.act ("trunk/encoder")
@@ -136,6 +136,8 @@ def test_runtime_planned_kernels(name, precision):
     fam = lambda a: "softplus" if a == "softplus" else "relu"      # noqa: E731
     trunk_act, _, enc_act = act.partition("/")
     want = KERNELS[(fam(trunk_act), fam(enc_act or trunk_act) if enc else fam(trunk_act))]
+    if precision != "fp32":      # the trunk on split-precision fp16 MFMAs (csrc/pndf_generic.hip gen_layer_split): its own four kernels
+        want = want.replace("pndf_generic_", "pndf_generic_split_")
     assert net._engine_for(torch.device("cuda:0")).kernel_name() == want
 
 
@@ -255,8 +257,12 @@ def test_runtime_planned_kernels_width_and_depth_extremes(hidden, act, enc):
     assert net._engine_for(q.device).kernel_name().startswith("pndf_generic_")
     sig_d, sig_g, d64, g64 = fp32_noise(q_np, sd, act)
     what = f"{hidden} {act} enc={enc}"
-    pose_gate(d_rows(d.detach().cpu().numpy(), d64), sig_d, what + " d")
-    pose_gate(rel_err_rows(dq.cpu().numpy(), g64), sig_g, what + " dq", exempt=kink_exempt(q_np, sd, act))
+    # (`escalate`, as in the held-out sweep of tests/test_gpu_sweep.py: a pose over the cheap envelope is held to twice the reference
+    # arithmetic's own variability there, measured properly -- the 3-unit bottlenecks of these networks make single poses ill-conditioned:
+    # pose 20 of [7, 1024, 5, 1024, 3, 1024, 9]: cheap sigma 5e-6, 32 perturbed fp32 evaluations of the oracle 4.7e-5)
+    pose_gate(d_rows(d.detach().cpu().numpy(), d64), sig_d, what + " d", escalate=lambda i: escalated_noise(q_np, sd, act, i, d64, kind="d"))
+    pose_gate(rel_err_rows(dq.cpu().numpy(), g64), sig_g, what + " dq", exempt=kink_exempt(q_np, sd, act),
+              escalate=lambda i: escalated_noise(q_np, sd, act, i, g64, kind="g"))
     qp, _ = net.project(torch.from_numpy(q_np).cuda(), steps=3)
     q64, _ = onp.project(q_np, sd, steps=3, act=act, dtype=np.float64)
     q32, _ = onp.project(q_np, sd, steps=3, act=act)
