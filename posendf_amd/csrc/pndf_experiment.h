@@ -120,7 +120,7 @@
 #ifndef PNDF_GEN_ABLATE
 #define PNDF_GEN_ABLATE 0        // pndf_generic.hip, timing arms only (WRONG results): 1 = no activation / derivative / gradient stores in the
 #endif                           // layer epilogues, 2 = no derivative loads in the backward epilogues, 4 = no operand-tile DMA after a pass's
-                                 // first two, 8 = no bias loads, 16 = no activation arithmetic, 32 = no vmcnt(0) at a pass's start, 64 = no weight-tile reads, 128 = no ring events; 256 = plain instead of non-temporal epilogue stores (correct results)
+                                 // first two, 8 = no bias loads, 16 = no activation arithmetic, 32 = no vmcnt(0) at a pass's start, 64 = no weight-tile reads, 128 = no ring events; 256 = plain instead of non-temporal epilogue stores, 512 / 1024 = plain instead of non-temporal operand-tile fetches / derivative loads (correct results)
 #ifndef PNDF_STAGGER
 #define PNDF_STAGGER 0           // pndf_kernel_split.hip: workgroups of XCD x start x * PNDF_STAGGER sleeps (~4 us each) late (round 6:
 #endif                           // does a chip whose XCDs are in different phases of a step sit closer to the power cap?)

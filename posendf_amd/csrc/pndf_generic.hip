@@ -80,7 +80,17 @@ struct GenLds {
     uint32_t lane16;
 };
 __device__ __forceinline__ void gw_dma_tile(const char* base, uint32_t voff, uint32_t dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
+    // the operand tiles are read ONCE: fetched non-temporally they do not push the weight stream out of L2 (arm 512 of PNDF_GEN_ABLATE:
+    // plain; with the derivative loads below 15.2 -> 14.3 ms per launch on the split path, Softplus 17.5 -> 15.7; nothing on the fp32 path)
+    if (PNDF_GEN_ABLATE & 512)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
+}
+// a derivative-factor tile of a backward epilogue: read once as well (arm 1024: plain)
+__device__ __forceinline__ f32x4 gen_load_d(const f32x4* p) {
+    if (PNDF_GEN_ABLATE & 1024) return *p;
+    return __builtin_nontemporal_load(p);
 }
 
 // the tiles of the group being multiplied
@@ -222,10 +232,27 @@ __device__ __forceinline__ void gen_act(f32x4& z, f32x4& dfac, float slope, cons
     }
 }
 
+// relu family: the derivative of a hidden unit is one BIT (z > 0: PyTorch's convention at 0), 32 per lane for a group of eight tiles --
+// a dword per lane and group in the scratch instead of eight fp32 tiles (the scratch's traffic is what bounds the split path: HBM)
+__device__ __forceinline__ void gen_act_bits(f32x4& z, float slope, uint32_t& bits, int j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool pos = z[r] > 0.0f;
+        bits |= pos ? (1u << (4 * j + r)) : 0u;
+        z[r] = pos ? z[r] : z[r] * slope;
+    }
+}
+__device__ __forceinline__ f32x4 gen_dfac_bits(uint32_t bits, int j, float slope) {
+    f32x4 d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r] = ((bits >> (4 * j + r)) & 1u) ? 1.0f : slope;
+    return d;
+}
+
 // one forward layer with NG groups of output tiles: bias -> accumulate -> (hidden layers) activation, derivative factor
 template <int NG, int H0, bool SP>
-__device__ __forceinline__ void gen_forward(Ring& ring, GenW& W, const float* bias, const char* xin, f32x4* xout, f32x4* dl, int nk, bool last,
-                                            float slope, const SpK& k, int g, f32x4& zlast, const GenLds& L) {
+__device__ __forceinline__ void gen_forward(Ring& ring, GenW& W, const float* bias, const char* xin, f32x4* xout, f32x4* dl, uint32_t* mk, int nk,
+                                            bool last, float slope, const SpK& k, int g, f32x4& zlast, const GenLds& L) {
     f32x4 acc[NG * NTB];
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) acc[t] = (PNDF_GEN_ABLATE & 8) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(bias + 16 * t + 4 * g);
@@ -238,42 +265,65 @@ __device__ __forceinline__ void gen_forward(Ring& ring, GenW& W, const float* bi
         zlast = acc[0];
         return;
     }
+    uint32_t bits = 0;
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) {
         f32x4 df = acc[t];
-        if (!(PNDF_GEN_ABLATE & 16)) gen_act<SP>(acc[t], df, slope, k);
+        if constexpr (SP) {
+            if (!(PNDF_GEN_ABLATE & 16)) gen_act<SP>(acc[t], df, slope, k);
+        } else {
+            if (!(PNDF_GEN_ABLATE & 16)) gen_act_bits(acc[t], slope, bits, t % NTB);
+        }
         if (!(PNDF_GEN_ABLATE & 1) || t == 0) {
             gen_store(xout + (size_t)t * SLOT_F4, acc[t]);
-            gen_store(dl + (size_t)t * SLOT_F4, df);
+            if constexpr (SP) gen_store(dl + (size_t)t * SLOT_F4, df);
         } else {
             asm volatile("" : : "v"(acc[t]), "v"(df));      // (the arm keeps the arithmetic)
         }
-        if (t % NTB == NTB - 1) __builtin_amdgcn_sched_barrier(0);      // a group at a time: the accumulators fill up to half the register file
+        if (t % NTB == NTB - 1) {
+            if constexpr (!SP) {
+                __builtin_nontemporal_store(bits, mk + (size_t)(t / NTB) * WG_THREADS);
+                bits = 0;
+            }
+            __builtin_amdgcn_sched_barrier(0);      // a group at a time: the accumulators fill up to half the register file
+        }
     }
 }
 
 // one backward layer: G_in = W^T G_out, times the derivative factors of the layer below (l > 0) or into the pose's feature row
-template <int NG, int H0>
-__device__ __forceinline__ void gen_backward(Ring& ring, GenW& W, const char* gin, f32x4* gout, const f32x4* dprev, float* my_f, int nk, int g, int t0,
-                                             const GenLds& L) {
+template <int NG, int H0, bool SP>
+__device__ __forceinline__ void gen_backward(Ring& ring, GenW& W, const char* gin, f32x4* gout, const f32x4* dprev, const uint32_t* mkprev, float slope,
+                                             float* my_f, int nk, int g, int t0, const GenLds& L) {
     f32x4 acc[NG * NTB];
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     gen_layer<NG, H0>(ring, W, gin, nk, acc, L);
-    if (dprev) {
+    if (!SP && dprev) {
+        // relu family: one dword of derivative bits per lane and group
+        uint32_t mb[NG];
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) mb[gq] = (PNDF_GEN_ABLATE & 2) ? 0xffffffffu : __builtin_nontemporal_load(mkprev + (size_t)gq * WG_THREADS);
+#pragma unroll
+        for (int t = 0; t < NG * NTB; ++t) {
+            const f32x4 go = acc[t] * gen_dfac_bits(mb[t / NTB], t % NTB, slope);
+            if (!(PNDF_GEN_ABLATE & 1) || t == 0) gen_store(gout + (size_t)t * SLOT_F4, go);
+            else asm volatile("" : : "v"(go));
+            if (t % NTB == NTB - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if (dprev) {
         // x act'(z_{l-1}), a group of tiles at a time with the NEXT group's derivative factors already on their way: in program order
         // L0 | L1 S0 | L2 S1 | ..., so the counted wait hipcc puts in front of a group's multiplies (vmcnt counts loads and stores alike,
         // in order) never includes a store.  With load - multiply - store group after group, every group's loads queued behind the
         // previous group's stores: 3 ms of a 30 ms launch (arms 1, 2 and 3 of PNDF_GEN_ABLATE, profiles/r06/generic_ablate.txt).
         f32x4 dp[2][NTB];
 #pragma unroll
-        for (int j = 0; j < NTB; ++j) dp[0][j] = (PNDF_GEN_ABLATE & 2) ? f32x4{1.f, 1.f, 1.f, 1.f} : dprev[(size_t)j * SLOT_F4];
+        for (int j = 0; j < NTB; ++j) dp[0][j] = (PNDF_GEN_ABLATE & 2) ? f32x4{1.f, 1.f, 1.f, 1.f} : gen_load_d(dprev + (size_t)j * SLOT_F4);
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
             if (gq + 1 < NG) {
 #pragma unroll
                 for (int j = 0; j < NTB; ++j)
-                    dp[(gq + 1) & 1][j] = (PNDF_GEN_ABLATE & 2) ? f32x4{1.f, 1.f, 1.f, 1.f} : dprev[(size_t)((gq + 1) * NTB + j) * SLOT_F4];
+                    dp[(gq + 1) & 1][j] = (PNDF_GEN_ABLATE & 2) ? f32x4{1.f, 1.f, 1.f, 1.f} : gen_load_d(dprev + (size_t)((gq + 1) * NTB + j) * SLOT_F4);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -400,7 +450,7 @@ __device__ __forceinline__ void gen_layer_split(Ring& ring, GenWS& W, const char
     };
     dma_blk(0, 0);
     dma_blk(nkb > 1 ? 1 : 0, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(PNDF_GEN_ABLATE & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GBlk xc, xn;
     {
         const f32x4 ra = *(const f32x4*)L.x_ptr, rb = *(const f32x4*)(L.x_ptr + TILE_BYTES);
@@ -410,7 +460,7 @@ __device__ __forceinline__ void gen_layer_split(Ring& ring, GenWS& W, const char
     uint32_t xb = 0;
     for (int kb = 0; kb < nkb; ++kb) {
         const uint32_t xb1 = (xb == GX_BUFS - 1) ? 0u : xb + 1, xb2 = (xb1 == GX_BUFS - 1) ? 0u : xb1 + 1;
-        dma_blk((kb + 2 < nkb) ? kb + 2 : nkb - 1, xb2);
+        if (!(PNDF_GEN_ABLATE & 4)) dma_blk((kb + 2 < nkb) ? kb + 2 : nkb - 1, xb2);
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             DmaSrc src{nullptr, 0u};
@@ -453,13 +503,13 @@ __device__ __forceinline__ void gen_layer_split(Ring& ring, GenWS& W, const char
 }
 
 template <int NG, bool SP>
-__device__ __forceinline__ void gen_forward_split(Ring& ring, GenWS& W, const float* bias, const char* xin, f32x4* xout, f32x4* dl, int nkb, bool last,
-                                                  float slope, const SpK& k, int g, f32x4& zlast, const GenLds& L, float sigma, float to_true,
-                                                  float& amax) {
+__device__ __forceinline__ void gen_forward_split(Ring& ring, GenWS& W, const float* bias, const char* xin, f32x4* xout, f32x4* dl, uint32_t* mk, int nkb,
+                                                  bool last, float slope, const SpK& k, int g, f32x4& zlast, const GenLds& L, float sigma,
+                                                  float to_true, float& amax) {
     const float bscale = gen_pow2_rcp(to_true);
     f32x4 acc[NG * NTB];
 #pragma unroll
-    for (int t = 0; t < NG * NTB; ++t) acc[t] = *(const f32x4*)(bias + 16 * t + 4 * g) * bscale;
+    for (int t = 0; t < NG * NTB; ++t) acc[t] = (PNDF_GEN_ABLATE & 8) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(bias + 16 * t + 4 * g) * bscale;
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) asm volatile("" : "+v"(acc[t]));      // (see gen_forward)
     gen_layer_split<NG>(ring, W, xin, nkb, sigma, acc, L);
@@ -467,33 +517,58 @@ __device__ __forceinline__ void gen_forward_split(Ring& ring, GenWS& W, const fl
         zlast = acc[0] * to_true;
         return;
     }
+    uint32_t bits = 0;
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) {
-        f32x4 z = acc[t] * to_true, df;
-        gen_act<SP>(z, df, slope, k);
+        f32x4 z = acc[t] * to_true, df = z;
+        if constexpr (SP) gen_act<SP>(z, df, slope, k);
+        else gen_act_bits(z, slope, bits, t % NTB);
         amax = gen_absmax4(amax, z);
-        gen_store(xout + (size_t)t * SLOT_F4, z);
-        gen_store(dl + (size_t)t * SLOT_F4, df);
-        if (t % NTB == NTB - 1) __builtin_amdgcn_sched_barrier(0);
+        if (!(PNDF_GEN_ABLATE & 1) || t == 0) {
+            gen_store(xout + (size_t)t * SLOT_F4, z);
+            if constexpr (SP) gen_store(dl + (size_t)t * SLOT_F4, df);
+        } else {
+            asm volatile("" : : "v"(z), "v"(df));
+        }
+        if (t % NTB == NTB - 1) {
+            if constexpr (!SP) {
+                __builtin_nontemporal_store(bits, mk + (size_t)(t / NTB) * WG_THREADS);
+                bits = 0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
-template <int NG>
-__device__ __forceinline__ void gen_backward_split(Ring& ring, GenWS& W, const char* gin, f32x4* gout, const f32x4* dprev, float* my_f, int nkb, int g,
-                                                   int t0, const GenLds& L, float sigma, float to_true, float& amax) {
+template <int NG, bool SP>
+__device__ __forceinline__ void gen_backward_split(Ring& ring, GenWS& W, const char* gin, f32x4* gout, const f32x4* dprev, const uint32_t* mkprev, float slope,
+                                                   float* my_f, int nkb, int g, int t0, const GenLds& L, float sigma, float to_true, float& amax) {
     f32x4 acc[NG * NTB];
 #pragma unroll
     for (int t = 0; t < NG * NTB; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     gen_layer_split<NG>(ring, W, gin, nkb, sigma, acc, L);
-    if (dprev) {                   // (the loads one group ahead of the stores: see gen_backward)
+    if (!SP && dprev) {            // relu family: derivative bits (see gen_backward)
+        uint32_t mb[NG];
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) mb[gq] = (PNDF_GEN_ABLATE & 2) ? 0xffffffffu : __builtin_nontemporal_load(mkprev + (size_t)gq * WG_THREADS);
+#pragma unroll
+        for (int t = 0; t < NG * NTB; ++t) {
+            const f32x4 go = (acc[t] * to_true) * gen_dfac_bits(mb[t / NTB], t % NTB, slope);
+            amax = gen_absmax4(amax, go);
+            if (!(PNDF_GEN_ABLATE & 1) || t == 0) gen_store(gout + (size_t)t * SLOT_F4, go);
+            else asm volatile("" : : "v"(go));
+            if (t % NTB == NTB - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if (dprev) {            // (the loads one group ahead of the stores: see gen_backward)
         f32x4 dp[2][NTB];
 #pragma unroll
-        for (int j = 0; j < NTB; ++j) dp[0][j] = dprev[(size_t)j * SLOT_F4];
+        for (int j = 0; j < NTB; ++j) dp[0][j] = (PNDF_GEN_ABLATE & 2) ? f32x4{1.f, 1.f, 1.f, 1.f} : gen_load_d(dprev + (size_t)j * SLOT_F4);
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
             if (gq + 1 < NG) {
 #pragma unroll
-                for (int j = 0; j < NTB; ++j) dp[(gq + 1) & 1][j] = dprev[(size_t)((gq + 1) * NTB + j) * SLOT_F4];
+                for (int j = 0; j < NTB; ++j)
+                    dp[(gq + 1) & 1][j] = (PNDF_GEN_ABLATE & 2) ? f32x4{1.f, 1.f, 1.f, 1.f} : gen_load_d(dprev + (size_t)((gq + 1) * NTB + j) * SLOT_F4);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -501,7 +576,8 @@ __device__ __forceinline__ void gen_backward_split(Ring& ring, GenWS& W, const c
                 const int t = gq * NTB + j;
                 const f32x4 go = (acc[t] * to_true) * dp[gq & 1][j];
                 amax = gen_absmax4(amax, go);
-                gen_store(gout + (size_t)t * SLOT_F4, go);
+                if (!(PNDF_GEN_ABLATE & 1) || t == 0) gen_store(gout + (size_t)t * SLOT_F4, go);
+                else asm volatile("" : : "v"(go));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -636,13 +712,14 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                     const int nkb = args.kb[l], ng = args.ntp[l] / NTB;
                     const float* bias = args.lbias + args.b_off[l];
                     f32x4* dl = wg + (size_t)args.d_off[l] * SLOT_F4;
+                    uint32_t* mk = (uint32_t*)(wg - tid + (size_t)args.d_off[l] * SLOT_F4) + tid;      // relu family: a dword per lane and group
                     const float sigma = gen_pose_scale(gen_pose_max(amax));
                     const float to_true = args.w_inv[l] * gen_pow2_rcp(sigma);
                     amax = 0.f;
                     for (int g0 = 0; g0 < ng; g0 += GEN_PASS_GROUPS) {
                         const int n = (ng - g0 < GEN_PASS_GROUPS) ? ng - g0 : GEN_PASS_GROUPS, t0 = g0 * NTB;
                         switch (n) {
-#define PNDF_GEN_FWDS(N) case N: gen_forward_split<N, SP>(ring, wsp, bias + 16 * t0, xuni[l & 1], xbuf[(l + 1) & 1] + (size_t)t0 * SLOT_F4, dl + (size_t)t0 * SLOT_F4, nkb, l == L - 1, args.slope, ap.k, g, zlast, gl, sigma, to_true, amax); break;
+#define PNDF_GEN_FWDS(N) case N: gen_forward_split<N, SP>(ring, wsp, bias + 16 * t0, xuni[l & 1], xbuf[(l + 1) & 1] + (size_t)t0 * SLOT_F4, dl + (size_t)t0 * SLOT_F4, mk + (size_t)g0 * WG_THREADS, nkb, l == L - 1, args.slope, ap.k, g, zlast, gl, sigma, to_true, amax); break;
                             PNDF_GEN_FWDS(1) PNDF_GEN_FWDS(2) PNDF_GEN_FWDS(3) PNDF_GEN_FWDS(4)
 #undef PNDF_GEN_FWDS
                             default: break;
@@ -655,10 +732,11 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                 const int nk = args.kt[l], ng = args.ntp[l] / NTB;
                 const float* bias = args.lbias + args.b_off[l];
                 f32x4* dl = wg + (size_t)args.d_off[l] * SLOT_F4;
+                uint32_t* mk = (uint32_t*)(wg - tid + (size_t)args.d_off[l] * SLOT_F4) + tid;          // relu family: a dword per lane and group
                 for (int g0 = 0; g0 < ng; g0 += GEN_PASS_GROUPS) {      // passes of at most 8 groups of output tiles
                     const int n = (ng - g0 < GEN_PASS_GROUPS) ? ng - g0 : GEN_PASS_GROUPS, t0 = g0 * NTB;
                     switch (2 * n + half) {      // (stream order: [pass][k tile][tile of the pass])
-#define PNDF_GEN_FWD(N, H) case 2 * N + H: gen_forward<N, H, SP>(ring, wcur, bias + 16 * t0, xuni[l & 1], xbuf[(l + 1) & 1] + (size_t)t0 * SLOT_F4, dl + (size_t)t0 * SLOT_F4, nk, l == L - 1, args.slope, ap.k, g, zlast, gl); break;
+#define PNDF_GEN_FWD(N, H) case 2 * N + H: gen_forward<N, H, SP>(ring, wcur, bias + 16 * t0, xuni[l & 1], xbuf[(l + 1) & 1] + (size_t)t0 * SLOT_F4, dl + (size_t)t0 * SLOT_F4, mk + (size_t)g0 * WG_THREADS, nk, l == L - 1, args.slope, ap.k, g, zlast, gl); break;
                         PNDF_GEN_GROUP_CASES(PNDF_GEN_FWD)
 #undef PNDF_GEN_FWD
                         default: break;      // (pndf_generic_create plans no other group count)
@@ -699,13 +777,14 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                 for (int l = L - 1; l >= 0; --l) {
                     const int nkb = args.nb[l], ng = args.ktp[l] / NTB;
                     const f32x4* dprev = (l > 0) ? wg + (size_t)args.d_off[l - 1] * SLOT_F4 : nullptr;
+                    const uint32_t* mkprev = (const uint32_t*)(wg - tid + (size_t)args.d_off[l > 0 ? l - 1 : 0] * SLOT_F4) + tid;
                     const float sigma = gen_pose_scale(gen_pose_max(amax));
                     const float to_true = args.w_inv[l] * gen_pow2_rcp(sigma);
                     amax = 0.f;
                     for (int g0 = 0; g0 < ng; g0 += GEN_PASS_GROUPS) {
                         const int n = (ng - g0 < GEN_PASS_GROUPS) ? ng - g0 : GEN_PASS_GROUPS, t0 = g0 * NTB;
                         switch (n) {
-#define PNDF_GEN_BWDS(N) case N: gen_backward_split<N>(ring, wsp, xuni[cur], xbuf[cur ^ 1] + (size_t)t0 * SLOT_F4, dprev ? dprev + (size_t)t0 * SLOT_F4 : nullptr, my_f, nkb, g, t0, gl, sigma, to_true, amax); break;
+#define PNDF_GEN_BWDS(N) case N: gen_backward_split<N, SP>(ring, wsp, xuni[cur], xbuf[cur ^ 1] + (size_t)t0 * SLOT_F4, dprev ? dprev + (size_t)t0 * SLOT_F4 : nullptr, mkprev + (size_t)g0 * WG_THREADS, args.slope, my_f, nkb, g, t0, gl, sigma, to_true, amax); break;
                             PNDF_GEN_BWDS(1) PNDF_GEN_BWDS(2) PNDF_GEN_BWDS(3) PNDF_GEN_BWDS(4)
 #undef PNDF_GEN_BWDS
                             default: break;
@@ -718,10 +797,11 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
             for (int l = L - 1; l >= 0; --l) {
                 const int nk = args.nt[l], ng = args.ktp[l] / NTB;
                 const f32x4* dprev = (l > 0) ? wg + (size_t)args.d_off[l - 1] * SLOT_F4 : nullptr;
+                const uint32_t* mkprev = (const uint32_t*)(wg - tid + (size_t)args.d_off[l > 0 ? l - 1 : 0] * SLOT_F4) + tid;
                 for (int g0 = 0; g0 < ng; g0 += GEN_PASS_GROUPS) {
                     const int n = (ng - g0 < GEN_PASS_GROUPS) ? ng - g0 : GEN_PASS_GROUPS, t0 = g0 * NTB;
                     switch (2 * n + half) {
-#define PNDF_GEN_BWD(N, H) case 2 * N + H: gen_backward<N, H>(ring, wcur, xuni[cur], xbuf[cur ^ 1] + (size_t)t0 * SLOT_F4, dprev ? dprev + (size_t)t0 * SLOT_F4 : nullptr, my_f, nk, g, t0, gl); break;
+#define PNDF_GEN_BWD(N, H) case 2 * N + H: gen_backward<N, H, SP>(ring, wcur, xuni[cur], xbuf[cur ^ 1] + (size_t)t0 * SLOT_F4, dprev ? dprev + (size_t)t0 * SLOT_F4 : nullptr, mkprev + (size_t)g0 * WG_THREADS, args.slope, my_f, nk, g, t0, gl); break;
                         PNDF_GEN_GROUP_CASES(PNDF_GEN_BWD)
 #undef PNDF_GEN_BWD
                         default: break;
