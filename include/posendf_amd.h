@@ -57,7 +57,8 @@ typedef struct {
                                encoder-less model (model.StrEnc.use = False, model/posendf.py:40-42,73-74).  `dims` is the
                                reference's free list (net_modules.py:14-28): six hidden widths within amass.yaml's run on the
                                fused kernels (narrower ones zero padded); any other n_dims 3 .. 9 with hidden widths 1 .. 1024
-                               runs on the runtime-planned kernels (exact fp32); beyond that PNDF_ERR_UNSUPPORTED */
+                               runs on the runtime-planned kernels (exact fp32, or split-precision
+                               fp16 MFMAs for PNDF_PREC_F16X3 / _F16); beyond that PNDF_ERR_UNSUPPORTED */
     int32_t parent[32];     /* net_utils.py:46 */
     int32_t precision;      /* pndf_precision: arithmetic of the trunk (engine knob, no reference counterpart) */
     int32_t enc_act;        /* model.StrEnc.act when it differs from model.DFNet.act (net_modules.py:128 reads its own key);

@@ -6,8 +6,9 @@
 // 1 .. 1024 -- runs here, with the same ownership (a workgroup = 4 waves = 64 poses for the whole call, one persistent launch for
 // all projection steps), the same MFMA encoder, normalisation and update code (pndf_device.h), and the trunk LAYER BY LAYER from a
 // plan that travels in the kernel arguments:
-//   * arithmetic: exact fp32 (v_mfma_f32_16x16x4_f32, fp32 accumulate from the bias), the same operation order as
-//     pndf_fused_relu_kernel -- whatever `precision` the handle asked for (a request for speed, not for less accuracy);
+//   * arithmetic: precision fp32 -- exact fp32 (v_mfma_f32_16x16x4_f32, fp32 accumulate from the bias), the same operation order as
+//     pndf_fused_relu_kernel; precision f16x3 / f16 -- the same plan on split-precision fp16 MFMAs (pndf_generic_split_*_kernel,
+//     "the same trunk on split-precision fp16 MFMAs" below), unless a layer cannot be scaled into the fp16 range;
 //   * transposed like the fused kernels: D tile = 16 rows x the wave's 16 poses, and a D tile is the B operand of the next
 //     layer as it stands (pndf_layout.h), so activations are never transposed;
 //   * what does not fit the register file at run-time widths lives in a per-workgroup global scratch that only ITS OWN lane ever
@@ -25,8 +26,9 @@
 //     barrier in the middle of a slot); see "the trunk's weight ring" and gen_layer below for the forms that were measured before it.
 // Roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic work per pose-step 4 x sum_l in_l out_l FLOP.  Not the benchmark path
 // (BASELINE.json names amass.yaml).  Measured (tools/bench_generic.py, B = 65,536 x 10 steps, profiles/r06/generic_arch*.jsonl), as a
-// fraction of the fp32 MFMA peak: 0.78 on configs/amass.yaml itself (PNDF_FORCE_GENERIC=1; the fused exact-fp32 kernel: 0.89), 0.72
-// with Softplus, 0.82 on 512-1024-1024-640-256-128; where the rest goes: profiles/r06/generic_ablate.txt.
+// fraction of the fp32 MFMA peak: 0.80 on configs/amass.yaml itself (PNDF_FORCE_GENERIC=1; the fused exact-fp32 kernel: 0.89), 0.73
+// with Softplus, 0.83 on 512-1024-1024-640-256-128; the split-precision form: 13.5 ms per launch against 28.5 ms (the fused split
+// kernel: 9.4 ms); where the rest goes: profiles/r06/generic_ablate.txt.
 #include "pndf_device.h"
 
 #include <stdlib.h>

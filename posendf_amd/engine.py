@@ -272,7 +272,7 @@ class Engine:
         if hidden is not None:
             # model.DFNet.dims (reference net_modules.py:14-28: a free list).  Six hidden widths within configs/amass.yaml's run on
             # the fused kernels (narrower ones zero padded); any other list of 1 .. 7 widths up to 1024 on the runtime-planned
-            # kernels (csrc/pndf_generic.hip, exact fp32); pndf_create refuses the rest
+            # kernels (csrc/pndf_generic.hip: exact fp32, or split-precision fp16 MFMAs for f16x3 / f16); pndf_create refuses the rest
             hidden = [int(w) for w in hidden]
             if not 1 <= len(hidden) <= 7:
                 raise PndfError(f"DFNet with {len(hidden)} hidden layers: 1 .. 7 are implemented")
