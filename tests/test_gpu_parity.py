@@ -304,7 +304,7 @@ def test_weight_reload_and_errors(torch_cuda):
         PoseNDF(cfg)(q, train=False)
     cfg["model"]["DFNet"]["dims"] = [256, 512, 1024, 512, 256]         # another depth RUNS (runtime-planned kernels, tests/test_depth.py)
     other = PoseNDF(cfg)
-    assert other(q, train=False)["dist_pred"].shape == (64, 1) and other._engine_for(q.device).kernel_name() == "pndf_generic_relu_kernel"
+    assert other(q, train=False)["dist_pred"].shape == (64, 1) and other._engine_for(q.device).kernel_name() == "pndf_generic_split_relu_kernel"      # (default precision f16x3)
     with pytest.raises(RuntimeError):                      # no double backward on the engine path
         qq = q.clone().requires_grad_(True)
         dd = net(qq, train=False)["dist_pred"]

@@ -3,5 +3,5 @@
 set -u
 OUT=gpurun_out/r6_29
 mkdir -p $OUT
-timeout 2400 python -m pytest tests -m gpu -q -x --durations=8 > $OUT/pytest_gpu.txt 2>&1
+timeout 2400 python -m pytest tests -m gpu -q --durations=8 > $OUT/pytest_gpu.txt 2>&1
 echo "gpu suite rc=$?"; tail -14 $OUT/pytest_gpu.txt
