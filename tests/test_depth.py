@@ -236,8 +236,9 @@ def live_weights(dims, act):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])      # the exact and the split-precision form of the runtime-planned kernels
 @pytest.mark.parametrize("hidden,act,enc", EXTREMES, ids=lambda v: "-".join(map(str, v)) if isinstance(v, list) else str(v))
-def test_runtime_planned_kernels_width_and_depth_extremes(hidden, act, enc):
+def test_runtime_planned_kernels_width_and_depth_extremes(hidden, act, enc, precision):
     """Hidden widths 1, 15 - 17, one past a tile / a pass / 512, 1024; one to seven hidden layers; bottlenecks of a few units between
     1024-wide layers: single step and a 3-step projection against the numpy oracle (fp64 truth, the fp32 oracle's own noise as the
     envelope), through the per-pose gates."""
@@ -247,16 +248,19 @@ def test_runtime_planned_kernels_width_and_depth_extremes(hidden, act, enc):
     assert torch.cuda.is_available(), "GPU tests need a visible MI355X (no CPU fallback exists)"
     dims = (126 if enc else 84, *hidden, 1)
     sd = live_weights(dims, act)
-    net = PoseNDF(config_for(hidden, act, enc, "cuda:0"))
+    cfg = config_for(hidden, act, enc, "cuda:0")
+    cfg["engine"] = {"precision": precision}
+    net = PoseNDF(cfg)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     net.eval()
     q_np = np.concatenate([synth.make_poses(100, seed=61), synth.make_poses(100, seed=62, signed=True)])
     q = torch.from_numpy(q_np).cuda().requires_grad_(True)
     d = net(q, train=False)["dist_pred"]
     (dq,) = torch.autograd.grad(d.sum(), q)
-    assert net._engine_for(q.device).kernel_name().startswith("pndf_generic_")
+    assert net._engine_for(q.device).kernel_name().startswith("pndf_generic_split_" if precision == "f16x3" else "pndf_generic_")
+    assert ("_split_" in net._engine_for(q.device).kernel_name()) == (precision == "f16x3")
     sig_d, sig_g, d64, g64 = fp32_noise(q_np, sd, act)
-    what = f"{hidden} {act} enc={enc}"
+    what = f"{hidden} {act} enc={enc} {precision}"
     # (`escalate`, as in the held-out sweep of tests/test_gpu_sweep.py: a pose over the cheap envelope is held to twice the reference
     # arithmetic's own variability there, measured properly -- the 3-unit bottlenecks of these networks make single poses ill-conditioned:
     # pose 20 of [7, 1024, 5, 1024, 3, 1024, 9]: cheap sigma 5e-6, 32 perturbed fp32 evaluations of the oracle 4.7e-5)
