@@ -735,7 +735,7 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                 const float* bias = args.lbias + args.b_off[l];
                 f32x4* dl = wg + (size_t)args.d_off[l] * SLOT_F4;
                 uint32_t* mk = (uint32_t*)(wg - tid + (size_t)args.d_off[l] * SLOT_F4) + tid;          // relu family: a dword per lane and group
-                for (int g0 = 0; g0 < ng; g0 += GEN_PASS_GROUPS) {      // passes of at most 8 groups of output tiles
+                for (int g0 = 0; g0 < ng; g0 += GEN_PASS_GROUPS) {      // passes of at most 4 groups of output tiles
                     const int n = (ng - g0 < GEN_PASS_GROUPS) ? ng - g0 : GEN_PASS_GROUPS, t0 = g0 * NTB;
                     switch (2 * n + half) {      // (stream order: [pass][k tile][tile of the pass])
 #define PNDF_GEN_FWD(N, H) case 2 * N + H: gen_forward<N, H, SP>(ring, wcur, bias + 16 * t0, xuni[l & 1], xbuf[(l + 1) & 1] + (size_t)t0 * SLOT_F4, dl + (size_t)t0 * SLOT_F4, mk + (size_t)g0 * WG_THREADS, nk, l == L - 1, args.slope, ap.k, g, zlast, gl); break;
@@ -963,7 +963,7 @@ static gen_kernel_t gen_kernel(const pndf_config& cfg, bool split, const char** 
 // tiles -> tiles rounded up to a group count the layer code exists for (PNDF_GEN_GROUP_CASES)
 static inline int gen_round_tiles(int tiles) {
     const int groups = ceil_div(tiles, NTB);
-    const int full = (groups - 1) / GEN_PASS_GROUPS * GEN_PASS_GROUPS, rest = groups - full;      // whole passes of 8 groups + a last one
+    const int full = (groups - 1) / GEN_PASS_GROUPS * GEN_PASS_GROUPS, rest = groups - full;      // whole passes of 4 groups + a last one
     return (full + rest) * NTB;      // (every 1 .. GEN_PASS_GROUPS groups of a last pass have their instantiation: PNDF_GEN_GROUP_CASES)
 }
 
