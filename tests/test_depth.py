@@ -272,3 +272,37 @@ def test_runtime_planned_kernels_width_and_depth_extremes(hidden, act, enc, prec
     q32, _ = onp.project(q_np, sd, steps=3, act=act)
     env = traj_envelope(q_np, sd, act, 3, q64)
     outlier_gate(rel_err_rows(qp.cpu().numpy(), q64), rel_err_rows(q32, q64), TOL, what + " project 3", margin=env["margin"], sigma=env["sigma"])
+
+
+@pytest.mark.gpu
+def test_runtime_planned_reload_switches_between_the_two_forms():
+    """precision f16x3 on a runtime-planned network: the split-precision form -- unless a layer has no finite non-zero weight (it cannot
+    be scaled into the fp16 range), in which case the SAME handle runs the exact fp32 form after that load, and the split form again
+    after the next one (csrc/pndf_generic.hip pndf_generic_load re-plans the stream per load)."""
+    import torch
+    from oracle import posendf_np as onp
+    from posendf_amd import PoseNDF, synth
+    hidden, act = [96, 200, 40], "lrelu"
+    dims = (126, *hidden, 1)
+    sd = live_weights(dims, act)
+    net = PoseNDF(config_for(hidden, act, True, "cuda:0"))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    q_np = synth.make_poses(96, seed=63)
+    q = torch.from_numpy(q_np).cuda()
+    eng = net._engine_for(q.device)
+    p1, d1 = net.project(q, steps=3)
+    assert eng.kernel_name() == "pndf_generic_split_relu_kernel"
+    dead = {k: v.copy() for k, v in sd.items()}
+    dead["dfnet.lin1.weight"][:] = 0.0                       # a layer of zeros: d = act(b) downstream, finite, but unscalable
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in dead.items()})
+    p2, d2 = net.project(q, steps=3)
+    eng = net._engine_for(q.device)
+    assert eng.kernel_name() == "pndf_generic_relu_kernel"
+    q64, d64 = onp.project(q_np, dead, steps=3, act=act, dtype=np.float64)
+    assert np.isfinite(p2.cpu().numpy()).all()
+    assert np.abs(p2.cpu().numpy().reshape(q64.shape) - q64).max() < 1e-5 and np.abs(d2.cpu().numpy().reshape(-1) - d64.reshape(-1)).max() < 1e-5
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    p3, d3 = net.project(q, steps=3)
+    assert net._engine_for(q.device).kernel_name() == "pndf_generic_split_relu_kernel"
+    assert torch.equal(p1, p3) and torch.equal(d1, d3)
