@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """The runtime-planned kernels (csrc/pndf_generic.hip) on one GPU: project(B = 65,536, 10 steps) for the depth / width cases of
 tests/golden/make_golden_depth.py, and for configs/amass.yaml itself against the fused exact-fp32 kernel (PNDF_FORCE_GENERIC=1 in a
-child process).  Prints one JSON line per arm: kernel, ms, algorithmic TFLOP/s (4 x sum in x out FLOP per pose-step), fraction of the
-fp32 MFMA peak.  usage: python tools/bench_generic.py > profiles/r06/generic_arch.jsonl"""
+child process), exact fp32 form and split-precision form (precision f16x3: arms 10 ..).  Prints one JSON line per arm: kernel, ms,
+algorithmic TFLOP/s (4 x sum in x out FLOP per pose-step), fraction of the fp32 (fp16 for the split arms) MFMA peak.
+usage: python tools/bench_generic.py [arm ...] > profiles/r06/generic_arch.jsonl"""
 import json
 import os
 import subprocess
