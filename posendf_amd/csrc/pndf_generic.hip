@@ -393,6 +393,15 @@ __device__ __forceinline__ float gen_pose_scale(float bound) {
     e = e < 100u ? 100u : (e > 180u ? 180u : e);
     return __builtin_bit_cast(float, (267u - e) << 23);
 }
+// The same for a GRADIENT tensor, whose magnitude has no floor: behind a one-unit Softplus layer in its saturated branch the whole
+// gradient of a pose is e^(beta z) ~ 1e-20 -- in fp32's range, and 2^-40 of clamp away from a normal fp16 (found by tools/sweep_generic.py:
+// 100 % error on such poses).  No bias enters the backward accumulators, so the scale may be as large as fp32 carries the reciprocal of
+// s_l sigma: bounds down to 2^-80 keep their place in the fp16 range.
+__device__ __forceinline__ float gen_pose_scale_grad(float bound) {
+    uint32_t e = (__builtin_bit_cast(uint32_t, bound) >> 23) & 0xffu;
+    e = e < 47u ? 47u : (e > 180u ? 180u : e);
+    return __builtin_bit_cast(float, (267u - e) << 23);
+}
 __device__ __forceinline__ float gen_pow2_rcp(float p) { return __builtin_bit_cast(float, 0x7F000000u - __builtin_bit_cast(uint32_t, p)); }
 // a pose's rows live in the four lane groups (lane = 16 g + p): maximum over them
 __device__ __forceinline__ float gen_pose_max(float m) {
@@ -780,7 +789,7 @@ __device__ __forceinline__ void pndf_generic_body(const PndfGenericArgs& args) {
                     const int nkb = args.nb[l], ng = args.ktp[l] / NTB;
                     const f32x4* dprev = (l > 0) ? wg + (size_t)args.d_off[l - 1] * SLOT_F4 : nullptr;
                     const uint32_t* mkprev = (const uint32_t*)(wg - tid + (size_t)args.d_off[l > 0 ? l - 1 : 0] * SLOT_F4) + tid;
-                    const float sigma = gen_pose_scale(gen_pose_max(amax));
+                    const float sigma = gen_pose_scale_grad(gen_pose_max(amax));
                     const float to_true = args.w_inv[l] * gen_pow2_rcp(sigma);
                     amax = 0.f;
                     for (int g0 = 0; g0 < ng; g0 += GEN_PASS_GROUPS) {

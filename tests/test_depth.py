@@ -219,7 +219,10 @@ EXTREMES = [([1], "lrelu", True), ([16], "relu", True), ([17], "softplus", True)
             # three groups per pass (the k steps of such a pass alternate between the halves of a ring slot), passes of 4 + 1 and 4 + 3
             # groups, an even and an odd number of groups in the whole stream (a slot of padding or half a slot behind the trunk)
             ([384], "lrelu", True), ([384, 384], "softplus", True), ([640, 896], "relu", True), ([130, 384, 48], "lrelu", False),
-            ([128], "relu", False), ([128, 128], "lrelu", True)]
+            ([128], "relu", False), ([128, 128], "lrelu", True),
+            # found by tools/sweep_generic.py: behind a ONE-unit Softplus layer the gradient of a pose is e^(beta z) ~ 1e-20 -- the split
+            # form's gradient scale must reach that far (gen_pose_scale_grad)
+            ([65, 347, 385, 256, 81, 1, 2], "softplus", True)]
 
 
 def live_weights(dims, act):
