@@ -945,6 +945,14 @@ bool pndf_generic_needed(const pndf_config& cfg) {
     if (cfg.n_dims != NLIN + 1) return true;
     for (int i = 1; i < NLIN; ++i)
         if (cfg.dims[i] > DIMS[i]) return true;
+    // Softplus networks with a layer of a few units, split precision: behind such a layer a pose's WHOLE gradient is e^(beta z) of a
+    // saturated unit (1e-20 and below), and the fused split kernels' per-pose scale stops at 2^40 -- they lose it (measured:
+    // 126-256-2-1024-512-2-64-1, 49 of 200 poses beyond 1 % in d d/d q, tools/r6/fused_narrow.py); the runtime-planned split kernels' gradient
+    // scale reaches 2^-80 (gen_pose_scale_grad).  With eight units or fewer that can happen; with a whole tile of units it takes every one
+    // of them saturated at once.  (precision fp32: the fused exact kernel has fp32's own range.)
+    if (cfg.act == PNDF_ACT_SOFTPLUS && cfg.precision != PNDF_PREC_FP32)
+        for (int i = 1; i < NLIN; ++i)
+            if (cfg.dims[i] <= 8) return true;
     return false;
 }
 

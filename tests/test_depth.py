@@ -309,3 +309,31 @@ def test_runtime_planned_reload_switches_between_the_two_forms():
     p3, d3 = net.project(q, steps=3)
     assert net._engine_for(q.device).kernel_name() == "pndf_generic_split_relu_kernel"
     assert torch.equal(p1, p3) and torch.equal(d1, d3)
+
+
+@pytest.mark.gpu
+def test_softplus_bottleneck_network_takes_the_runtime_planned_split_kernels():
+    """Six hidden widths within amass.yaml's normally run zero-padded on the fused kernels.  A Softplus network with a layer of a few
+    units is the exception under split precision: behind such a layer a pose's whole gradient is e^(beta z) ~ 1e-20, below what the fused
+    split kernels' per-pose scale (2^-40 .. 2^40) can lift into fp16's range -- 49 of these 200 poses came back beyond 1 % from
+    pndf_fused_split_softplus_kernel (tools/r6/fused_narrow.py); the runtime-planned split kernels scale gradients down to 2^-80."""
+    import torch
+    from oracle import posendf_np as onp
+    from posendf_amd import PoseNDF, synth
+    hidden, act = [256, 2, 1024, 512, 2, 64], "softplus"
+    sd = live_weights((126, *hidden, 1), act)
+    q_np = np.concatenate([synth.make_poses(100, seed=61), synth.make_poses(100, seed=62, signed=True)])
+    sig_d, sig_g, d64, g64 = fp32_noise(q_np, sd, act)
+    for precision, kernel in (("f16x3", "pndf_generic_split_softplus_kernel"), ("fp32", "pndf_fused_softplus_kernel")):
+        cfg = config_for(hidden, act, True, "cuda:0")
+        cfg["engine"] = {"precision": precision}
+        net = PoseNDF(cfg)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net.eval()
+        q = torch.from_numpy(q_np).cuda().requires_grad_(True)
+        d = net(q, train=False)["dist_pred"]
+        (dq,) = torch.autograd.grad(d.sum(), q)
+        assert net._engine_for(q.device).kernel_name() == kernel
+        what = f"{hidden} {act} {precision}"
+        pose_gate(d_rows(d.detach().cpu().numpy(), d64), sig_d, what + " d", escalate=lambda i: escalated_noise(q_np, sd, act, i, d64, kind="d"))
+        pose_gate(rel_err_rows(dq.cpu().numpy(), g64), sig_g, what + " dq", escalate=lambda i: escalated_noise(q_np, sd, act, i, g64, kind="g"))
