@@ -56,7 +56,8 @@ typedef struct {
     int32_t dims[16];       /* 126,256,512,1024,512,256,64,1 (amass.yaml:26,30); dims[0] = 84 selects the
                                encoder-less model (model.StrEnc.use = False, model/posendf.py:40-42,73-74).  `dims` is the
                                reference's free list (net_modules.py:14-28): six hidden widths within amass.yaml's run on the
-                               fused kernels (narrower ones zero padded); any other n_dims 3 .. 9 with hidden widths 1 .. 1024
+                               fused kernels (narrower ones zero padded; softplus with a hidden width <= 8 under split precision: as the
+                               next case); any other n_dims 3 .. 9 with hidden widths 1 .. 1024
                                runs on the runtime-planned kernels (exact fp32, or split-precision
                                fp16 MFMAs for PNDF_PREC_F16X3 / _F16); beyond that PNDF_ERR_UNSUPPORTED */
     int32_t parent[32];     /* net_utils.py:46 */
