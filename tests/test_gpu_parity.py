@@ -448,6 +448,62 @@ def test_large_batch_indexing(torch_cuda, precision):
             assert np.median(rel_err_rows(qp[sl].cpu().numpy(), qp_o)) < TOL / 10
 
 
+@pytest.mark.parametrize("act,precision", [("lrelu", "f16x3"), ("softplus", "f16x3"), ("lrelu", "fp32"), ("lrelu", "generic")])
+def test_maximum_batch_crosses_every_32_bit_boundary(torch_cuda, act, precision):
+    """26,000,003 poses in ONE launch: 2.18e9 floats (past 2^31 elements) and 8.7 GB (past 2^32 bytes) per pose tensor, 406,251
+    workgroups with a ragged tail -- sized for the 288 GB of one MI355X, where the reference's own loop (sample_poses.py:67-74) is
+    bounded by HBM alone.  Poses are generated on the device (sample_poses.py:96-97's distribution).  Every window that straddles a
+    boundary (2^31 bytes, 2^32 bytes, 2^31 elements) and both ends are (i) bit-identical to the same rows launched alone -- a
+    pose's result depends on nothing but the pose -- and (ii) inside the 1e-4 bar against the oracle."""
+    torch = torch_cuda
+    from oracle import posendf_np as onp
+    from posendf_amd import PoseNDF, amass_config, synth
+    B = 26_000_003
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2**30:
+        pytest.skip(f"needs 40 GB of free HBM, the device has {free / 2**30:.0f}")
+    if precision == "generic":          # a runtime-planned network (net_modules.py:14-28: dims is a free list), split form
+        hidden = [96, 200, 40]
+        sd = synth.make_weights(5, 2.0, 0.1, dims=(126, *hidden, 1))
+        cfg = amass_config(act, "cuda:0")
+        cfg["model"]["DFNet"]["dims"] = hidden
+        net = PoseNDF(cfg)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        net.eval()
+    else:
+        sd = golden_weights("live")
+        net = make_net(torch, act, sd=sd, precision=precision)
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    q = torch.rand((B, 21, 4), device="cuda", generator=gen)
+    q /= q.norm(dim=2, keepdim=True)
+    with torch.no_grad():
+        d = net(q, train=False)["dist_pred"]
+    qp, dl = net.project(q, steps=2)
+    assert d.shape == (B, 1) and qp.shape == (B, 21, 4) and dl.shape == (B, 1)
+    row_bytes = 84 * 4
+    starts = {0, B - 70, 2**31 // row_bytes - 35, 2**32 // row_bytes - 35, 2**31 // 84 - 35, 2**33 // row_bytes - 35}
+    for lo in sorted(starts):
+        sl = slice(lo, min(lo + 70, B))
+        qs = q[sl].clone()
+        with torch.no_grad():
+            d_alone = net(qs, train=False)["dist_pred"]
+        qp_alone, dl_alone = net.project(qs, steps=2)
+        assert torch.equal(d[sl], d_alone), f"rows {lo}..: forward differs from the same rows launched alone"
+        assert torch.equal(qp[sl], qp_alone) and torch.equal(dl[sl], dl_alone), f"rows {lo}..: projection differs"
+        qn = qs.cpu().numpy()
+        d_o, _ = onp.forward_grad(qn, sd, act)
+        assert d_err(d[sl, 0].cpu().numpy(), d_o) < TOL
+        qp_o, _ = onp.project(qn, sd, steps=2, act=act)
+        assert np.median(rel_err_rows(qp[sl].cpu().numpy(), qp_o)) < TOL / 10
+    # nothing in between was skipped or written twice: the same poses projected in four launches give the same bits everywhere
+    assert bool(torch.isfinite(d).all())
+    for i in range(0, B, 6_500_001):
+        j = min(i + 6_500_001, B)
+        qp_part, dl_part = net.project(q[i:j], steps=2)
+        assert torch.equal(qp_part, qp[i:j]) and torch.equal(dl_part, dl[i:j]), f"rows {i}..{j}"
+        del qp_part, dl_part
+
+
 def test_precision_auto_selects_by_weight_range(torch_cuda):
     """Default precision 'auto': the split kernel when every trunk layer is inside its operating range, the exact
     fp32 kernel (with a warning) when not -- both are HIP kernels, there is no fallback off the engine."""
