@@ -33,7 +33,9 @@ KERNELS = {"fp32": ("pndf_fused_relu_kernel", PEAK_FP32_MFMA_TFLOPS, "f32"),
            "f16x3": ("pndf_fused_split_relu_kernel", PEAK_F16_MFMA_TFLOPS,
                      "f16x3 (fp32 operands split into fp16 hi+lo, 3 MFMAs per product block, fp32 accumulate)"),
            "f16": ("pndf_fused_half_relu_kernel", PEAK_F16_MFMA_TFLOPS,
-                   "f16 (operands ROUNDED to fp16, fp32 accumulate; NOT within the 1e-4 parity bar)")}
+                   "f16 (operands ROUNDED to fp16, fp32 accumulate; NOT within the 1e-4 parity bar)"),
+           "bf16": ("pndf_fused_bf16_relu_kernel", PEAK_F16_MFMA_TFLOPS,
+                    "bf16 (operands ROUNDED to bfloat16, fp32 accumulate; NOT within the 1e-4 parity bar)")}
 
 
 def _cpu_model():
@@ -588,9 +590,9 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="poses per GPU")
     ap.add_argument("--proj-steps", type=int, default=100)
     ap.add_argument("--act", default="lrelu")
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32", "f16"],
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32", "f16", "bf16"],
                     help="trunk arithmetic of the measured path; f16x3 and fp32 meet the 1e-4 parity gates (tests -m "
-                         "gpu); f16 is the reduced-precision comparison point of BASELINE.json configs[2], not a valid "
+                         "gpu); f16 / bf16 are the reduced-precision comparison points of BASELINE.json configs[2], not a valid "
                          "headline")
     ap.add_argument("--no-fp32-ref", action="store_true",
                     help="skip the short exact-fp32 and plain-f16 runs reported beside f16x3")
@@ -656,7 +658,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     sd = synth.make_weights(0, 2.0, 0.1)                        # BASELINE.md section 3 "live regime"
-    precision = "fp32" if (args.act == "softplus" and args.precision == "f16") else args.precision
+    precision = "fp32" if (args.act == "softplus" and args.precision in ("f16", "bf16")) else args.precision
 
     def build(prec, act=None, weights=None):
         cfg = amass_config(act or args.act, f"cuda:{dev_index}")
@@ -803,7 +805,9 @@ def main():
     # What was timed is also CHECKED: a sample of the projected poses of the last timed pass against the oracle's fp64
     # trajectory of the same inputs, with the reference arithmetic's own fp32 trajectory beside it (outside the timed region;
     # rank 0 only, like the cpu_baseline leg).
-    def parity_sample(n=128):
+    oracle_traj = {}                                            # the oracle's trajectories of the sample, computed once
+
+    def parity_sample(n=128, result=None):
         from oracle import posendf_np as onp
         try:        # 256 hardware threads on the GPU box: keep numpy's BLAS from spreading small matmuls over all of them
             from threadpoolctl import threadpool_limits
@@ -811,17 +815,19 @@ def main():
         except ImportError:
             pass
         idx = np.random.default_rng(0).choice(B, min(n, B), replace=False)
-        q_in = q0[idx].cpu().numpy()
-        q64, _ = onp.project(q_in, sd, steps=args.proj_steps, act=args.act, dtype=np.float64)
-        q32, _ = onp.project(q_in, sd, steps=args.proj_steps, act=args.act)
+        if n not in oracle_traj:
+            q_in = q0[idx].cpu().numpy()
+            oracle_traj[n] = (onp.project(q_in, sd, steps=args.proj_steps, act=args.act, dtype=np.float64)[0],
+                              onp.project(q_in, sd, steps=args.proj_steps, act=args.act)[0])
+        q64, q32 = oracle_traj[n]
 
         def rows(a):
             a = np.asarray(a, np.float64).reshape(len(idx), -1)
             b = q64.reshape(len(idx), -1)
             return np.abs(a - b).max(1) / np.maximum(np.abs(b).max(1), 1e-30)
 
-        mine, ref = rows(qp[idx].cpu().numpy()), rows(q32)
-        return {"what": f"{len(idx)} poses of the last timed pass vs the numpy oracle's fp64 {args.proj_steps}-step trajectory "
+        mine, ref = rows((qp if result is None else result)[idx].cpu().numpy()), rows(q32)
+        return {"what": f"{len(idx)} poses of {'the last timed pass' if result is None else 'this run'} vs the numpy oracle's fp64 {args.proj_steps}-step trajectory "
                         "(per-pose max |dq| / max |q|); `reference_fp32` = the reference arithmetic's own fp32 trajectory",
                 "median": float(np.median(mine)), "p95": float(np.percentile(mine, 95)), "max": float(mine.max()),
                 "reference_fp32": {"median": float(np.median(ref)), "p95": float(np.percentile(ref, 95)), "max": float(ref.max())},
@@ -831,7 +837,7 @@ def main():
 
     # the exact-fp32 and the plain-fp16 kernels beside the split-precision one (same inputs, short runs, outside the
     # timed region): the three points of BASELINE.json configs[2] "fp32 vs bf16"
-    def side_run(prec, act=None, weights=None):
+    def side_run(prec, act=None, weights=None, keep=None):
         ref = build(prec, act, weights)
         ref.project(q0, steps=args.proj_steps)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -845,6 +851,8 @@ def main():
         # agreement with the measured kernel on this batch after the full projection (median per-pose relative difference)
         a, b = qp.reshape(B, -1), q_ref.reshape(B, -1)
         diff = ((a - b).abs().amax(1) / b.abs().amax(1).clamp_min(1e-30)).median().item()
+        if keep is not None:
+            keep.append(q_ref)
         return {"kernel": ref._engine_for(dev).kernel_name(), "kernel_ms": ms, "poses_per_s_per_gpu": B / (ms * 1e-3),
                 "achieved_tflops": tf, "median_rel_diff_of_projected_poses_vs_f16x3": diff}
 
@@ -992,7 +1000,7 @@ def main():
 
     denoise = motion_denoise_block() if (side and diag and not args.no_motion_denoise and args.act != "softplus") else None
 
-    fp32_ref = f16_ref = sp_ref = h16_ref = None
+    fp32_ref = f16_ref = sp_ref = h16_ref = bf16_ref = None
     if precision == "f16x3" and side and args.act != "softplus":
         # the activation of the reference's published checkpoints (sample_poses.py:115, motion_denoise.py:162-163)
         sp_ref = side_run("f16x3", "softplus")
@@ -1009,11 +1017,22 @@ def main():
     if precision == "f16x3" and side:
         fp32_ref = side_run("fp32")
         fp32_ref["frac_of_fp32_mfma_peak"] = fp32_ref["achieved_tflops"] / PEAK_FP32_MFMA_TFLOPS
+    if precision == "f16x3" and side and args.act != "softplus":
+        # the literal second half of BASELINE.json configs[2] "fp32 vs bf16": one bf16 MFMA per product block, same schedule
+        kept = []
+        bf16_ref = side_run("bf16", keep=kept)
+        bf16_ref["frac_of_bf16_mfma_peak"] = bf16_ref["achieved_tflops"] / PEAK_F16_MFMA_TFLOPS
+        if not args.no_parity_sample:
+            bf16_ref["parity_sample"] = parity_sample(result=kept[0])
+        bf16_ref["note"] = ("reduced precision: operands rounded to bfloat16 (8 significant bits), one v_mfma_f32_16x16x32_bf16 per "
+                            "product block; two to three orders of magnitude outside the 1e-4 parity bar "
+                            "(tests/test_gpu_parity.py::test_one_term_kernels_compute_their_stated_arithmetic), a comparison point only")
+        del kept
     if precision == "f16x3" and side and diag and args.act != "softplus":
         f16_ref = side_run("f16")
         f16_ref["frac_of_fp16_mfma_peak"] = f16_ref["achieved_tflops"] / PEAK_F16_MFMA_TFLOPS
         f16_ref["note"] = ("reduced precision: operands rounded to fp16, one MFMA per product block; outside the 1e-4 "
-                           "parity bar (tests/test_gpu_parity.py::test_f16_single_is_a_bounded_approximation), reported "
+                           "parity bar (tests/test_gpu_parity.py::test_one_term_kernels_compute_their_stated_arithmetic), reported "
                            "as a comparison point only")
 
     if rank == 0:
@@ -1047,15 +1066,17 @@ def main():
             "data": "synthetic",
             # (the driver's record keeps ~120 characters of a string: what was measured comes first)
             "config": {"workload": (f"cfg[2] B={B}/GPU x{args.proj_steps} steps {args.act}: "
-                                    + {"f16x3": "f16x3 (fp32-split) timed, fp32 (exact) reported, bf16 not built (f16 dominates it)",
-                                       "fp32": "fp32 (exact) timed", "f16": "f16 (NOT parity grade) timed"}[precision]
+                                    + {"f16x3": "f16x3 (fp32-split) timed; fp32 (exact), bf16 (not parity grade) reported",
+                                       "fp32": "fp32 (exact) timed", "f16": "f16 (NOT parity grade) timed",
+                                       "bf16": "bf16 (NOT parity grade) timed"}[precision]
                                     + f"; BASELINE.json configs[2], {args.proj_steps}-step project() loop, amass.yaml arch, random-init "
                                       "weights (uniform +-2/sqrt(fan_in), lin6.bias=0.1)"),
                        "precision": precision,
                        "precisions": ("f16x3 = fp32 operands split into fp16 hi+lo, 3 MFMAs per block, fp32 accumulate (timed); "
-                                      "fp32 = exact fp32 MFMA (reported beside it: fp32_exact); bf16 of configs[2] not built: fp16 has "
-                                      "3 more mantissa bits at the same MFMA rate (f16_single under --diagnostics, not parity grade)"),
-                       "parity": ("NOT parity grade (fp16-rounded operands)" if precision == "f16" else
+                                      "fp32 = exact fp32 MFMA (reported beside it: fp32_exact); bf16 = operands rounded to bfloat16, "
+                                      "1 MFMA per block (reported beside it: bf16, with its error against the fp64 oracle -- not parity "
+                                      "grade; its fp16 sibling with 3 more mantissa bits at the same rate: f16_single under --diagnostics)"),
+                       "parity": ("NOT parity grade (operands rounded to 16 bits)" if precision in ("f16", "bf16") else
                                   "same 1e-4 gates as the fp32 kernel (tests/test_gpu_parity.py, both precisions)"),
                        "global_batch": B * world, "proj_steps": args.proj_steps,
                        "parallelism": f"batch-sharded x{world}, final RCCL all_gather" if world > 1 else "single GPU"},
@@ -1099,6 +1120,13 @@ def main():
             rl["fp32_exact_poses_per_s"] = fp32_ref["poses_per_s_per_gpu"]
             rl["fp32_exact_kernel_ms"] = fp32_ref["kernel_ms"]
             rl["fp32_exact_frac_of_fp32_mfma_peak"] = fp32_ref["frac_of_fp32_mfma_peak"]
+        if bf16_ref is not None:
+            # (scalars of `roofline` too: the driver's record keeps those)
+            out["bf16"] = bf16_ref
+            rl["bf16_poses_per_s"] = bf16_ref["poses_per_s_per_gpu"]
+            rl["bf16_kernel_ms"] = bf16_ref["kernel_ms"]
+            if "parity_sample" in bf16_ref:
+                rl["bf16_median_rel_err_vs_fp64"] = bf16_ref["parity_sample"]["median"]
         if f16_ref is not None:
             out["f16_single"] = f16_ref
         if sp_ref is not None:

@@ -82,8 +82,12 @@ typedef struct {
  *                  three-term kernels (A/B runs); pndf_kernel_name() tells which one a handle launches.
  * PNDF_PREC_F16  : plain fp16 operands (round to nearest), ONE MFMA per product block, fp32 accumulate.  A measured
  *                  comparison point (BASELINE.json configs[2] "fp32 vs bf16"): ~1e-3 relative, NOT within the 1e-4
- *                  parity bar of the two modes above; never selected implicitly; relu / lrelu only. */
-typedef enum { PNDF_PREC_FP32 = 0, PNDF_PREC_F16X3 = 1, PNDF_PREC_F16 = 2 } pndf_precision;
+ *                  parity bar of the two modes above; never selected implicitly; relu / lrelu only.
+ * PNDF_PREC_BF16 : plain bfloat16 operands (round to nearest even), ONE v_mfma_f32_16x16x32_bf16 per product block, fp32
+ *                  accumulate: the literal second half of BASELINE.json configs[2] "fp32 vs bf16".  Same schedule and rate
+ *                  as PNDF_PREC_F16 with three fewer significant bits (~1e-2 relative): a measured comparison point only;
+ *                  never selected implicitly; relu / lrelu only; amass.yaml-shaped networks only. */
+typedef enum { PNDF_PREC_FP32 = 0, PNDF_PREC_F16X3 = 1, PNDF_PREC_F16 = 2, PNDF_PREC_BF16 = 3 } pndf_precision;
 
 /* Fills cfg with the configs/amass.yaml architecture and the SMPL parent table. */
 void pndf_default_config(pndf_config* cfg, int32_t act, float beta);

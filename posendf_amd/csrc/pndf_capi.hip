@@ -26,6 +26,7 @@ extern "C" __global__ void pndf_fused_split_softplus_kernel(PndfKernelArgs args)
 extern "C" __global__ void pndf_fused_split2_relu_kernel(PndfKernelArgs args);        // pndf_kernel_split_x2.hip
 extern "C" __global__ void pndf_fused_split2_softplus_kernel(PndfKernelArgs args);
 extern "C" __global__ void pndf_fused_half_relu_kernel(PndfKernelArgs args);
+extern "C" __global__ void pndf_fused_bf16_relu_kernel(PndfKernelArgs args);     // pndf_kernel_bf16.hip
 extern "C" long long pndf_kernel_softplus_scratch_floats_per_wg();
 extern "C" int pndf_kernel_lds_bytes();
 
@@ -73,11 +74,11 @@ static int fail(pndf_engine* h, int code, const std::string& msg) {
 PNDF_EXPORT_EXPERIMENT_WORD(capi)
 extern "C" {
 extern const unsigned pndf_experiment_word_fp32, pndf_experiment_word_split, pndf_experiment_word_split_x2, pndf_experiment_word_lbs,
-    pndf_experiment_word_generic;
+    pndf_experiment_word_generic, pndf_experiment_word_bf16;
 }
 extern "C" unsigned pndf_experiment_word(void) {
     return pndf_experiment_word_capi | pndf_experiment_word_fp32 | pndf_experiment_word_split | pndf_experiment_word_split_x2 |
-           pndf_experiment_word_lbs | pndf_experiment_word_generic;
+           pndf_experiment_word_lbs | pndf_experiment_word_generic | pndf_experiment_word_bf16;
 }
 extern "C" const char* pndf_version(void) {
     static const std::string v = [] {
@@ -129,10 +130,11 @@ static int check_config(pndf_engine* h, const pndf_config* cfg) {
         return fail(h, PNDF_ERR_UNSUPPORTED, "unknown encoder activation (relu, lrelu and softplus are implemented; -1 = the trunk's)");
     if (cfg->enc_act == PNDF_ACT_SOFTPLUS && !(cfg->enc_beta > 0.f) && !(cfg->beta > 0.f))
         return fail(h, PNDF_ERR_BAD_ARG, "softplus beta of the encoder must be positive");
-    if (cfg->precision != PNDF_PREC_FP32 && cfg->precision != PNDF_PREC_F16X3 && cfg->precision != PNDF_PREC_F16)
-        return fail(h, PNDF_ERR_UNSUPPORTED, "unknown precision (fp32, f16x3 and f16 are implemented)");
-    if (cfg->precision == PNDF_PREC_F16 && cfg->act == PNDF_ACT_SOFTPLUS)
-        return fail(h, PNDF_ERR_UNSUPPORTED, "the plain-f16 comparison kernel implements relu / lrelu only");
+    if (cfg->precision != PNDF_PREC_FP32 && cfg->precision != PNDF_PREC_F16X3 && cfg->precision != PNDF_PREC_F16 &&
+        cfg->precision != PNDF_PREC_BF16)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "unknown precision (fp32, f16x3, f16 and bf16 are implemented)");
+    if ((cfg->precision == PNDF_PREC_F16 || cfg->precision == PNDF_PREC_BF16) && cfg->act == PNDF_ACT_SOFTPLUS)
+        return fail(h, PNDF_ERR_UNSUPPORTED, "the plain-f16 / plain-bf16 comparison kernels implement relu / lrelu only");
     return PNDF_OK;
 }
 
@@ -159,6 +161,11 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
     }
     h->resident_wgs = prop.multiProcessorCount;
     if (pndf_generic_needed(*cfg)) {
+        if (cfg->precision == PNDF_PREC_BF16) {
+            delete h;
+            return fail(nullptr, PNDF_ERR_UNSUPPORTED, "the plain-bf16 comparison kernel exists for amass.yaml-shaped networks only "
+                                                       "(the runtime-planned kernels run fp32 or split-precision fp16)");
+        }
         std::string why;
         rc = pndf_generic_create(&h->generic, *cfg, h->resident_wgs, why);
         if (rc != PNDF_OK) {
@@ -191,6 +198,8 @@ extern "C" int pndf_create(pndf_handle* out, const pndf_config* cfg, int device)
         e = hipFuncSetAttribute((const void*)pndf_fused_split2_softplus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_half_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)pndf_fused_bf16_relu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)pndf_fused_softplus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pndf_kernel_lds_bytes());
     if (e != hipSuccess) {
@@ -325,14 +334,25 @@ inline void split_f16(float w, _Float16& hi, _Float16& lo) {
     }
 #endif
 }
-// block(M, nt, kb): hi tile then lo tile, 8 halfs per lane each; returns whether any lo half is non-zero
-bool emit_pair(const Mat& m, int nt, int kb, float* dst, float scale) {
+// fp32 -> bfloat16 bits, round to nearest even (the packer's inputs are finite: pack_host_split refuses a layer that is not)
+inline uint16_t bf16_bits(float w) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, w);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+// block(M, nt, kb): hi tile then lo tile, 8 halfs per lane each; returns whether any lo half is non-zero.
+// `bf16` (precision bf16, the one-term comparison kernel): the hi tile holds bfloat16 bits, the lo tile zeros.
+bool emit_pair(const Mat& m, int nt, int kb, float* dst, float scale, bool bf16) {
     _Float16* hi = (_Float16*)dst;
     _Float16* lo = (_Float16*)(dst + TILE_FLOATS);
     bool any_lo = false;
     for (int lane = 0; lane < 64; ++lane)
         for (int jj = 0; jj < 8; ++jj) {
             const float w = m.at(16 * nt + (lane & 15), 16 * (2 * kb + (jj >> 2)) + 4 * (lane >> 4) + (jj & 3));
+            if (bf16) {
+                hi[lane * 8 + jj] = __builtin_bit_cast(_Float16, bf16_bits(w * scale));
+                lo[lane * 8 + jj] = (_Float16)0;
+                continue;
+            }
             split_f16(w * scale, hi[lane * 8 + jj], lo[lane * 8 + jj]);
             any_lo |= (lo[lane * 8 + jj] != (_Float16)0);
         }
@@ -341,13 +361,13 @@ bool emit_pair(const Mat& m, int nt, int kb, float* dst, float scale) {
 }  // namespace
 
 static int pack_host_split(const float* const* tensors, const int64_t* numel, int n_tensors, float* stream, float* bias,
-                           bool* lo_all_zero);
+                           bool* lo_all_zero, bool bf16 = false);
 extern "C" int pndf_pack_host_split(const float* const* tensors, const int64_t* numel, int n_tensors, float* stream,
                                     float* bias) {
     return pack_host_split(tensors, numel, n_tensors, stream, bias, nullptr);
 }
 static int pack_host_split(const float* const* tensors, const int64_t* numel, int n_tensors, float* stream, float* bias,
-                           bool* lo_all_zero) {
+                           bool* lo_all_zero, bool bf16) {
     // biases and encoder tiles are identical to the fp32 stream (the encoder stays on fp32 MFMA)
     int rc = pndf_pack_host(tensors, numel, n_tensors, stream, bias);
     if (rc != PNDF_OK) return rc;
@@ -407,11 +427,11 @@ static int pack_host_split(const float* const* tensors, const int64_t* numel, in
         const Mat B{lin[2 * P.b_lin], nd.out(P.b_lin), nd.in(P.b_lin), P.transposed};
         auto partA = [&](int c) {
             for (int kb = 0; kb < P.KA / 2; ++kb)
-                for (int ci = 0; ci < P.CT; ++ci, dst += 2 * TILE_FLOATS) any_lo |= emit_pair(A, c * P.CT + ci, kb, dst, wscale[P.a_lin]);
+                for (int ci = 0; ci < P.CT; ++ci, dst += 2 * TILE_FLOATS) any_lo |= emit_pair(A, c * P.CT + ci, kb, dst, wscale[P.a_lin], bf16);
         };
         auto partB = [&](int c) {
             for (int nb = 0; nb < P.NB; ++nb)
-                for (int b = 0; b < P.CT / 2; ++b, dst += 2 * TILE_FLOATS) any_lo |= emit_pair(B, nb, (c * P.CT) / 2 + b, dst, wscale[P.b_lin]);
+                for (int b = 0; b < P.CT / 2; ++b, dst += 2 * TILE_FLOATS) any_lo |= emit_pair(B, nb, (c * P.CT) / 2 + b, dst, wscale[P.b_lin], bf16);
         };
         partA(0);
         for (int c = 0; c < P.NC; ++c) {
@@ -444,7 +464,7 @@ extern "C" int pndf_load_weights(pndf_handle h, const float* const* tensors, con
     std::vector<float> stream((size_t)STEP_TILES * TILE_FLOATS), bias(BIAS_FLOATS);
     bool lo_zero = false;
     const int prc = (h->cfg.precision != PNDF_PREC_FP32)
-                        ? pack_host_split(tensors, numel, n_tensors, stream.data(), bias.data(), &lo_zero)
+                        ? pack_host_split(tensors, numel, n_tensors, stream.data(), bias.data(), &lo_zero, h->cfg.precision == PNDF_PREC_BF16)
                         : pndf_pack_host(tensors, numel, n_tensors, stream.data(), bias.data());
     if (prc == PNDF_ERR_UNSUPPORTED)
         return fail(h, PNDF_ERR_UNSUPPORTED, "a trunk layer has no finite non-zero weight: outside the operating "
@@ -484,6 +504,7 @@ extern "C" const char* pndf_kernel_name(pndf_handle h) {
             if (h->lo_all_zero) return sp ? "pndf_fused_split2_softplus_kernel" : "pndf_fused_split2_relu_kernel";
             return sp ? "pndf_fused_split_softplus_kernel" : "pndf_fused_split_relu_kernel";
         case PNDF_PREC_F16: return "pndf_fused_half_relu_kernel";
+        case PNDF_PREC_BF16: return "pndf_fused_bf16_relu_kernel";
         default: return sp ? "pndf_fused_softplus_kernel" : "pndf_fused_relu_kernel";
     }
 }
@@ -573,6 +594,7 @@ static int launch(pndf_engine* h, int mode, const float* q, const float* gout, f
         void* kargs[] = {&a};
         HIP_TRY(h, hipLaunchKernel(instrumented, grid, block, kargs, pndf_kernel_lds_bytes(), (hipStream_t)stream));
     } else if (half) hipLaunchKernelGGL(pndf_fused_half_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
+    else if (h->cfg.precision == PNDF_PREC_BF16) hipLaunchKernelGGL(pndf_fused_bf16_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else if (split && h->lo_all_zero) hipLaunchKernelGGL(pndf_fused_split2_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else if (split) hipLaunchKernelGGL(pndf_fused_split_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);
     else hipLaunchKernelGGL(pndf_fused_relu_kernel, grid, block, pndf_kernel_lds_bytes(), (hipStream_t)stream, a);

@@ -94,6 +94,7 @@ extern "C" int pndf_debug_project_timing(pndf_handle h, const float* q_in, float
     if (ds.precision == PNDF_PREC_F16X3 && ds.lo_all_zero)
         return g_fail(h, PNDF_ERR_UNSUPPORTED, "no instrumented build of the two-term split kernels (set PNDF_THREE_TERMS=1 to time the three-term ones)");
     if (sp && ds.precision != PNDF_PREC_F16X3) return g_fail(h, PNDF_ERR_UNSUPPORTED, "softplus timing kernel: f16x3 only");
+    if (ds.precision == PNDF_PREC_BF16) return g_fail(h, PNDF_ERR_UNSUPPORTED, "no instrumented build of the plain-bf16 comparison kernel");
     const void* k = sp ? (const void*)pndf_fused_split_softplus_kernel_timing
                     : ds.precision == PNDF_PREC_F16X3 ? (const void*)pndf_fused_split_relu_kernel_timing
                     : ds.precision == PNDF_PREC_F16 ? (const void*)pndf_fused_half_relu_kernel_timing

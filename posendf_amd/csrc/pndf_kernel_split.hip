@@ -28,9 +28,18 @@ struct Pair {         // one weight block: hi tile + lo tile
     f16x8 h, l;
 };
 
+#if defined(PNDF_BF16_TU)
+// Translation unit of the plain-bf16 comparison kernel (pndf_kernel_bf16.hip; BASELINE.json configs[2] "fp32 vs bf16"): the one-term
+// instantiation with the 16 operand bits read as bfloat16 -- same registers, stream layout and schedule, v_mfma_f32_16x16x32_bf16.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mf16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+#else
 __device__ __forceinline__ f32x4 mf16(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+#endif
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -40,10 +49,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <bool SINGLE>
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
     if constexpr (SINGLE) {        // plain fp16 operands: round to nearest, no lo part
+#if defined(PNDF_BF16_TU)          // (plain bf16 operands: one v_cvt_pk_bf16_f32, round to nearest even, NaN stays NaN)
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+#else
         f16x2 r;
         r[0] = (_Float16)a;
         r[1] = (_Float16)b;
         hi = __builtin_bit_cast(unsigned, r);
+#endif
         lo = 0u;
         return;
     }
@@ -1202,6 +1215,13 @@ extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_sof
 }
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_half_relu_kernel_timing(PndfKernelArgs args) {
     pndf_fused_split_body<true, 3 - 2>(args);
+}
+#elif defined(PNDF_BF16_TU)
+// plain-bf16 kernel (precision "bf16"): the other half of BASELINE.json configs[2] "fp32 vs bf16" -- one MFMA per product block,
+// operands rounded to bfloat16 (8 significant bits), fp32 accumulate.  A measured comparison point, two orders of magnitude outside
+// the 1e-4 parity bar; never selected implicitly; relu / lrelu only.
+extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_bf16_relu_kernel(PndfKernelArgs args) {
+    pndf_fused_split_body<false, 1>(args);
 }
 #elif !defined(PNDF_SPLIT_X2_TU)
 extern "C" __global__ void __launch_bounds__(WG_THREADS, 1) pndf_fused_split_relu_kernel(PndfKernelArgs args) {

@@ -103,7 +103,7 @@ static_assert(2 * (phase_a_pairs(PHASES[2]) + phase_b_pairs(PHASES[2])) == phase
 // Experiment switch (split-precision stream and kernels only): chunk size of the two big phases (lin2,lin3) / (lin3^T,lin2^T).
 // 2 = product; 4 = part B's accumulators get chains of six MFMAs per chunk instead of three (DESIGN.md Appendix C 7.1 b).
 // (PNDF_BIG_CT: default in pndf_experiment.h)
-enum Precision { PREC_FP32 = 0, PREC_F16X3 = 1, PREC_F16 = 2 };
+enum Precision { PREC_FP32 = 0, PREC_F16X3 = 1, PREC_F16 = 2, PREC_BF16 = 3 };
 
 // bias block (floats) copied to LDS: b0..b5, then w6 (64), then b6
 constexpr int BIAS_OFF[NLIN] = {0, 256, 768, 1792, 2304, 2560, 2688};

@@ -15,7 +15,7 @@ import numpy as np
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libposendf_amd.so")
 
 ACT_CODES = {"relu": 0, "lrelu": 1, "softplus": 2}
-PRECISION_CODES = {"fp32": 0, "f16x3": 1, "f16": 2}
+PRECISION_CODES = {"fp32": 0, "f16x3": 1, "f16": 2, "bf16": 3}
 
 
 class PndfConfig(ctypes.Structure):
@@ -262,7 +262,7 @@ class Engine:
         if act not in ACT_CODES:
             raise PndfError(f"unknown activation {act!r}")
         if precision not in PRECISION_CODES:
-            raise PndfError(f"unknown precision {precision!r} (fp32, f16x3, f16)")
+            raise PndfError(f"unknown precision {precision!r} (fp32, f16x3, f16, bf16)")
         cfg = PndfConfig()
         self.lib.pndf_default_config(ctypes.byref(cfg), ACT_CODES[act], float(beta))
         cfg.precision = PRECISION_CODES[precision]

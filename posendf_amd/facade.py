@@ -83,7 +83,8 @@ class PoseNDF(nn.Module):
         # engine knob (no reference counterpart): arithmetic of the trunk -- "fp32" (exact fp32 MFMA), "f16x3" (fp16
         # hi/lo split, fp32 accumulate: fp32-class accuracy, same parity gates, ~3x the throughput), "auto" (default:
         # f16x3, or fp32 with a warning when a layer's weights are outside the split's operating range), "f16"
-        # (reduced precision, comparison only); opt["engine"]["precision"] or $PNDF_PRECISION
+        # / "bf16" (reduced precision, ONE MFMA per product block: the measured comparison points of BASELINE.json configs[2] "fp32 vs
+        # bf16", outside the 1e-4 parity bar, relu family only); opt["engine"]["precision"] or $PNDF_PRECISION
         self._precision = (opt.get("engine") or {}).get("precision") or os.environ.get("PNDF_PRECISION", "auto")
         self._act = opt["model"]["DFNet"]["act"]
         self._beta = float(opt["model"]["DFNet"].get("beta", 100.0))
@@ -139,8 +140,8 @@ class PoseNDF(nn.Module):
             entry = self._engines[idx] = [CpuEngine(self._act, self._beta, encoder=self.enc is not None, hidden=self._hidden,
                                                     enc_act=self._enc_act, enc_beta=self._enc_beta), None]
         if entry is None:
-            # the plain-f16 comparison kernel is relu-family only; fp32 and f16x3 implement all three activations
-            prec = "fp32" if (self._act == "softplus" and self._precision == "f16") else self._precision
+            # the plain-f16 / plain-bf16 comparison kernels are relu-family only; fp32 and f16x3 implement all three activations
+            prec = "fp32" if (self._act == "softplus" and self._precision in ("f16", "bf16")) else self._precision
             entry = [Engine(self._act, self._beta, idx, precision="f16x3" if prec == "auto" else prec,
                             encoder=self.enc is not None, hidden=self._hidden, enc_act=self._enc_act, enc_beta=self._enc_beta), None]
             self._engines[idx] = entry

@@ -35,6 +35,13 @@ def _split16(a):
     return hi, lo
 
 
+def q_bf16(a):
+    """round to nearest-even bfloat16 (8 significant bits, fp32's exponent range)"""
+    u = np.asarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32).astype(np.float64)
+
+
 def _q8_blocks(a, block, axis):
     """fp8 with one power-of-two scale per `block` elements along `axis` (block = 0: one per row / pose)"""
     if block == 0:
@@ -59,12 +66,16 @@ def q_i8(a, axis, tie=None):
 
 
 def split_matmul(x, W, mode, block=32):
-    """x [B,K] @ W[N,K]^T under the emulated arithmetic.  mode: 'f16x3' (product), 'f16f8' (cross terms on fp8),
+    """x [B,K] @ W[N,K]^T under the emulated arithmetic.  mode: 'f16x3' (product), 'f16' / 'bf16' (the one-term comparison kernels
+    pndf_fused_half_relu_kernel / pndf_fused_bf16_relu_kernel: tests/test_gpu_parity.py holds them to this model), 'f16f8' (cross terms on fp8),
     'f16i8' (cross terms on int8, every operand with its own per-row / per-pose scale: two v_mfma_i32_16x16x64_i8 with
     separate int32 accumulators), 'f16i8c' (the ONE-instruction form of VERDICT r4 item 2: [Wh | Wl] . [xl ; xh], K = 64, lo
     scales tied to the hi scales by 2^10 so that both products share one int32 scale)."""
     sw = _pow2_scale(W, 2.0 ** 13)                                # per layer
     sx = _pow2_scale(x, 2.0 ** 14, axis=1)                        # per pose
+    if mode in ("f16", "bf16"):     # the ONE-term comparison kernels (precision f16 / bf16): operands rounded once, Wh xh alone
+        rnd = q_bf16 if mode == "bf16" else (lambda a: a.astype(np.float16).astype(np.float64))
+        return ((rnd(x * sx) @ rnd(W * sw).T).astype(np.float32).astype(np.float64) / sx) / sw
     Wh, Wl = _split16(W * sw)
     xh, xl = _split16(x * sx)
     acc = (xh @ Wh.T).astype(np.float32).astype(np.float64)

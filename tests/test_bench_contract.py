@@ -38,8 +38,13 @@ def test_bench_json_line_default_precision():
     assert d["value"] > 0 and d["unit"] == "poses/s" and "workload" in d["config"]
     # the line names its precisions honestly, within what the driver's record keeps of a string
     head = d["config"]["workload"][:120]
-    assert "f16x3 (fp32-split) timed" in head and "fp32 (exact) reported" in head and "bf16 not built" in head
-    assert len("cfg[2] B=65536/GPU x100 steps lrelu: f16x3 (fp32-split) timed, fp32 (exact) reported, bf16 not built (f16 dominates it)") <= 120
+    assert "f16x3 (fp32-split) timed" in head and "fp32 (exact), bf16 (not parity grade) reported" in head
+    assert len("cfg[2] B=65536/GPU x100 steps lrelu: f16x3 (fp32-split) timed; fp32 (exact), bf16 (not parity grade) reported") <= 120
+    # BASELINE.json configs[2] "fp32 vs bf16": both halves in the default line, the bf16 one with its error against the fp64 oracle
+    bf = d["bf16"]
+    assert bf["kernel"] == "pndf_fused_bf16_relu_kernel" and bf["kernel_ms"] > 0
+    assert bf["parity_sample"]["median"] > 10 * d["parity_sample"]["median"] and bf["parity_sample"]["within_tolerance_frac"] < 0.5
+    assert d["roofline"]["bf16_poses_per_s"] == bf["poses_per_s_per_gpu"] and d["roofline"]["bf16_median_rel_err_vs_fp64"] == bf["parity_sample"]["median"]
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
     cb = d["cpu_baseline"]
